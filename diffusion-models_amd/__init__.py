@@ -1,0 +1,25 @@
+"""MI355X-native sampling path for lbarseghyan/diffusion-models.
+
+The directory name carries a hyphen (it is the name the build contract asks
+for); import it as ``diffusion_models_amd`` through the shim at the repo root.
+"""
+from .spec import (  # noqa: F401
+    DecoderConfig,
+    UnetConfig,
+    ddim_time_pairs,
+    decoder_param_spec,
+    make_schedule,
+    unet_param_spec,
+)
+from .synth import synth_state_dict, synth_tensor  # noqa: F401
+
+__all__ = [
+    "UnetConfig",
+    "DecoderConfig",
+    "unet_param_spec",
+    "decoder_param_spec",
+    "make_schedule",
+    "ddim_time_pairs",
+    "synth_state_dict",
+    "synth_tensor",
+]

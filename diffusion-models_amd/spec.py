@@ -1,0 +1,391 @@
+"""Static description of the denoiser and of the noise schedule (host side).
+
+Nothing in this module touches the GPU.  It answers three questions the rest of
+the package (and the tests) need answered identically:
+
+* which tensors a ``DenoisingDiffusion.state_dict()`` holds, with which names and
+  shapes, for a given U-Net configuration            -> :func:`unet_param_spec`
+* which 13 schedule buffers the diffusion wrapper registers -> :func:`make_schedule`
+* which (t, t_next) pairs a DDIM run visits          -> :func:`ddim_time_pairs`
+
+Reference behaviour restated here (paths relative to the reference checkout):
+  denoising-diffusion-pytorch/denoising_diffusion/denoising_diffusion.py
+    :233-343  Unet.__init__          (module tree -> parameter names/shapes)
+    :399-433  linear / cosine / sigmoid beta schedules (fp64)
+    :482-541  DenoisingDiffusion.__init__ buffers (fp64 -> fp32 once)
+    :672-674  ddim time pairs
+  denoising-diffusion-pytorch/denoising_diffusion/denoising_diffusion_text_conditional.py
+    :38-52,:97-125  CrossAttention / text U-Net extra parameters
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+NUM_MEM_KV = 4  # LinearAttention / Attention default (denoising_diffusion.py:156,201)
+
+
+@dataclass(frozen=True)
+class UnetConfig:
+    """Constructor arguments of the reference ``Unet`` that change shapes.
+
+    Mirrors denoising_diffusion.py:234-252 (and the text subclass,
+    denoising_diffusion_text_conditional.py:97).  Options the sampling path
+    never uses with ``DenoisingDiffusion`` (learned sinusoidal embedding,
+    dropout at eval time, flash attention) are deliberately absent.
+    """
+
+    dim: int = 64
+    init_dim: Optional[int] = None
+    out_dim: Optional[int] = None
+    dim_mults: Tuple[int, ...] = (1, 2, 4, 8)
+    channels: int = 3
+    self_condition: bool = False
+    learned_variance: bool = False
+    sinusoidal_pos_emb_theta: float = 10000.0
+    attn_dim_head: int = 32
+    attn_heads: int = 4
+    full_attn: Optional[Tuple[bool, ...]] = None
+    # image-conditional variant widens init_conv (denoising_diffusion_image_conditional.py:42-49)
+    cond_channels: int = 0
+    # text variant
+    text_condition: bool = False
+    use_cross_attn: bool = False
+    text_emb_dim: int = 512
+
+    # ---- derived quantities -------------------------------------------------
+    @property
+    def init_dim_(self) -> int:
+        return self.init_dim if self.init_dim is not None else self.dim
+
+    @property
+    def input_channels(self) -> int:
+        return self.channels * (2 if self.self_condition else 1) + self.cond_channels
+
+    @property
+    def out_dim_(self) -> int:
+        if self.out_dim is not None:
+            return self.out_dim
+        return self.channels * (2 if self.learned_variance else 1)
+
+    @property
+    def time_dim(self) -> int:
+        return self.dim * 4
+
+    @property
+    def dims(self) -> List[int]:
+        return [self.init_dim_, *[self.dim * m for m in self.dim_mults]]
+
+    @property
+    def in_out(self) -> List[Tuple[int, int]]:
+        d = self.dims
+        return list(zip(d[:-1], d[1:]))
+
+    @property
+    def num_stages(self) -> int:
+        return len(self.dim_mults)
+
+    @property
+    def full_attn_(self) -> Tuple[bool, ...]:
+        # denoising_diffusion.py:289-293: full attention only in the innermost stage
+        if not self.full_attn:
+            return (*((False,) * (self.num_stages - 1)), True)
+        return tuple(self.full_attn)
+
+    @property
+    def hidden_dim(self) -> int:
+        return self.attn_dim_head * self.attn_heads
+
+    @property
+    def downsample_factor(self) -> int:
+        return 2 ** (self.num_stages - 1)
+
+
+ParamSpec = List[Tuple[str, Tuple[int, ...]]]
+
+
+def _resnet_spec(prefix: str, din: int, dout: int, time_dim: int) -> ParamSpec:
+    s: ParamSpec = [
+        (f"{prefix}.mlp.1.weight", (dout * 2, time_dim)),
+        (f"{prefix}.mlp.1.bias", (dout * 2,)),
+        (f"{prefix}.block1.proj.weight", (dout, din, 3, 3)),
+        (f"{prefix}.block1.proj.bias", (dout,)),
+        (f"{prefix}.block1.norm.g", (1, dout, 1, 1)),
+        (f"{prefix}.block2.proj.weight", (dout, dout, 3, 3)),
+        (f"{prefix}.block2.proj.bias", (dout,)),
+        (f"{prefix}.block2.norm.g", (1, dout, 1, 1)),
+    ]
+    if din != dout:
+        s += [
+            (f"{prefix}.res_conv.weight", (dout, din, 1, 1)),
+            (f"{prefix}.res_conv.bias", (dout,)),
+        ]
+    return s
+
+
+def _attn_spec(prefix: str, dim: int, full: bool, heads: int, dim_head: int) -> ParamSpec:
+    hidden = heads * dim_head
+    if full:
+        return [
+            (f"{prefix}.mem_kv", (2, heads, NUM_MEM_KV, dim_head)),
+            (f"{prefix}.norm.g", (1, dim, 1, 1)),
+            (f"{prefix}.to_qkv.weight", (hidden * 3, dim, 1, 1)),
+            (f"{prefix}.to_out.weight", (dim, hidden, 1, 1)),
+            (f"{prefix}.to_out.bias", (dim,)),
+        ]
+    return [
+        (f"{prefix}.mem_kv", (2, heads, dim_head, NUM_MEM_KV)),
+        (f"{prefix}.norm.g", (1, dim, 1, 1)),
+        (f"{prefix}.to_qkv.weight", (hidden * 3, dim, 1, 1)),
+        (f"{prefix}.to_out.0.weight", (dim, hidden, 1, 1)),
+        (f"{prefix}.to_out.0.bias", (dim,)),
+        (f"{prefix}.to_out.1.g", (1, dim, 1, 1)),
+    ]
+
+
+def _cross_attn_spec(prefix: str, dim: int, ctx: int, heads: int, dim_head: int) -> ParamSpec:
+    inner = heads * dim_head
+    return [
+        (f"{prefix}.to_q.weight", (inner, dim)),
+        (f"{prefix}.to_k.weight", (inner, ctx)),
+        (f"{prefix}.to_v.weight", (inner, ctx)),
+        (f"{prefix}.to_out.0.weight", (dim, inner)),
+        (f"{prefix}.to_out.0.bias", (dim,)),
+        (f"{prefix}.to_out.1.g", (1, dim)),
+    ]
+
+
+def unet_param_spec(cfg: UnetConfig, prefix: str = "") -> ParamSpec:
+    """(name, shape) of every U-Net parameter, in ``state_dict()`` order."""
+    p = prefix
+    td = cfg.time_dim
+    spec: ParamSpec = [
+        (f"{p}init_conv.weight", (cfg.init_dim_, cfg.input_channels, 7, 7)),
+        (f"{p}init_conv.bias", (cfg.init_dim_,)),
+        (f"{p}time_mlp.1.weight", (td, cfg.dim)),
+        (f"{p}time_mlp.1.bias", (td,)),
+        (f"{p}time_mlp.3.weight", (td, td)),
+        (f"{p}time_mlp.3.bias", (td,)),
+    ]
+    n = len(cfg.in_out)
+    for i, ((din, dout), full) in enumerate(zip(cfg.in_out, cfg.full_attn_)):
+        last = i >= n - 1
+        spec += _resnet_spec(f"{p}downs.{i}.0", din, din, td)
+        spec += _resnet_spec(f"{p}downs.{i}.1", din, din, td)
+        spec += _attn_spec(f"{p}downs.{i}.2", din, full, cfg.attn_heads, cfg.attn_dim_head)
+        if not last:
+            spec += [(f"{p}downs.{i}.3.1.weight", (dout, din * 4, 1, 1)), (f"{p}downs.{i}.3.1.bias", (dout,))]
+        else:
+            spec += [(f"{p}downs.{i}.3.weight", (dout, din, 3, 3)), (f"{p}downs.{i}.3.bias", (dout,))]
+    mid = cfg.dims[-1]
+    for j, ((din, dout), full) in enumerate(zip(reversed(cfg.in_out), reversed(cfg.full_attn_))):
+        last = j == n - 1
+        spec += _resnet_spec(f"{p}ups.{j}.0", dout + din, dout, td)
+        spec += _resnet_spec(f"{p}ups.{j}.1", dout + din, dout, td)
+        spec += _attn_spec(f"{p}ups.{j}.2", dout, full, cfg.attn_heads, cfg.attn_dim_head)
+        if not last:
+            spec += [(f"{p}ups.{j}.3.1.weight", (din, dout, 3, 3)), (f"{p}ups.{j}.3.1.bias", (din,))]
+        else:
+            spec += [(f"{p}ups.{j}.3.weight", (din, dout, 3, 3)), (f"{p}ups.{j}.3.bias", (din,))]
+    # ModuleLists `downs` and `ups` are registered before the mid blocks (:306-307)
+    spec += _resnet_spec(f"{p}mid_block1", mid, mid, td)
+    spec += _attn_spec(f"{p}mid_attn", mid, True, cfg.attn_heads, cfg.attn_dim_head)
+    spec += _resnet_spec(f"{p}mid_block2", mid, mid, td)
+    spec += _resnet_spec(f"{p}final_res_block", cfg.init_dim_ * 2, cfg.init_dim_, td)
+    spec += [
+        (f"{p}final_conv.weight", (cfg.out_dim_, cfg.init_dim_, 1, 1)),
+        (f"{p}final_conv.bias", (cfg.out_dim_,)),
+    ]
+    if cfg.text_condition and not cfg.use_cross_attn:
+        spec += [
+            (f"{p}text_proj.0.weight", (td, cfg.text_emb_dim)),
+            (f"{p}text_proj.0.bias", (td,)),
+            (f"{p}text_proj.2.weight", (td, td)),
+            (f"{p}text_proj.2.bias", (td,)),
+            (f"{p}text_concat_proj.weight", (td, td * 2)),
+            (f"{p}text_concat_proj.bias", (td,)),
+        ]
+    if cfg.text_condition and cfg.use_cross_attn:
+        for name in ("cross_attn", "cross_attn_down", "cross_attn_up"):
+            spec += _cross_attn_spec(f"{p}{name}", mid, cfg.text_emb_dim, 4, cfg.attn_dim_head)
+    return spec
+
+
+# ----------------------------------------------------------------------------
+# schedule
+# ----------------------------------------------------------------------------
+
+SCHEDULE_BUFFERS = (
+    "betas",
+    "alphas_cumprod",
+    "alphas_cumprod_prev",
+    "sqrt_alphas_cumprod",
+    "sqrt_one_minus_alphas_cumprod",
+    "log_one_minus_alphas_cumprod",
+    "sqrt_recip_alphas_cumprod",
+    "sqrt_recipm1_alphas_cumprod",
+    "posterior_variance",
+    "posterior_log_variance_clipped",
+    "posterior_mean_coef1",
+    "posterior_mean_coef2",
+    "loss_weight",
+)
+
+
+def _betas(name: str, timesteps: int, **kw) -> torch.Tensor:
+    f64 = torch.float64
+    if name == "linear":  # denoising_diffusion.py:399-406
+        scale = 1000 / timesteps
+        return torch.linspace(scale * 0.0001, scale * 0.02, timesteps, dtype=f64)
+    steps = timesteps + 1
+    t = torch.linspace(0, timesteps, steps, dtype=f64) / timesteps
+    if name == "cosine":  # :408-418
+        s = kw.get("s", 0.008)
+        ac = torch.cos((t + s) / (1 + s) * math.pi * 0.5) ** 2
+    elif name == "sigmoid":  # :420-433
+        start, end, tau = kw.get("start", -3), kw.get("end", 3), kw.get("tau", 1)
+        v_start = torch.tensor(start / tau).sigmoid()
+        v_end = torch.tensor(end / tau).sigmoid()
+        ac = (-((t * (end - start) + start) / tau).sigmoid() + v_end) / (v_end - v_start)
+    else:
+        raise ValueError(f"unknown beta schedule {name}")
+    ac = ac / ac[0]
+    return torch.clip(1 - (ac[1:] / ac[:-1]), 0, 0.999)
+
+
+def make_schedule(timesteps: int = 1000, beta_schedule: str = "linear", **schedule_fn_kwargs) -> Dict[str, torch.Tensor]:
+    """The 13 fp32 buffers of ``DenoisingDiffusion`` (ddpm=True loss weight)."""
+    betas = _betas(beta_schedule, timesteps, **schedule_fn_kwargs)
+    alphas = 1.0 - betas
+    ac = torch.cumprod(alphas, dim=0)
+    ac_prev = torch.cat([torch.ones(1, dtype=torch.float64), ac[:-1]])
+    post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+    f64 = {
+        "betas": betas,
+        "alphas_cumprod": ac,
+        "alphas_cumprod_prev": ac_prev,
+        "sqrt_alphas_cumprod": torch.sqrt(ac),
+        "sqrt_one_minus_alphas_cumprod": torch.sqrt(1.0 - ac),
+        "log_one_minus_alphas_cumprod": torch.log(1.0 - ac),
+        "sqrt_recip_alphas_cumprod": torch.sqrt(1.0 / ac),
+        "sqrt_recipm1_alphas_cumprod": torch.sqrt(1.0 / ac - 1),
+        "posterior_variance": post_var,
+        "posterior_log_variance_clipped": torch.log(post_var.clamp(min=1e-20)),
+        "posterior_mean_coef1": betas * torch.sqrt(ac_prev) / (1.0 - ac),
+        "posterior_mean_coef2": (1.0 - ac_prev) * torch.sqrt(alphas) / (1.0 - ac),
+        "loss_weight": torch.ones(timesteps, dtype=torch.float64),
+    }
+    return {k: v.to(torch.float32) for k, v in f64.items()}
+
+
+def ddim_time_pairs(total_timesteps: int, sampling_timesteps: int) -> List[Tuple[int, int]]:
+    """[(t, t_next)] as visited by ddim_sample (denoising_diffusion.py:672-674)."""
+    times = torch.linspace(-1, total_timesteps - 1, steps=sampling_timesteps + 1)
+    times = list(reversed(times.int().tolist()))
+    return list(zip(times[:-1], times[1:]))
+
+
+def ddim_step_coefficients(alphas_cumprod: torch.Tensor, t: int, t_next: int, eta: float) -> Tuple[float, float, float]:
+    """(sqrt(alpha_next), c, sigma) as fp32 numbers, computed the way the
+    reference does on 0-dim fp32 tensors (denoising_diffusion.py:691-695)."""
+    alpha = alphas_cumprod[t]
+    alpha_next = alphas_cumprod[t_next]
+    sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+    c = (1 - alpha_next - sigma ** 2).sqrt()
+    return float(alpha_next.sqrt()), float(c), float(sigma)
+
+
+# ----------------------------------------------------------------------------
+# VAE decoder (LDM)
+# ----------------------------------------------------------------------------
+
+
+@dataclass(frozen=True)
+class DecoderConfig:
+    """``ddconfig`` keys the Decoder reads (latent-diffusion/ldm/modules/diffusionmodules/model.py:476-550)."""
+
+    ch: int = 64
+    out_ch: int = 3
+    ch_mult: Tuple[int, ...] = (1, 2)
+    num_res_blocks: int = 2
+    attn_resolutions: Tuple[int, ...] = ()
+    resolution: int = 32
+    z_channels: int = 3
+    embed_dim: int = 3  # VQModel.post_quant_conv: embed_dim -> z_channels (autoencoder.py:53)
+
+    @property
+    def num_resolutions(self) -> int:
+        return len(self.ch_mult)
+
+    @property
+    def z_res(self) -> int:
+        return self.resolution // 2 ** (self.num_resolutions - 1)
+
+
+def _vae_resblock_spec(prefix: str, cin: int, cout: int) -> ParamSpec:
+    s: ParamSpec = [
+        (f"{prefix}.norm1.weight", (cin,)),
+        (f"{prefix}.norm1.bias", (cin,)),
+        (f"{prefix}.conv1.weight", (cout, cin, 3, 3)),
+        (f"{prefix}.conv1.bias", (cout,)),
+        (f"{prefix}.norm2.weight", (cout,)),
+        (f"{prefix}.norm2.bias", (cout,)),
+        (f"{prefix}.conv2.weight", (cout, cout, 3, 3)),
+        (f"{prefix}.conv2.bias", (cout,)),
+    ]
+    if cin != cout:
+        s += [(f"{prefix}.nin_shortcut.weight", (cout, cin, 1, 1)), (f"{prefix}.nin_shortcut.bias", (cout,))]
+    return s
+
+
+def _vae_attn_spec(prefix: str, c: int) -> ParamSpec:
+    s: ParamSpec = [(f"{prefix}.norm.weight", (c,)), (f"{prefix}.norm.bias", (c,))]
+    for n in ("q", "k", "v", "proj_out"):
+        s += [(f"{prefix}.{n}.weight", (c, c, 1, 1)), (f"{prefix}.{n}.bias", (c,))]
+    return s
+
+
+def decoder_param_spec(cfg: DecoderConfig, prefix: str = "") -> ParamSpec:
+    """Parameters of ``VQModel.post_quant_conv`` + ``VQModel.decoder``."""
+    p = prefix
+    block_in = cfg.ch * cfg.ch_mult[-1]
+    spec: ParamSpec = [
+        (f"{p}post_quant_conv.weight", (cfg.z_channels, cfg.embed_dim, 1, 1)),
+        (f"{p}post_quant_conv.bias", (cfg.z_channels,)),
+        (f"{p}decoder.conv_in.weight", (block_in, cfg.z_channels, 3, 3)),
+        (f"{p}decoder.conv_in.bias", (block_in,)),
+    ]
+    spec += _vae_resblock_spec(f"{p}decoder.mid.block_1", block_in, block_in)
+    spec += _vae_attn_spec(f"{p}decoder.mid.attn_1", block_in)
+    spec += _vae_resblock_spec(f"{p}decoder.mid.block_2", block_in, block_in)
+    curr_res = cfg.z_res
+    per_level: Dict[int, ParamSpec] = {}
+    for lvl in reversed(range(cfg.num_resolutions)):
+        block_out = cfg.ch * cfg.ch_mult[lvl]
+        s: ParamSpec = []
+        attn: ParamSpec = []
+        for b in range(cfg.num_res_blocks + 1):
+            s += _vae_resblock_spec(f"{p}decoder.up.{lvl}.block.{b}", block_in, block_out)
+            block_in = block_out
+            if curr_res in cfg.attn_resolutions:
+                attn += _vae_attn_spec(f"{p}decoder.up.{lvl}.attn.{b}", block_in)
+        s += attn
+        if lvl != 0:
+            s += [
+                (f"{p}decoder.up.{lvl}.upsample.conv.weight", (block_in, block_in, 3, 3)),
+                (f"{p}decoder.up.{lvl}.upsample.conv.bias", (block_in,)),
+            ]
+            curr_res *= 2
+        per_level[lvl] = s
+    for lvl in range(cfg.num_resolutions):  # ModuleList order after the insert(0, …) calls
+        spec += per_level[lvl]
+    spec += [
+        (f"{p}decoder.norm_out.weight", (block_in,)),
+        (f"{p}decoder.norm_out.bias", (block_in,)),
+        (f"{p}decoder.conv_out.weight", (cfg.out_ch, block_in, 3, 3)),
+        (f"{p}decoder.conv_out.bias", (cfg.out_ch,)),
+    ]
+    return spec

@@ -1,0 +1,134 @@
+"""ORACLE -- test infrastructure, not product code.
+
+CPU restatement of the reference DDPM / DDIM sampling loops with *injected*
+noise, so that two implementations can be compared on identical random draws.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module.
+
+Pinned by ``tests/golden/sampler_*.pt`` (outputs of the reference's own
+``p_sample_loop`` / ``ddim_sample`` with ``torch.randn`` / ``randn_like``
+redirected to the same seeded stream; see ``tests/golden/make_golden.py``).
+
+DD = denoising-diffusion-pytorch/denoising_diffusion/ in the reference checkout.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+Model = Callable[[torch.Tensor, torch.Tensor], torch.Tensor]
+
+
+class NoiseStream:
+    """Sequential N(0,1) draws from one seeded CPU generator.
+
+    Draw 0 is x_T; draw i (i>=1) is the noise of loop iteration i-1, in the
+    order the reference calls ``torch.randn`` / ``torch.randn_like``
+    (DD/denoising_diffusion.py:651,643 and :676,697).
+    """
+
+    def __init__(self, seed: int):
+        self.g = torch.Generator(device="cpu")
+        self.g.manual_seed(seed)
+
+    def __call__(self, shape) -> torch.Tensor:
+        return torch.randn(tuple(shape), generator=self.g, dtype=torch.float32)
+
+
+def _tbl(sched: Dict[str, torch.Tensor], name: str, t: int) -> torch.Tensor:
+    # `extract` (DD/denoising_diffusion.py:394-397) with a batch-constant t
+    return sched[name][t]
+
+
+def predict_start_from_noise(sched, x_t, t: int, noise):
+    """DD/denoising_diffusion.py:570-574."""
+    return _tbl(sched, "sqrt_recip_alphas_cumprod", t) * x_t - _tbl(sched, "sqrt_recipm1_alphas_cumprod", t) * noise
+
+
+def predict_noise_from_start(sched, x_t, t: int, x0):
+    """DD/denoising_diffusion.py:576-580."""
+    return (_tbl(sched, "sqrt_recip_alphas_cumprod", t) * x_t - x0) / _tbl(sched, "sqrt_recipm1_alphas_cumprod", t)
+
+
+def p_sample(model: Model, sched, x: torch.Tensor, t: int, noise: Optional[torch.Tensor]):
+    """DD/denoising_diffusion.py:638-645 (+ :628-636, :594-601) for objective pred_noise."""
+    b = x.shape[0]
+    bt = torch.full((b,), t, dtype=torch.long)
+    eps = model(x, bt)
+    x0 = predict_start_from_noise(sched, x, t, eps).clamp(-1.0, 1.0)
+    mean = _tbl(sched, "posterior_mean_coef1", t) * x0 + _tbl(sched, "posterior_mean_coef2", t) * x
+    logvar = _tbl(sched, "posterior_log_variance_clipped", t)
+    if t > 0:
+        return mean + (0.5 * logvar).exp() * noise, x0
+    return mean + (0.5 * logvar).exp() * 0.0, x0
+
+
+@torch.inference_mode()
+def p_sample_loop(
+    model: Model,
+    sched,
+    shape,
+    noise: Callable,
+    unnormalize: bool = True,
+    return_all_timesteps: bool = False,
+    num_steps: Optional[int] = None,
+):
+    """DD/denoising_diffusion.py:647-664.  ``num_steps`` (oracle-only) stops
+    after that many iterations, for timing a bounded sample of the loop."""
+    T = sched["betas"].shape[0]
+    img = noise(shape)
+    imgs = [img]
+    done = 0
+    for t in reversed(range(T)):
+        z = noise(shape) if t > 0 else None
+        img, _ = p_sample(model, sched, img, t, z)
+        imgs.append(img)
+        done += 1
+        if num_steps is not None and done >= num_steps:
+            break
+    ret = img if not return_all_timesteps else torch.stack(imgs, dim=1)
+    return (ret + 1) * 0.5 if unnormalize else ret
+
+
+def ddim_pairs(T: int, S: int) -> List[Tuple[int, int]]:
+    """DD/denoising_diffusion.py:672-674."""
+    times = torch.linspace(-1, T - 1, steps=S + 1)
+    times = list(reversed(times.int().tolist()))
+    return list(zip(times[:-1], times[1:]))
+
+
+@torch.inference_mode()
+def ddim_sample(
+    model: Model,
+    sched,
+    shape,
+    noise: Callable,
+    sampling_timesteps: int,
+    eta: float = 0.0,
+    unnormalize: bool = True,
+    return_all_timesteps: bool = False,
+):
+    """DD/denoising_diffusion.py:666-708 for objective pred_noise."""
+    T = sched["betas"].shape[0]
+    b = shape[0]
+    img = noise(shape)
+    imgs = [img]
+    ac = sched["alphas_cumprod"]
+    for t, t_next in ddim_pairs(T, sampling_timesteps):
+        bt = torch.full((b,), t, dtype=torch.long)
+        eps = model(img, bt)
+        x0 = predict_start_from_noise(sched, img, t, eps).clamp(-1.0, 1.0)
+        eps = predict_noise_from_start(sched, img, t, x0)
+        if t_next < 0:
+            img = x0
+            imgs.append(img)
+            continue
+        alpha, alpha_next = ac[t], ac[t_next]
+        sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+        c = (1 - alpha_next - sigma ** 2).sqrt()
+        z = noise(shape)  # drawn even when sigma == 0 (DD/denoising_diffusion.py:697)
+        img = x0 * alpha_next.sqrt() + c * eps + sigma * z
+        imgs.append(img)
+    ret = img if not return_all_timesteps else torch.stack(imgs, dim=1)
+    return (ret + 1) * 0.5 if unnormalize else ret

@@ -1,0 +1,55 @@
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # -m gpu tests are skipped (not failed) when collected without a GPU and without -m selection
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    return torch.load(os.path.join(GOLDEN, name), weights_only=True)
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="session")
+def golden_blocks():
+    return load_golden("blocks.pt")
+
+
+@pytest.fixture(scope="session")
+def golden_samplers():
+    return load_golden("samplers.pt")
+
+
+@pytest.fixture(scope="session")
+def golden_vae():
+    return load_golden("vae.pt")
+
+
+@pytest.fixture(scope="session")
+def golden_schedule():
+    return load_golden("schedule.pt")

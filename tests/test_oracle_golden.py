@@ -1,0 +1,205 @@
+"""The oracle (oracle/*.py) against the vectors generated from the reference
+itself (tests/golden/make_golden.py).  CPU only.
+
+Tolerance: the oracle uses the same ATen CPU ops as the reference in a slightly
+different composition, so agreement is at fp32 rounding level (<= 1e-5 rel-L2;
+measured ~1e-7)."""
+import json
+import os
+
+import pytest
+import torch
+
+import diffusion_models_amd as dm
+from diffusion_models_amd.spec import DecoderConfig, UnetConfig
+from oracle import sampler_oracle as so
+from oracle import unet_oracle as uo
+from oracle import vae_oracle as vo
+
+from conftest import GOLDEN, rel_l2
+
+TOL = 1e-5
+
+SMALL = UnetConfig(dim=32, dim_mults=(1, 2), channels=3)
+SMALL_TC = UnetConfig(dim=32, dim_mults=(1, 2), channels=3, text_condition=True, use_cross_attn=True)
+SMALL_TCAT = UnetConfig(dim=32, dim_mults=(1, 2), channels=3, text_condition=True, use_cross_attn=False)
+
+
+@pytest.fixture(scope="module")
+def small_sd():
+    return dm.synth_state_dict(dm.unet_param_spec(SMALL), salt=1)
+
+
+def test_state_dict_keys_match_reference():
+    with open(os.path.join(GOLDEN, "state_dict_keys.json")) as f:
+        keys = json.load(f)
+    cases = {
+        "unet_full": dm.unet_param_spec(UnetConfig()),
+        "unet_text_cross": dm.unet_param_spec(UnetConfig(text_condition=True, use_cross_attn=True)),
+        "unet_text_concat_d32": dm.unet_param_spec(SMALL_TCAT),
+        "decoder_cifar": [kv for kv in dm.decoder_param_spec(DecoderConfig()) if kv[0].startswith("decoder.")],
+    }
+    for name, spec in cases.items():
+        ref = {k: tuple(s) for k, s in keys[name]}
+        ours = {k: tuple(s) for k, s in spec}
+        assert ours == ref, name
+    # same order as state_dict() for the U-Net
+    assert [k for k, _ in keys["unet_full"]] == [k for k, _ in cases["unet_full"]]
+
+
+def test_schedule_tables(golden_schedule):
+    for name, kw in (("linear", {}), ("cosine", {}), ("sigmoid", {})):
+        ours = dm.make_schedule(1000, name)
+        ref = golden_schedule["sched"][name]
+        assert set(ours) == set(ref)
+        for k in ref:
+            assert torch.equal(ours[k], ref[k]), (name, k)
+    ours = dm.make_schedule(250, "linear")
+    for k, v in golden_schedule["sched"]["linear250"].items():
+        assert torch.equal(ours[k], v), k
+
+
+def test_schedule_known_answers():
+    # linear beta, T=1000, indices (0, 1, 499, 999)
+    s = dm.make_schedule(1000, "linear")
+    idx = [0, 1, 499, 999]
+    known = {
+        "betas": [1.0e-4, 1.19920e-4, 1.004004e-2, 2.0e-2],
+        "alphas_cumprod": [0.99989998, 0.99978012, 0.078587241, 4.0358296e-5],
+        "posterior_variance": [0, 5.4531876e-5, 1.0031356e-2, 1.9999983e-2],
+        "posterior_log_variance_clipped": [-46.0517006, -9.81672478, -4.60203934, -3.91202378],
+        "posterior_mean_coef1": [1.0, 0.54529148, 3.0700711e-3, 1.2835149e-4],
+        "posterior_mean_coef2": [0, 0.45470849, 0.99410665, 0.98994869],
+        "sqrt_recip_alphas_cumprod": [1.00004995, 1.00011003, 3.56717134, 157.410461],
+        "sqrt_recipm1_alphas_cumprod": [0.0100005, 0.01483092, 3.42413664, 157.407288],
+    }
+    for k, vals in known.items():
+        got = s[k][idx].double()
+        assert torch.allclose(got, torch.tensor(vals, dtype=torch.float64), rtol=2e-6, atol=1e-12), k
+
+
+def test_ddim_pairs(golden_schedule):
+    for key, ref in golden_schedule["ddim_pairs"].items():
+        T, S = map(int, key.split("_"))
+        assert dm.ddim_time_pairs(T, S) == [tuple(p) for p in ref]
+        assert so.ddim_pairs(T, S) == [tuple(p) for p in ref]
+    p = dm.ddim_time_pairs(1000, 50)
+    assert p[0] == (999, 979) and p[-1] == (19, -1) and len(p) == 50
+
+
+def test_blocks(golden_blocks, small_sd):
+    g, sd = golden_blocks, small_sd
+    assert rel_l2(uo.rms_norm(g["rmsnorm"]["x"], g["rmsnorm"]["g"]), g["rmsnorm"]["y"]) < TOL
+    assert rel_l2(uo.block(sd, "downs.0.0.block2", g["block_plain"]["x"]), g["block_plain"]["y"]) < TOL
+    b = g["block_ss"]
+    assert rel_l2(uo.block(sd, "downs.0.0.block1", b["x"], (b["scale"], b["shift"])), b["y"]) < TOL
+    b = g["resnet_same"]
+    assert rel_l2(uo.resnet_block(sd, "downs.0.0", b["x"], b["temb"]), b["y"]) < TOL
+    b = g["resnet_resconv"]
+    assert rel_l2(uo.resnet_block(sd, "ups.0.0", b["x"], b["temb"]), b["y"]) < TOL
+    b = g["linattn"]
+    assert rel_l2(uo.linear_attention(sd, "downs.0.2", b["x"], 4, 32), b["y"]) < TOL
+    b = g["fullattn"]
+    assert rel_l2(uo.full_attention(sd, "mid_attn", b["x"], 4, 32), b["y"]) < TOL
+    b = g["downsample"]
+    assert rel_l2(uo.downsample(sd, "downs.0.3", b["x"]), b["y"]) < TOL
+    b = g["upsample"]
+    assert rel_l2(uo.upsample(sd, "ups.0.3", b["x"]), b["y"]) < TOL
+    b = g["sinusoid"]
+    assert rel_l2(uo.sinusoidal_pos_emb(b["t"], 32), b["y"]) < TOL
+    b = g["time_mlp"]
+    assert rel_l2(uo.time_mlp(sd, "", b["t"], 32, 10000.0), b["y"]) < TOL
+    b = g["unet_small"]
+    assert rel_l2(uo.unet_forward(sd, SMALL, b["x"], b["t"]), b["y"]) < TOL
+
+
+def test_text_blocks(golden_blocks):
+    g = golden_blocks
+    sd = dm.synth_state_dict(dm.unet_param_spec(SMALL_TC), salt=2)
+    for key in ("cross_m1", "cross_m3"):
+        b = g[key]
+        assert rel_l2(uo.cross_attention(sd, "cross_attn", b["x"], b["ctx"]), b["y"]) < TOL
+    for key in ("unet_text_cross", "unet_text_cross_m3"):
+        b = g[key]
+        assert rel_l2(uo.unet_forward(sd, SMALL_TC, b["x"], b["t"], text_emb=b["ctx"]), b["y"]) < TOL
+    sd = dm.synth_state_dict(dm.unet_param_spec(SMALL_TCAT), salt=3)
+    b = g["unet_text_concat"]
+    assert rel_l2(uo.unet_forward(sd, SMALL_TCAT, b["x"], b["t"], text_emb=b["ctx"]), b["y"]) < TOL
+
+
+def test_cross_attention_single_token_ignores_image(golden_blocks):
+    # with one context token softmax == 1 and x drops out.
+    sd = dm.synth_state_dict(dm.unet_param_spec(SMALL_TC), salt=2)
+    b = golden_blocks["cross_m1"]
+    y1 = uo.cross_attention(sd, "cross_attn", b["x"], b["ctx"])
+    y2 = uo.cross_attention(sd, "cross_attn", torch.randn_like(b["x"]), b["ctx"])
+    assert torch.equal(y1, y2)
+
+
+def test_vae(golden_vae):
+    cfg = DecoderConfig()
+    sd = dm.synth_state_dict(dm.decoder_param_spec(cfg), salt=4)
+    g = golden_vae
+    assert rel_l2(vo.vae_resnet_block(sd, "decoder.mid.block_1", g["resblock"]["x"]), g["resblock"]["y"]) < TOL
+    assert rel_l2(vo.vae_attn_block(sd, "decoder.mid.attn_1", g["attnblock"]["x"]), g["attnblock"]["y"]) < TOL
+    assert rel_l2(vo.vae_resnet_block(sd, "decoder.up.0.block.0", g["resblock_nin"]["x"]), g["resblock_nin"]["y"]) < TOL
+    assert rel_l2(vo.vq_decode(sd, cfg, g["decode_cifar"]["z"]), g["decode_cifar"]["y"]) < TOL
+    cfg2 = DecoderConfig(ch=32, ch_mult=(1, 2, 4), num_res_blocks=1, attn_resolutions=(8,), resolution=16,
+                         z_channels=4, embed_dim=4)
+    sd2 = dm.synth_state_dict(dm.decoder_param_spec(cfg2), salt=5)
+    assert rel_l2(vo.vq_decode(sd2, cfg2, g["decode_attn3"]["z"]), g["decode_attn3"]["y"]) < TOL
+
+
+def _small_model(sd):
+    return lambda x, t: uo.unet_forward(sd, SMALL, x, t)
+
+
+def test_samplers_small(golden_samplers, small_sd):
+    g = golden_samplers
+    model = _small_model(small_sd)
+    sched = dm.make_schedule(1000, "linear")
+    b = g["small_ddim50"]
+    y = so.ddim_sample(model, sched, b["shape"], so.NoiseStream(b["seed"]), b["S"], eta=b["eta"])
+    assert rel_l2(y, b["y"]) < 1e-4
+    b = g["small_ddim20_eta"]
+    y = so.ddim_sample(model, sched, b["shape"], so.NoiseStream(b["seed"]), b["S"], eta=b["eta"])
+    assert rel_l2(y, b["y"]) < 1e-4
+    b = g["small_ddpm50_all"]
+    y = so.p_sample_loop(model, dm.make_schedule(50, "linear"), b["shape"], so.NoiseStream(b["seed"]),
+                         return_all_timesteps=True)
+    assert y.shape == b["y"].shape == (1, 51, 3, 16, 16)
+    assert rel_l2(y, b["y"]) < 1e-4
+
+
+@pytest.mark.slow
+def test_sampler_small_ddpm1000(golden_samplers, small_sd):
+    b = golden_samplers["small_ddpm1000"]
+    y = so.p_sample_loop(_small_model(small_sd), dm.make_schedule(1000, "linear"), b["shape"],
+                         so.NoiseStream(b["seed"]))
+    assert rel_l2(y, b["y"]) < 1e-4
+
+
+def test_unet_full_config(golden_samplers):
+    cfg = UnetConfig()
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=0)
+    b = golden_samplers["unet_full_32"]
+    assert rel_l2(uo.unet_forward(sd, cfg, b["x"], b["t"]), b["y"]) < TOL
+    b = golden_samplers["unet_full_64"]
+    assert rel_l2(uo.unet_forward(sd, cfg, b["x"], b["t"]), b["y"]) < TOL
+    tcfg = UnetConfig(text_condition=True, use_cross_attn=True)
+    tsd = dm.synth_state_dict(dm.unet_param_spec(tcfg), salt=0)
+    b = golden_samplers["unet_text_full_32"]
+    assert rel_l2(uo.unet_forward(tsd, tcfg, b["x"], b["t"], text_emb=b["ctx"]), b["y"]) < TOL
+    lcfg = UnetConfig(channels=4)
+    lsd = dm.synth_state_dict(dm.unet_param_spec(lcfg), salt=0)
+    b = golden_samplers["unet_latent4_32"]
+    assert rel_l2(uo.unet_forward(lsd, lcfg, b["x"], b["t"]), b["y"]) < TOL
+
+
+def test_full_ddim50(golden_samplers):
+    cfg = UnetConfig()
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=0)
+    b = golden_samplers["full_ddim50"]
+    y = so.ddim_sample(lambda x, t: uo.unet_forward(sd, cfg, x, t), dm.make_schedule(1000, "linear"),
+                       b["shape"], so.NoiseStream(b["seed"]), b["S"], eta=b["eta"])
+    assert rel_l2(y, b["y"]) < 1e-4
