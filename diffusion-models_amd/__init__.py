@@ -12,8 +12,20 @@ from .spec import (  # noqa: F401
     unet_param_spec,
 )
 from .synth import synth_state_dict, synth_tensor  # noqa: F401
+from .unet import Unet  # noqa: F401
+from .diffusion import DenoisingDiffusion, LatentDiffusion, TextConditionalDenoisingDiffusion  # noqa: F401
+from .vae import VQDecoder  # noqa: F401
+from .dist import gather_shards, sample_sharded, shard_bounds  # noqa: F401
 
 __all__ = [
+    "Unet",
+    "DenoisingDiffusion",
+    "TextConditionalDenoisingDiffusion",
+    "LatentDiffusion",
+    "VQDecoder",
+    "sample_sharded",
+    "gather_shards",
+    "shard_bounds",
     "UnetConfig",
     "DecoderConfig",
     "unet_param_spec",

@@ -1,0 +1,112 @@
+"""ctypes binding of libdm_hip.so (C ABI declared in include/dm_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails the
+error is raised, never swallowed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdm_hip.so")
+DM_MAX_STAGES = 8
+DM_COEFS = 8
+ABI_VERSION = 1
+
+# every symbol include/dm_hip.h declares (tests check the library exports all of them)
+EXPORTS = (
+    "dm_last_error", "dm_abi_version",
+    "dm_unet_create", "dm_unet_destroy", "dm_unet_set_param", "dm_unet_missing_params", "dm_unet_finalize",
+    "dm_unet_forward", "dm_sample", "dm_randn",
+    "dm_decoder_create", "dm_decoder_destroy", "dm_decoder_set_param", "dm_decoder_missing_params",
+    "dm_decoder_finalize", "dm_decoder_forward",
+    "dm_op_conv2d", "dm_op_downsample", "dm_op_rmsnorm", "dm_op_block", "dm_op_linear_attention",
+    "dm_op_attention", "dm_op_sampler_update",
+)
+
+
+class UnetCfg(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int32), ("init_dim", C.c_int32), ("out_dim", C.c_int32), ("channels", C.c_int32),
+        ("input_channels", C.c_int32), ("n_stages", C.c_int32),
+        ("dim_mults", C.c_int32 * DM_MAX_STAGES), ("full_attn", C.c_int32 * DM_MAX_STAGES),
+        ("attn_heads", C.c_int32), ("attn_dim_head", C.c_int32),
+        ("text_mode", C.c_int32), ("text_emb_dim", C.c_int32), ("sinusoidal_theta", C.c_float),
+    ]
+
+
+class DecoderCfg(C.Structure):
+    _fields_ = [
+        ("ch", C.c_int32), ("out_ch", C.c_int32), ("n_levels", C.c_int32), ("ch_mult", C.c_int32 * DM_MAX_STAGES),
+        ("num_res_blocks", C.c_int32), ("n_attn_res", C.c_int32), ("attn_resolutions", C.c_int32 * DM_MAX_STAGES),
+        ("resolution", C.c_int32), ("z_channels", C.c_int32), ("embed_dim", C.c_int32),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def _declare(lib: C.CDLL) -> None:
+    vp, i32, i64, u64, fp = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_void_p
+    lib.dm_last_error.restype = C.c_char_p
+    lib.dm_last_error.argtypes = []
+    lib.dm_abi_version.restype = i32
+    lib.dm_unet_create.argtypes = [C.POINTER(UnetCfg), i32, C.POINTER(vp)]
+    lib.dm_unet_destroy.argtypes = [vp]
+    lib.dm_unet_destroy.restype = None
+    lib.dm_unet_set_param.argtypes = [vp, C.c_char_p, fp, C.POINTER(i64), i32]
+    lib.dm_unet_missing_params.argtypes = [vp]
+    lib.dm_unet_finalize.argtypes = [vp]
+    lib.dm_unet_forward.argtypes = [vp, fp, vp, fp, i32, fp, i32, i32, i32, vp]
+    lib.dm_sample.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, u64, fp, i32, fp, fp,
+                              i32, i32, i32, i32, i32, vp]
+    lib.dm_randn.argtypes = [fp, i64, u64, u64, vp]
+    lib.dm_decoder_create.argtypes = [C.POINTER(DecoderCfg), i32, C.POINTER(vp)]
+    lib.dm_decoder_destroy.argtypes = [vp]
+    lib.dm_decoder_destroy.restype = None
+    lib.dm_decoder_set_param.argtypes = [vp, C.c_char_p, fp, C.POINTER(i64), i32]
+    lib.dm_decoder_missing_params.argtypes = [vp]
+    lib.dm_decoder_finalize.argtypes = [vp]
+    lib.dm_decoder_forward.argtypes = [vp, fp, fp, i32, i32, i32, vp]
+    lib.dm_op_conv2d.argtypes = [fp, i32, fp, i32, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.dm_op_downsample.argtypes = [fp, i32, fp, fp, fp, i32, i32, i32, i32, vp]
+    lib.dm_op_rmsnorm.argtypes = [fp, fp, fp, i32, i32, i32, i32, vp]
+    lib.dm_op_block.argtypes = [fp, i32, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, vp]
+    lib.dm_op_linear_attention.argtypes = [fp, fp, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, vp]
+    lib.dm_op_attention.argtypes = [fp, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, vp]
+    lib.dm_op_sampler_update.argtypes = [i32, fp, fp, fp, C.POINTER(C.c_float), fp, i64, vp]
+
+
+def load() -> C.CDLL:
+    """Load libdm_hip.so; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C diffusion-models_amd/csrc`). "
+            "There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    _declare(lib)
+    if lib.dm_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libdm_hip.so ABI {lib.dm_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().dm_last_error().decode(errors="replace")
+        raise RuntimeError(f"libdm_hip: {msg}")
+
+
+def ptr(t) -> Optional[int]:
+    """Device (or host) address of a contiguous fp32 / int64 torch tensor, None passes NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensor must be contiguous at the C ABI"
+    return t.data_ptr()

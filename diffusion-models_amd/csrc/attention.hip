@@ -1,0 +1,258 @@
+// Attention cores of the denoising U-Net (gfx950).  dim_head is 32 in every reference config
+// (DD/denoising_diffusion.py:248,155,200); the kernels below are specialised for it.
+//
+//   LinearAttention core  DD/denoising_diffusion.py:179-192   (two softmaxes + two 32x32 products/head)
+//   Attention core        DD/denoising_diffusion.py:221-226 + DD/attend.py:109-124
+//   CrossAttention core   DD/denoising_diffusion_text_conditional.py:68-77 (same kernel, no memory kv)
+//
+// qkv tensors are NHWC, i.e. one row of 3*heads*32 floats per token: [q(h,d) | k(h,d) | v(h,d)].
+#include "dm_common.h"
+
+namespace dm {
+
+constexpr int DH = 32;
+
+__device__ __forceinline__ float wave_max64(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// LinearAttention, part 1: ctx[b][h][d][e] = sum_n softmax_n(k)[d][n] * v[e][n]  (n includes 4 memory tokens)
+// grid (heads, B), 256 threads.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restrict__ qkv,
+                                                          const float* __restrict__ mem_kv,
+                                                          float* __restrict__ ctx, int n, int heads, int n_mem) {
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int ld = 3 * heads * DH;
+    const float* kbase = qkv + (size_t)b * n * ld + heads * DH + h * DH;
+    const float* vbase = qkv + (size_t)b * n * ld + 2 * heads * DH + h * DH;
+    const float* mk = mem_kv + (size_t)h * DH * n_mem;            // [d][j]
+    const float* mv = mem_kv + (size_t)(heads + h) * DH * n_mem;  // [e][j]
+    const int ntok = n + n_mem;
+
+    __shared__ float red[8][DH];
+    __shared__ float kmax[DH];
+    __shared__ float ke[64][DH + 1];
+    __shared__ __attribute__((aligned(16))) float vv[64][DH];
+    __shared__ float ksum_s[DH];
+
+    // pass 1: max over tokens for each d
+    {
+        const int d = tid & 31, part = tid >> 5;
+        float m = -INFINITY;
+        for (int t = part; t < ntok; t += 8) {
+            float kv = t < n_mem ? mk[d * n_mem + t] : kbase[(size_t)(t - n_mem) * ld + d];
+            m = fmaxf(m, kv);
+        }
+        red[part][d] = m;
+        __syncthreads();
+        if (tid < DH) {
+            float mm = red[0][tid];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) mm = fmaxf(mm, red[q][tid]);
+            kmax[tid] = mm;
+        }
+        __syncthreads();
+    }
+    // pass 2: exp, running sum and the 32x32 outer-product accumulation
+    const int d = tid >> 3, e0 = (tid & 7) * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float ksum = 0.f;
+    for (int t0 = 0; t0 < ntok; t0 += 64) {
+        __syncthreads();
+        for (int it = tid; it < 64 * DH; it += 256) {
+            int tt = it >> 5, c = it & 31;
+            int t = t0 + tt;
+            float kval = 0.f, vval = 0.f;
+            if (t < ntok) {
+                if (t < n_mem) {
+                    kval = __expf(mk[c * n_mem + t] - kmax[c]);
+                    vval = mv[c * n_mem + t];
+                } else {
+                    kval = __expf(kbase[(size_t)(t - n_mem) * ld + c] - kmax[c]);
+                    vval = vbase[(size_t)(t - n_mem) * ld + c];
+                }
+            }
+            ke[tt][c] = kval;
+            vv[tt][c] = vval;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int tt = 0; tt < 64; ++tt) {
+            float kx = ke[tt][d];
+            float4 v4 = *reinterpret_cast<const float4*>(&vv[tt][e0]);
+            ksum += kx;
+            acc[0] += kx * v4.x;
+            acc[1] += kx * v4.y;
+            acc[2] += kx * v4.z;
+            acc[3] += kx * v4.w;
+        }
+    }
+    if ((tid & 7) == 0) ksum_s[d] = ksum;
+    __syncthreads();
+    const float inv = 1.0f / ksum_s[d];
+    float* cp = ctx + ((size_t)(b * heads + h) * DH + d) * DH + e0;
+    *reinterpret_cast<float4*>(cp) = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+}
+
+// LinearAttention, part 2: out[b][n][h*32+e] = sum_d ctx[b][h][d][e] * softmax_d(q[b][n][h][:])[d] * 32^-0.5
+// grid (ceil(n/64), B), block = 64*heads threads: thread = h*64 + pixel (one head per wavefront).
+__global__ void linattn_out_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                   float* __restrict__ out, int n, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float cs[];  // [heads][DH][DH]
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < heads * DH * DH; i += blockDim.x) cs[i] = ctx[(size_t)b * heads * DH * DH + i];
+    __syncthreads();
+    const int h = tid >> 6;
+    const int p = blockIdx.x * 64 + (tid & 63);
+    if (p >= n) return;
+    const int ld = 3 * heads * DH;
+    const float* qp = qkv + ((size_t)b * n + p) * ld + h * DH;
+    float q[DH];
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) {
+        float4 t = *reinterpret_cast<const float4*>(qp + 4 * i);
+        q[4 * i] = t.x; q[4 * i + 1] = t.y; q[4 * i + 2] = t.z; q[4 * i + 3] = t.w;
+    }
+    float m = q[0];
+#pragma unroll
+    for (int i = 1; i < DH; ++i) m = fmaxf(m, q[i]);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < DH; ++i) {
+        q[i] = __expf(q[i] - m);
+        s += q[i];
+    }
+    const float inv = scale / s;
+    float o[DH];
+#pragma unroll
+    for (int i = 0; i < DH; ++i) o[i] = 0.f;
+    const float* ch = cs + h * DH * DH;
+#pragma unroll
+    for (int dd = 0; dd < DH; ++dd) {
+        const float qd = q[dd] * inv;
+#pragma unroll
+        for (int i = 0; i < DH / 4; ++i) {
+            float4 c4 = *reinterpret_cast<const float4*>(ch + dd * DH + 4 * i);
+            o[4 * i] += qd * c4.x;
+            o[4 * i + 1] += qd * c4.y;
+            o[4 * i + 2] += qd * c4.z;
+            o[4 * i + 3] += qd * c4.w;
+        }
+    }
+    float* op = out + ((size_t)b * n + p) * (heads * DH) + h * DH;
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i)
+        *reinterpret_cast<float4*>(op + 4 * i) = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+}
+
+int launch_linear_attention_core(const float* qkv, const float* mem_kv, float* ctx_ws, float* out, int B, int n,
+                                 int heads, int dh, hipStream_t s) {
+    DM_REQUIRE(dh == DH, "LinearAttention kernel is specialised for dim_head == 32");
+    DM_REQUIRE(heads >= 1 && heads <= 16, "LinearAttention kernel supports 1..16 heads");
+    hipLaunchKernelGGL(linattn_ctx_kernel, dim3(heads, B), dim3(256), 0, s, qkv, mem_kv, ctx_ws, n, heads, 4);
+    DM_CHECK_HIP(hipGetLastError());
+    size_t lds = (size_t)heads * DH * DH * sizeof(float);
+    hipLaunchKernelGGL(linattn_out_kernel, dim3((n + 63) / 64, B), dim3(64 * heads), lds, s, qkv, ctx_ws, out, n,
+                       heads, 1.0f / sqrtf((float)dh));
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// softmax(q k^T * scale) v for short sequences; K and V of one (batch, head) live in LDS.
+// grid (heads, B), 256 threads (4 waves, one query row per wave at a time).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attention_core_kernel(const float* __restrict__ q, int ldq,
+                                                             const float* __restrict__ k,
+                                                             const float* __restrict__ v, int ldk,
+                                                             const float* __restrict__ mem_k,
+                                                             const float* __restrict__ mem_v, int n_mem,
+                                                             float* __restrict__ out, int ldo, int nq, int nk,
+                                                             float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntok = nk + n_mem;
+    float* Ks = sm;                      // [ntok][DH+1]
+    float* Vs = Ks + ntok * (DH + 1);    // [ntok][DH]
+    float* Ps = Vs + ntok * DH;          // [4][ntok]
+    float* Qs = Ps + 4 * ntok;           // [4][DH]
+    for (int it = tid; it < ntok * DH; it += 256) {
+        int t = it >> 5, c = it & 31;
+        float kv, vvv;
+        if (t < n_mem) {
+            kv = mem_k[((size_t)h * n_mem + t) * DH + c];
+            vvv = mem_v[((size_t)h * n_mem + t) * DH + c];
+        } else {
+            size_t o = ((size_t)b * nk + (t - n_mem)) * ldk + h * DH + c;
+            kv = k[o];
+            vvv = v[o];
+        }
+        Ks[t * (DH + 1) + c] = kv;
+        Vs[t * DH + c] = vvv;
+    }
+    __syncthreads();
+    float* pw = Ps + wave * ntok;
+    float* qw = Qs + wave * DH;
+    for (int i = wave; i < nq; i += 4) {
+        if (lane < DH) qw[lane] = q[((size_t)b * nq + i) * ldq + h * DH + lane] * scale;
+        __builtin_amdgcn_wave_barrier();
+        // scores for keys j = lane, lane+64, ...
+        float mx = -INFINITY;
+        for (int j = lane; j < ntok; j += 64) {
+            float sc = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) sc += qw[c] * Ks[j * (DH + 1) + c];
+            pw[j] = sc;
+            mx = fmaxf(mx, sc);
+        }
+        mx = wave_max64(mx);
+        float sum = 0.f;
+        for (int j = lane; j < ntok; j += 64) {
+            float pe = __expf(pw[j] - mx);
+            pw[j] = pe;
+            sum += pe;
+        }
+        sum = wave_sum64(sum);
+        __builtin_amdgcn_wave_barrier();
+        // out[d] = sum_j p_j v[j][d]; lane = (half, d): halves split the keys
+        const int d = lane & 31, half = lane >> 5;
+        float acc = 0.f;
+        for (int j = half; j < ntok; j += 2) acc += pw[j] * Vs[j * DH + d];
+        acc += __shfl_xor(acc, 32);
+        if (lane < DH) out[((size_t)b * nq + i) * ldo + h * DH + d] = acc / sum;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int launch_attention_core(const float* q, int ldq, const float* k, const float* v, int ldk, const float* mem_k,
+                          const float* mem_v, int n_mem, float* out, int ldo, int B, int nq, int nk, int heads,
+                          int dh, float scale, hipStream_t s) {
+    DM_REQUIRE(dh == DH, "attention kernel is specialised for dim_head == 32");
+    int ntok = nk + n_mem;
+    size_t lds = ((size_t)ntok * (DH + 1) + (size_t)ntok * DH + 4 * (size_t)ntok + 4 * DH) * sizeof(float);
+    DM_REQUIRE(lds <= 160 * 1024, "attention: sequence too long for the LDS-resident kernel");
+    static bool attr_set = false;
+    if (!attr_set) {
+        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_core_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_core_kernel, dim3(heads, B), dim3(256), lds, s, q, ldq, k, v, ldk, mem_k, mem_v,
+                       n_mem, out, ldo, nq, nk, scale);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dm

@@ -1,0 +1,848 @@
+// C ABI of libdm_hip.so (include/dm_hip.h): U-Net handle, forward, samplers, single operators.
+// Host orchestration only -- every FLOP runs in the kernels of conv_mfma.hip / attention.hip /
+// elementwise.hip.  No allocation, copy or synchronisation happens inside the per-step launch
+// sequence, so one denoise step can be captured into a hipGraph and replayed.
+#include "../../include/dm_hip.h"
+#include "dm_common.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace dm {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+// ---------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    bool set = false;
+    size_t numel() const {
+        size_t n = 1;
+        for (auto d : shape) n *= (size_t)d;
+        return n;
+    }
+};
+
+struct DeviceOwner {
+    std::vector<void*> ptrs;
+    ~DeviceOwner() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    int upload(const float* host, size_t n, float** out) {
+        void* p = nullptr;
+        DM_CHECK_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)));
+        ptrs.push_back(p);
+        if (n) DM_CHECK_HIP(hipMemcpy(p, host, n * sizeof(float), hipMemcpyHostToDevice));
+        *out = static_cast<float*>(p);
+        return 0;
+    }
+};
+
+// bump allocator over one device buffer; `dry` only measures
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0;
+    bool dry = false;
+    float* alloc(size_t nfloats) {
+        size_t bytes = (nfloats * sizeof(float) + 255) & ~size_t(255);
+        float* p = dry ? nullptr : reinterpret_cast<float*>(base + off);
+        off += bytes;
+        return p;
+    }
+};
+
+struct ConvLayer {
+    int C0 = 0, C1 = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0;
+    bool up = false;
+    float* w = nullptr;
+    float* bias = nullptr;
+};
+
+struct ResBlock {
+    ConvLayer c1, c2, res;
+    bool has_res = false;
+    float *g1 = nullptr, *g2 = nullptr;
+    int ss_off = 0, dout = 0;
+};
+
+struct AttnLayer {
+    bool full = false;
+    int dim = 0;
+    float *norm_g = nullptr, *mem_kv = nullptr, *out_g = nullptr;
+    ConvLayer qkv, out;
+};
+
+struct CrossLayer {
+    ConvLayer q, out;
+    float *wk = nullptr, *wv = nullptr, *g = nullptr;
+};
+
+struct Stage {
+    ResBlock b1, b2;
+    AttnLayer attn;
+    ConvLayer resample;
+};
+
+}  // namespace dm
+
+using namespace dm;
+
+struct dm_unet {
+    dm_unet_cfg cfg{};
+    int device = 0;
+    int init_dim = 0, out_dim = 0, time_dim = 0, heads = 0, dh = 0;
+    std::vector<int> dims;
+    std::map<std::string, HostTensor> params;  // expected entries, filled by set_param
+    std::vector<std::string> order;
+    bool finalized = false;
+    DeviceOwner own;
+    // layers
+    ConvLayer init_conv, final_conv;
+    std::vector<Stage> downs, ups;
+    ResBlock mid1, mid2, final_res;
+    AttnLayer mid_attn;
+    CrossLayer cross_down, cross_mid, cross_up;
+    float *freqs = nullptr, *tw1 = nullptr, *tb1 = nullptr, *tw2 = nullptr, *tb2 = nullptr;
+    float *ss_w = nullptr, *ss_b = nullptr;
+    int ss_total = 0;
+    float *tp_w0 = nullptr, *tp_b0 = nullptr, *tp_w2 = nullptr, *tp_b2 = nullptr, *tc_w = nullptr, *tc_b = nullptr;
+    // workspace
+    char* ws = nullptr;
+    size_t ws_cap = 0;
+    // sampler state (device)
+    int* step_dev = nullptr;
+    int64_t* times_dev = nullptr;
+    float* coefs_dev = nullptr;
+    int sampler_cap = 0;
+};
+
+namespace dm {
+
+static void expect(dm_unet* u, const std::string& name, std::vector<int64_t> shape) {
+    HostTensor t;
+    t.shape = std::move(shape);
+    u->params[name] = std::move(t);
+    u->order.push_back(name);
+}
+
+static void expect_resnet(dm_unet* u, const std::string& p, int din, int dout) {
+    int td = u->time_dim;
+    expect(u, p + ".mlp.1.weight", {2 * dout, td});
+    expect(u, p + ".mlp.1.bias", {2 * dout});
+    expect(u, p + ".block1.proj.weight", {dout, din, 3, 3});
+    expect(u, p + ".block1.proj.bias", {dout});
+    expect(u, p + ".block1.norm.g", {1, dout, 1, 1});
+    expect(u, p + ".block2.proj.weight", {dout, dout, 3, 3});
+    expect(u, p + ".block2.proj.bias", {dout});
+    expect(u, p + ".block2.norm.g", {1, dout, 1, 1});
+    if (din != dout) {
+        expect(u, p + ".res_conv.weight", {dout, din, 1, 1});
+        expect(u, p + ".res_conv.bias", {dout});
+    }
+}
+
+static void expect_attn(dm_unet* u, const std::string& p, int dim, bool full) {
+    int hidden = u->heads * u->dh;
+    if (full) {
+        expect(u, p + ".mem_kv", {2, u->heads, 4, u->dh});
+        expect(u, p + ".norm.g", {1, dim, 1, 1});
+        expect(u, p + ".to_qkv.weight", {3 * hidden, dim, 1, 1});
+        expect(u, p + ".to_out.weight", {dim, hidden, 1, 1});
+        expect(u, p + ".to_out.bias", {dim});
+    } else {
+        expect(u, p + ".mem_kv", {2, u->heads, u->dh, 4});
+        expect(u, p + ".norm.g", {1, dim, 1, 1});
+        expect(u, p + ".to_qkv.weight", {3 * hidden, dim, 1, 1});
+        expect(u, p + ".to_out.0.weight", {dim, hidden, 1, 1});
+        expect(u, p + ".to_out.0.bias", {dim});
+        expect(u, p + ".to_out.1.g", {1, dim, 1, 1});
+    }
+}
+
+static void expect_cross(dm_unet* u, const std::string& p, int dim) {
+    int inner = 4 * u->dh;
+    int ctx = u->cfg.text_emb_dim;
+    expect(u, p + ".to_q.weight", {inner, dim});
+    expect(u, p + ".to_k.weight", {inner, ctx});
+    expect(u, p + ".to_v.weight", {inner, ctx});
+    expect(u, p + ".to_out.0.weight", {dim, inner});
+    expect(u, p + ".to_out.0.bias", {dim});
+    expect(u, p + ".to_out.1.g", {1, dim});
+}
+
+static std::string idx(const std::string& a, int i) { return a + "." + std::to_string(i); }
+
+// ---- weight upload ----------------------------------------------------------------------
+static int make_conv(DeviceOwner& own, ConvLayer& L, const float* oihw, const float* bias, int Cout, int C0, int C1, int KH,
+                     int KW, int stride, int pad, bool up) {
+    L.C0 = C0; L.C1 = C1; L.Cout = Cout; L.KH = KH; L.KW = KW; L.stride = stride; L.pad = pad; L.up = up;
+    std::vector<float> packed(conv_packed_floats(Cout, C0, C1, KH, KW, false));
+    conv_pack_weights(oihw, packed.data(), Cout, C0, C1, KH, KW, false);
+    if (own.upload(packed.data(), packed.size(), &L.w)) return 1;
+    L.bias = nullptr;
+    if (bias && own.upload(bias, Cout, &L.bias)) return 1;
+    return 0;
+}
+
+static const HostTensor& P(dm_unet* u, const std::string& n) { return u->params.at(n); }
+
+static int up1(dm_unet* u, const std::string& n, float** out) {
+    const HostTensor& t = P(u, n);
+    return u->own.upload(t.data.data(), t.data.size(), out);
+}
+
+static int build_resnet(dm_unet* u, ResBlock& R, const std::string& p, int C0, int C1, int dout, int& ss_off,
+                        std::vector<float>& ssw, std::vector<float>& ssb) {
+    int din = C0 + C1;
+    R.dout = dout;
+    R.ss_off = ss_off;
+    const HostTensor& mw = P(u, p + ".mlp.1.weight");
+    const HostTensor& mb = P(u, p + ".mlp.1.bias");
+    ssw.insert(ssw.end(), mw.data.begin(), mw.data.end());
+    ssb.insert(ssb.end(), mb.data.begin(), mb.data.end());
+    ss_off += 2 * dout;
+    if (make_conv(u->own, R.c1, P(u, p + ".block1.proj.weight").data.data(), P(u, p + ".block1.proj.bias").data.data(),
+                  dout, C0, C1, 3, 3, 1, 1, false)) return 1;
+    if (make_conv(u->own, R.c2, P(u, p + ".block2.proj.weight").data.data(), P(u, p + ".block2.proj.bias").data.data(),
+                  dout, dout, 0, 3, 3, 1, 1, false)) return 1;
+    if (up1(u, p + ".block1.norm.g", &R.g1) || up1(u, p + ".block2.norm.g", &R.g2)) return 1;
+    R.has_res = din != dout;
+    if (R.has_res) {
+        if (make_conv(u->own, R.res, P(u, p + ".res_conv.weight").data.data(), P(u, p + ".res_conv.bias").data.data(),
+                      dout, C0, C1, 1, 1, 1, 0, false)) return 1;
+    }
+    return 0;
+}
+
+static int build_attn(dm_unet* u, AttnLayer& A, const std::string& p, int dim, bool full) {
+    A.full = full;
+    A.dim = dim;
+    int hidden = u->heads * u->dh;
+    if (up1(u, p + ".norm.g", &A.norm_g) || up1(u, p + ".mem_kv", &A.mem_kv)) return 1;
+    if (make_conv(u->own, A.qkv, P(u, p + ".to_qkv.weight").data.data(), nullptr, 3 * hidden, dim, 0, 1, 1, 1, 0, false))
+        return 1;
+    if (full) {
+        if (make_conv(u->own, A.out, P(u, p + ".to_out.weight").data.data(), P(u, p + ".to_out.bias").data.data(), dim,
+                      hidden, 0, 1, 1, 1, 0, false)) return 1;
+    } else {
+        if (make_conv(u->own, A.out, P(u, p + ".to_out.0.weight").data.data(), P(u, p + ".to_out.0.bias").data.data(),
+                      dim, hidden, 0, 1, 1, 1, 0, false)) return 1;
+        if (up1(u, p + ".to_out.1.g", &A.out_g)) return 1;
+    }
+    return 0;
+}
+
+static int build_cross(dm_unet* u, CrossLayer& C, const std::string& p, int dim) {
+    int inner = 4 * u->dh;
+    // nn.Linear weights [out, in] are 1x1 conv weights (out, in, 1, 1)
+    if (make_conv(u->own, C.q, P(u, p + ".to_q.weight").data.data(), nullptr, inner, dim, 0, 1, 1, 1, 0, false)) return 1;
+    if (make_conv(u->own, C.out, P(u, p + ".to_out.0.weight").data.data(), P(u, p + ".to_out.0.bias").data.data(), dim,
+                  inner, 0, 1, 1, 1, 0, false)) return 1;
+    if (up1(u, p + ".to_k.weight", &C.wk) || up1(u, p + ".to_v.weight", &C.wv) || up1(u, p + ".to_out.1.g", &C.g))
+        return 1;
+    return 0;
+}
+
+// ---- launches ---------------------------------------------------------------------------
+struct Ctx {
+    dm_unet* u;
+    Arena* A;
+    hipStream_t s;
+    int B;
+    const float* ss;   // [Bt][ss_total]
+    int ss_stride;     // 0 when one row serves the whole batch
+    bool dry() const { return A->dry; }
+};
+
+static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* in1, int Hin, int Win, float* out,
+                    int epi, const float* g, const float* scale, const float* residual, bool in_nchw = false,
+                    bool out_nchw = false) {
+    if (c.dry()) return 0;
+    ConvParams p{};
+    p.in0 = in0; p.in1 = in1; p.C0 = L.C0; p.C1 = L.C1;
+    int CK = conv_ck_for(L.C0, L.C1);
+    p.chunks0 = (L.C0 + CK - 1) / CK;
+    p.n_chunks = p.chunks0 + (L.C1 ? (L.C1 + CK - 1) / CK : 0);
+    p.Hin = Hin; p.Win = Win; p.up = L.up ? 1 : 0; p.in_nchw = in_nchw ? 1 : 0;
+    p.w = L.w; p.bias = L.bias;
+    p.Cout = L.Cout; p.KH = L.KH; p.KW = L.KW; p.stride = L.stride; p.pad = L.pad;
+    p.B = c.B;
+    p.Ho = (Hin + 2 * L.pad - L.KH) / L.stride + 1;
+    p.Wo = (Win + 2 * L.pad - L.KW) / L.stride + 1;
+    p.out = out; p.out_nchw = out_nchw ? 1 : 0;
+    p.epi = epi | (L.bias ? EPI_BIAS : 0);
+    p.residual = residual; p.g = g; p.scale = scale; p.ss_stride = c.ss_stride;
+    p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, L.KH, L.KW, L.stride, L.C0 + L.C1, false);
+    p.geo.CK = CK;
+    return conv_launch(p, c.s);
+}
+
+static bool can_fuse_norm(int Cout) { return Cout <= 256; }
+
+// Block.forward: conv3x3 -> RMSNorm -> (scale+1, shift) -> SiLU [-> + residual]
+static int run_block(Ctx& c, const ConvLayer& L, const float* in0, const float* in1, int H, int W, const float* g,
+                     const float* scale, const float* residual, float* out) {
+    int flags = EPI_NORM | EPI_SILU | (scale ? EPI_SCALE_SHIFT : 0) | (residual ? EPI_RESIDUAL : 0);
+    if (can_fuse_norm(L.Cout)) return run_conv(c, L, in0, in1, H, W, out, flags, g, scale, residual);
+    float* raw = c.A->alloc((size_t)c.B * H * W * L.Cout);
+    if (run_conv(c, L, in0, in1, H, W, raw, 0, nullptr, nullptr, nullptr)) return 1;
+    if (c.dry()) return 0;
+    return launch_norm_act(raw, g, scale, c.ss_stride, H * W, residual, out, (int64_t)c.B * H * W, L.Cout, flags, c.s);
+}
+
+// ResnetBlock.forward (DD/denoising_diffusion.py:136-148); x = cat(x0, x1)
+static int run_resnet(Ctx& c, const ResBlock& R, const float* x0, const float* x1, int H, int W, float** out) {
+    size_t n = (size_t)c.B * H * W * R.dout;
+    float* h1 = c.A->alloc(n);
+    float* h2 = c.A->alloc(n);
+    const float* scale = c.ss ? c.ss + R.ss_off : nullptr;
+    if (run_block(c, R.c1, x0, x1, H, W, R.g1, scale, nullptr, h1)) return 1;
+    if (!R.has_res) {
+        if (run_block(c, R.c2, h1, nullptr, H, W, R.g2, nullptr, x0, h2)) return 1;
+        *out = h2;
+        return 0;
+    }
+    if (run_block(c, R.c2, h1, nullptr, H, W, R.g2, nullptr, nullptr, h2)) return 1;
+    float* o = c.A->alloc(n);
+    if (run_conv(c, R.res, x0, x1, H, W, o, EPI_RESIDUAL, nullptr, nullptr, h2)) return 1;
+    *out = o;
+    return 0;
+}
+
+// attn(x) + x  (LinearAttention DD/denoising_diffusion.py:173-193, Attention :215-229)
+static int run_attn(Ctx& c, const AttnLayer& At, const float* x, int H, int W, float** out, bool add_x = true) {
+    const int res_flag = add_x ? EPI_RESIDUAL : 0;
+    const float* xres = add_x ? x : nullptr;
+    dm_unet* u = c.u;
+    const int n = H * W, hidden = u->heads * u->dh;
+    const size_t rows = (size_t)c.B * n;
+    float* xn = c.A->alloc(rows * At.dim);
+    float* qkv = c.A->alloc(rows * 3 * hidden);
+    float* o = c.A->alloc(rows * hidden);
+    float* y = c.A->alloc(rows * At.dim);
+    if (!c.dry() && launch_norm_act(x, At.norm_g, nullptr, 0, n, nullptr, xn, (int64_t)rows, At.dim, EPI_NORM, c.s))
+        return 1;
+    if (run_conv(c, At.qkv, xn, nullptr, H, W, qkv, 0, nullptr, nullptr, nullptr)) return 1;
+    if (At.full) {
+        if (!c.dry()) {
+            const float* mk = At.mem_kv;
+            const float* mv = At.mem_kv + (size_t)u->heads * 4 * u->dh;
+            if (launch_attention_core(qkv, 3 * hidden, qkv + hidden, qkv + 2 * hidden, 3 * hidden, mk, mv, 4, o,
+                                      hidden, c.B, n, n, u->heads, u->dh, 1.0f / sqrtf((float)u->dh), c.s))
+                return 1;
+        }
+        if (run_conv(c, At.out, o, nullptr, H, W, y, res_flag, nullptr, nullptr, xres)) return 1;
+    } else {
+        float* ctxws = c.A->alloc((size_t)c.B * u->heads * u->dh * u->dh);
+        if (!c.dry() && launch_linear_attention_core(qkv, At.mem_kv, ctxws, o, c.B, n, u->heads, u->dh, c.s)) return 1;
+        if (can_fuse_norm(At.dim)) {
+            if (run_conv(c, At.out, o, nullptr, H, W, y, EPI_NORM | res_flag, At.out_g, nullptr, xres)) return 1;
+        } else {
+            float* raw = c.A->alloc(rows * At.dim);
+            if (run_conv(c, At.out, o, nullptr, H, W, raw, 0, nullptr, nullptr, nullptr)) return 1;
+            if (!c.dry() && launch_norm_act(raw, At.out_g, nullptr, 0, n, xres, y, (int64_t)rows, At.dim,
+                                            EPI_NORM | res_flag, c.s))
+                return 1;
+        }
+    }
+    *out = y;
+    return 0;
+}
+
+// CrossAttention.forward (DD/denoising_diffusion_text_conditional.py:54-78); the result REPLACES x (:173-177)
+static int run_cross(Ctx& c, const CrossLayer& Cr, const float* x, int H, int W, const float* ctx, int m,
+                     float** out) {
+    dm_unet* u = c.u;
+    const int n = H * W, inner = 4 * u->dh, dim = Cr.out.Cout, E = u->cfg.text_emb_dim;
+    const size_t rows = (size_t)c.B * n;
+    float* q = c.A->alloc(rows * inner);
+    float* k = c.A->alloc((size_t)c.B * m * inner);
+    float* v = c.A->alloc((size_t)c.B * m * inner);
+    float* o = c.A->alloc(rows * inner);
+    float* y = c.A->alloc(rows * dim);
+    if (run_conv(c, Cr.q, x, nullptr, H, W, q, 0, nullptr, nullptr, nullptr)) return 1;
+    if (!c.dry()) {
+        if (launch_linear_rows(ctx, E, Cr.wk, nullptr, k, inner, c.B * m, E, inner, 0, 0, c.s)) return 1;
+        if (launch_linear_rows(ctx, E, Cr.wv, nullptr, v, inner, c.B * m, E, inner, 0, 0, c.s)) return 1;
+        if (launch_attention_core(q, inner, k, v, inner, nullptr, nullptr, 0, o, inner, c.B, n, m, 4, u->dh,
+                                  1.0f / sqrtf((float)u->dh), c.s))
+            return 1;
+    }
+    if (can_fuse_norm(dim)) {
+        if (run_conv(c, Cr.out, o, nullptr, H, W, y, EPI_NORM, Cr.g, nullptr, nullptr)) return 1;
+    } else {
+        float* raw = c.A->alloc(rows * dim);
+        if (run_conv(c, Cr.out, o, nullptr, H, W, raw, 0, nullptr, nullptr, nullptr)) return 1;
+        if (!c.dry() && launch_norm_act(raw, Cr.g, nullptr, 0, n, nullptr, y, (int64_t)rows, dim, EPI_NORM, c.s))
+            return 1;
+    }
+    *out = y;
+    return 0;
+}
+
+// Unet.forward (DD/denoising_diffusion.py:349-390; text hooks DD/denoising_diffusion_text_conditional.py:131-214)
+static int unet_forward_impl(dm_unet* u, Arena& A, const float* x_nchw, const int64_t* t_dev,
+                             const int64_t* step_times, const int* step_dev, const float* ctx, int ctx_tokens,
+                             float* out_nchw, int B, int H, int W, hipStream_t s) {
+    const dm_unet_cfg& cfg = u->cfg;
+    Ctx c{u, &A, s, B, nullptr, 0};
+    const int td = u->time_dim;
+    const bool text_concat = cfg.text_mode == DM_TEXT_CONCAT && ctx != nullptr;
+    const bool text_cross = cfg.text_mode == DM_TEXT_CROSS && ctx != nullptr;
+    // the time embedding is one row when the whole batch shares t (samplers), else one row per sample
+    const int Bt = (step_times && !text_concat) ? 1 : B;
+    const int Rt = step_times ? 1 : B;  // rows of the sinusoid / time_mlp
+    float* e0 = A.alloc((size_t)Rt * cfg.dim);
+    float* e1 = A.alloc((size_t)Rt * td);
+    float* temb = A.alloc((size_t)B * td);
+    float* ss = A.alloc((size_t)Bt * u->ss_total);
+    if (!A.dry) {
+        if (launch_sinusoid(t_dev, step_times, step_dev, u->freqs, e0, Rt, cfg.dim / 2, s)) return 1;
+        if (launch_linear_rows(e0, cfg.dim, u->tw1, u->tb1, e1, td, Rt, cfg.dim, td, 0, 2, s)) return 1;
+        if (launch_linear_rows(e1, td, u->tw2, u->tb2, temb, td, Rt, td, td, 0, 0, s)) return 1;
+    }
+    const float* tfinal = temb;
+    if (text_concat) {
+        // t = text_concat_proj(cat(t, text_proj(text_emb)))  (:146-152); ctx is (B, 1, E) or (B, E)
+        DM_REQUIRE(ctx_tokens == 1, "text concat conditioning takes one pooled embedding per sample");
+        float* cat = A.alloc((size_t)B * 2 * td);
+        float* tf0 = A.alloc((size_t)B * td);
+        float* t2 = A.alloc((size_t)B * td);
+        if (!A.dry) {
+            // left half: the time embedding of every row (broadcast when Rt == 1)
+            for (int r = 0; r < (Rt == 1 ? B : 0); ++r)
+                DM_CHECK_HIP(hipMemcpyAsync(cat + (size_t)r * 2 * td, temb, td * sizeof(float),
+                                            hipMemcpyDeviceToDevice, s));
+            if (Rt != 1)
+                DM_CHECK_HIP(hipMemcpy2DAsync(cat, 2 * td * sizeof(float), temb, td * sizeof(float),
+                                              td * sizeof(float), B, hipMemcpyDeviceToDevice, s));
+            if (launch_linear_rows(ctx, cfg.text_emb_dim, u->tp_w0, u->tp_b0, tf0, td, B, cfg.text_emb_dim, td, 0, 2, s))
+                return 1;
+            if (launch_linear_rows(tf0, td, u->tp_w2, u->tp_b2, cat + td, 2 * td, B, td, td, 0, 0, s)) return 1;
+            if (launch_linear_rows(cat, 2 * td, u->tc_w, u->tc_b, t2, td, B, 2 * td, td, 0, 0, s)) return 1;
+        }
+        tfinal = t2;
+    }
+    if (!A.dry) {
+        // every ResnetBlock.mlp (SiLU -> Linear) in one launch
+        if (launch_linear_rows(tfinal, td, u->ss_w, u->ss_b, ss, u->ss_total, Bt, td, u->ss_total, 1, 0, s)) return 1;
+    }
+    c.ss = A.dry ? reinterpret_cast<const float*>(16) : ss;  // non-null marker in dry mode
+    c.ss_stride = Bt == 1 ? 0 : u->ss_total;
+
+    const int n_st = cfg.n_stages;
+    float* x = A.alloc((size_t)B * H * W * u->init_dim);
+    if (run_conv(c, u->init_conv, x_nchw, nullptr, H, W, x, 0, nullptr, nullptr, nullptr, /*in_nchw=*/true)) return 1;
+    const float* r = x;
+    std::vector<const float*> skips;
+    std::vector<int> skipC;
+    int h = H, w = W;
+    float* cur = x;
+    for (int i = 0; i < n_st; ++i) {
+        Stage& S = u->downs[i];
+        float *a, *b2, *at;
+        if (run_resnet(c, S.b1, cur, nullptr, h, w, &a)) return 1;
+        skips.push_back(a); skipC.push_back(S.b1.dout);
+        if (run_resnet(c, S.b2, a, nullptr, h, w, &b2)) return 1;
+        if (run_attn(c, S.attn, b2, h, w, &at)) return 1;
+        skips.push_back(at); skipC.push_back(S.b2.dout);
+        int ho = (i < n_st - 1) ? h / 2 : h, wo = (i < n_st - 1) ? w / 2 : w;
+        float* d = A.alloc((size_t)B * ho * wo * S.resample.Cout);
+        if (run_conv(c, S.resample, at, nullptr, h, w, d, 0, nullptr, nullptr, nullptr)) return 1;
+        cur = d; h = ho; w = wo;
+    }
+    float* t0;
+    if (text_cross) { if (run_cross(c, u->cross_down, cur, h, w, ctx, ctx_tokens, &t0)) return 1; cur = t0; }
+    if (run_resnet(c, u->mid1, cur, nullptr, h, w, &t0)) return 1; cur = t0;
+    if (text_cross) { if (run_cross(c, u->cross_mid, cur, h, w, ctx, ctx_tokens, &t0)) return 1; cur = t0; }
+    if (run_attn(c, u->mid_attn, cur, h, w, &t0)) return 1; cur = t0;
+    if (run_resnet(c, u->mid2, cur, nullptr, h, w, &t0)) return 1; cur = t0;
+    if (text_cross) { if (run_cross(c, u->cross_up, cur, h, w, ctx, ctx_tokens, &t0)) return 1; cur = t0; }
+    for (int j = 0; j < n_st; ++j) {
+        Stage& S = u->ups[j];
+        float *a, *b2, *at;
+        const float* sk = skips.back(); skips.pop_back(); skipC.pop_back();
+        if (run_resnet(c, S.b1, cur, sk, h, w, &a)) return 1;
+        sk = skips.back(); skips.pop_back(); skipC.pop_back();
+        if (run_resnet(c, S.b2, a, sk, h, w, &b2)) return 1;
+        if (run_attn(c, S.attn, b2, h, w, &at)) return 1;
+        bool last = j == n_st - 1;
+        int ho = last ? h : h * 2, wo = last ? w : w * 2;
+        float* d = A.alloc((size_t)B * ho * wo * S.resample.Cout);
+        // the conv sees the (virtually) upsampled tensor
+        if (run_conv(c, S.resample, at, nullptr, ho, wo, d, 0, nullptr, nullptr, nullptr)) return 1;
+        cur = d; h = ho; w = wo;
+    }
+    float* fr;
+    if (run_resnet(c, u->final_res, cur, r, h, w, &fr)) return 1;
+    if (run_conv(c, u->final_conv, fr, nullptr, h, w, out_nchw, 0, nullptr, nullptr, nullptr, false, /*out_nchw=*/true))
+        return 1;
+    return 0;
+}
+
+static int ensure_workspace(dm_unet* u, size_t bytes) {
+    if (bytes <= u->ws_cap) return 0;
+    DM_CHECK_HIP(hipDeviceSynchronize());
+    if (u->ws) (void)hipFree(u->ws);
+    u->ws = nullptr;
+    u->ws_cap = 0;
+    void* p = nullptr;
+    DM_CHECK_HIP(hipMalloc(&p, bytes));
+    u->ws = static_cast<char*>(p);
+    u->ws_cap = bytes;
+    return 0;
+}
+
+static int check_hw(dm_unet* u, int H, int W) {
+    int f = 1 << (u->cfg.n_stages - 1);
+    if (H % f || W % f) {
+        set_error("your input dimensions (" + std::to_string(H) + ", " + std::to_string(W) +
+                  ") need to be divisible by " + std::to_string(f) + ", given the unet");
+        return 1;
+    }
+    return 0;
+}
+
+}  // namespace dm
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+const char* dm_last_error(void) { return g_err.c_str(); }
+int dm_abi_version(void) { return 1; }
+
+int dm_unet_create(const dm_unet_cfg* cfg, int device, dm_unet** out) {
+    DM_REQUIRE(cfg && out, "null argument");
+    DM_REQUIRE(cfg->n_stages >= 1 && cfg->n_stages <= DM_MAX_STAGES, "n_stages out of range");
+    DM_REQUIRE(cfg->dim > 0 && cfg->dim % 2 == 0, "dim must be positive and even");
+    DM_REQUIRE(cfg->attn_dim_head == 32, "HIP attention kernels are specialised for attn_dim_head == 32");
+    DM_REQUIRE(cfg->attn_heads >= 1 && cfg->attn_heads <= 16, "attn_heads out of range");
+    int ndev = 0;
+    DM_CHECK_HIP(hipGetDeviceCount(&ndev));
+    DM_REQUIRE(device >= 0 && device < ndev, "no such HIP device");
+    DM_CHECK_HIP(hipSetDevice(device));
+    auto u = std::make_unique<dm_unet>();
+    u->cfg = *cfg;
+    u->device = device;
+    u->init_dim = cfg->init_dim ? cfg->init_dim : cfg->dim;
+    u->out_dim = cfg->out_dim ? cfg->out_dim : cfg->channels;
+    u->time_dim = cfg->dim * 4;
+    u->heads = cfg->attn_heads;
+    u->dh = cfg->attn_dim_head;
+    u->dims.push_back(u->init_dim);
+    for (int i = 0; i < cfg->n_stages; ++i) u->dims.push_back(cfg->dim * cfg->dim_mults[i]);
+    dm_unet* p = u.get();
+    const int n = cfg->n_stages, td = u->time_dim;
+    expect(p, "init_conv.weight", {u->init_dim, cfg->input_channels, 7, 7});
+    expect(p, "init_conv.bias", {u->init_dim});
+    expect(p, "time_mlp.1.weight", {td, cfg->dim});
+    expect(p, "time_mlp.1.bias", {td});
+    expect(p, "time_mlp.3.weight", {td, td});
+    expect(p, "time_mlp.3.bias", {td});
+    for (int i = 0; i < n; ++i) {
+        int din = u->dims[i], dout = u->dims[i + 1];
+        std::string q = idx("downs", i);
+        expect_resnet(p, q + ".0", din, din);
+        expect_resnet(p, q + ".1", din, din);
+        expect_attn(p, q + ".2", din, cfg->full_attn[i] != 0);
+        if (i < n - 1) {
+            expect(p, q + ".3.1.weight", {dout, din * 4, 1, 1});
+            expect(p, q + ".3.1.bias", {dout});
+        } else {
+            expect(p, q + ".3.weight", {dout, din, 3, 3});
+            expect(p, q + ".3.bias", {dout});
+        }
+    }
+    for (int j = 0; j < n; ++j) {
+        int din = u->dims[n - 1 - j], dout = u->dims[n - j];
+        std::string q = idx("ups", j);
+        expect_resnet(p, q + ".0", dout + din, dout);
+        expect_resnet(p, q + ".1", dout + din, dout);
+        expect_attn(p, q + ".2", dout, cfg->full_attn[n - 1 - j] != 0);
+        if (j < n - 1) {
+            expect(p, q + ".3.1.weight", {din, dout, 3, 3});
+            expect(p, q + ".3.1.bias", {din});
+        } else {
+            expect(p, q + ".3.weight", {din, dout, 3, 3});
+            expect(p, q + ".3.bias", {din});
+        }
+    }
+    int mid = u->dims.back();
+    expect_resnet(p, "mid_block1", mid, mid);
+    expect_attn(p, "mid_attn", mid, true);
+    expect_resnet(p, "mid_block2", mid, mid);
+    expect_resnet(p, "final_res_block", 2 * u->init_dim, u->init_dim);
+    expect(p, "final_conv.weight", {u->out_dim, u->init_dim, 1, 1});
+    expect(p, "final_conv.bias", {u->out_dim});
+    if (cfg->text_mode == DM_TEXT_CONCAT) {
+        expect(p, "text_proj.0.weight", {td, cfg->text_emb_dim});
+        expect(p, "text_proj.0.bias", {td});
+        expect(p, "text_proj.2.weight", {td, td});
+        expect(p, "text_proj.2.bias", {td});
+        expect(p, "text_concat_proj.weight", {td, 2 * td});
+        expect(p, "text_concat_proj.bias", {td});
+    } else if (cfg->text_mode == DM_TEXT_CROSS) {
+        expect_cross(p, "cross_attn", mid);
+        expect_cross(p, "cross_attn_down", mid);
+        expect_cross(p, "cross_attn_up", mid);
+    }
+    *out = u.release();
+    return 0;
+}
+
+void dm_unet_destroy(dm_unet* u) {
+    if (!u) return;
+    (void)hipSetDevice(u->device);
+    if (u->ws) (void)hipFree(u->ws);
+    if (u->step_dev) (void)hipFree(u->step_dev);
+    if (u->times_dev) (void)hipFree(u->times_dev);
+    if (u->coefs_dev) (void)hipFree(u->coefs_dev);
+    delete u;
+}
+
+int dm_unet_set_param(dm_unet* u, const char* name, const float* data_host, const int64_t* shape, int ndim) {
+    DM_REQUIRE(u && name && data_host && shape, "null argument");
+    DM_REQUIRE(!u->finalized, "set_param after finalize");
+    auto it = u->params.find(name);
+    if (it == u->params.end()) {
+        set_error(std::string("unexpected parameter: ") + name);
+        return 1;
+    }
+    HostTensor& t = it->second;
+    bool ok = (int)t.shape.size() == ndim;
+    for (int i = 0; ok && i < ndim; ++i) ok = t.shape[i] == shape[i];
+    if (!ok) {
+        set_error(std::string("shape mismatch for ") + name);
+        return 1;
+    }
+    t.data.assign(data_host, data_host + t.numel());
+    t.set = true;
+    return 0;
+}
+
+int dm_unet_missing_params(dm_unet* u) {
+    if (!u) return -1;
+    int missing = 0;
+    std::string first;
+    for (auto& kv : u->params)
+        if (!kv.second.set) {
+            if (!missing) first = kv.first;
+            ++missing;
+        }
+    if (missing) set_error("missing parameter: " + first);
+    return missing;
+}
+
+int dm_unet_finalize(dm_unet* u) {
+    DM_REQUIRE(u, "null handle");
+    DM_REQUIRE(!u->finalized, "already finalized");
+    if (dm_unet_missing_params(u) != 0) return 1;
+    DM_CHECK_HIP(hipSetDevice(u->device));
+    const dm_unet_cfg& cfg = u->cfg;
+    const int n = cfg.n_stages;
+    // sinusoid frequencies, fp32 as the reference computes them (DD/denoising_diffusion.py:79-81)
+    {
+        int half = cfg.dim / 2;
+        double k = std::log((double)cfg.sinusoidal_theta) / (half - 1);
+        float kf = (float)(-k);
+        std::vector<float> f(half);
+        for (int i = 0; i < half; ++i) f[i] = std::exp((float)i * kf);
+        if (u->own.upload(f.data(), f.size(), &u->freqs)) return 1;
+    }
+    if (up1(u, "time_mlp.1.weight", &u->tw1) || up1(u, "time_mlp.1.bias", &u->tb1) ||
+        up1(u, "time_mlp.3.weight", &u->tw2) || up1(u, "time_mlp.3.bias", &u->tb2))
+        return 1;
+    if (make_conv(u->own, u->init_conv, P(u, "init_conv.weight").data.data(), P(u, "init_conv.bias").data.data(),
+                  u->init_dim, cfg.input_channels, 0, 7, 7, 1, 3, false)) return 1;
+    std::vector<float> ssw, ssb;
+    int ss_off = 0;
+    u->downs.resize(n);
+    u->ups.resize(n);
+    for (int i = 0; i < n; ++i) {
+        int din = u->dims[i], dout = u->dims[i + 1];
+        std::string q = idx("downs", i);
+        Stage& S = u->downs[i];
+        if (build_resnet(u, S.b1, q + ".0", din, 0, din, ss_off, ssw, ssb)) return 1;
+        if (build_resnet(u, S.b2, q + ".1", din, 0, din, ss_off, ssw, ssb)) return 1;
+        if (build_attn(u, S.attn, q + ".2", din, cfg.full_attn[i] != 0)) return 1;
+        if (i < n - 1) {
+            // pixel-unshuffle + 1x1  ==  2x2 stride-2 conv: W'[o][c][p1][p2] = W[o][c*4 + p1*2 + p2]
+            const HostTensor& w = P(u, q + ".3.1.weight");
+            if (make_conv(u->own, S.resample, w.data.data(), P(u, q + ".3.1.bias").data.data(), dout, din, 0, 2, 2, 2, 0,
+                          false)) return 1;
+        } else {
+            if (make_conv(u->own, S.resample, P(u, q + ".3.weight").data.data(), P(u, q + ".3.bias").data.data(), dout,
+                          din, 0, 3, 3, 1, 1, false)) return 1;
+        }
+    }
+    int mid = u->dims.back();
+    if (build_resnet(u, u->mid1, "mid_block1", mid, 0, mid, ss_off, ssw, ssb)) return 1;
+    if (build_attn(u, u->mid_attn, "mid_attn", mid, true)) return 1;
+    if (build_resnet(u, u->mid2, "mid_block2", mid, 0, mid, ss_off, ssw, ssb)) return 1;
+    for (int j = 0; j < n; ++j) {
+        int din = u->dims[n - 1 - j], dout = u->dims[n - j];
+        std::string q = idx("ups", j);
+        Stage& S = u->ups[j];
+        if (build_resnet(u, S.b1, q + ".0", dout, din, dout, ss_off, ssw, ssb)) return 1;
+        if (build_resnet(u, S.b2, q + ".1", dout, din, dout, ss_off, ssw, ssb)) return 1;
+        if (build_attn(u, S.attn, q + ".2", dout, cfg.full_attn[n - 1 - j] != 0)) return 1;
+        if (j < n - 1) {
+            if (make_conv(u->own, S.resample, P(u, q + ".3.1.weight").data.data(), P(u, q + ".3.1.bias").data.data(), din,
+                          dout, 0, 3, 3, 1, 1, /*up=*/true)) return 1;
+        } else {
+            if (make_conv(u->own, S.resample, P(u, q + ".3.weight").data.data(), P(u, q + ".3.bias").data.data(), din,
+                          dout, 0, 3, 3, 1, 1, false)) return 1;
+        }
+    }
+    if (build_resnet(u, u->final_res, "final_res_block", u->init_dim, u->init_dim, u->init_dim, ss_off, ssw, ssb))
+        return 1;
+    if (make_conv(u->own, u->final_conv, P(u, "final_conv.weight").data.data(), P(u, "final_conv.bias").data.data(),
+                  u->out_dim, u->init_dim, 0, 1, 1, 1, 0, false)) return 1;
+    u->ss_total = ss_off;
+    if (u->own.upload(ssw.data(), ssw.size(), &u->ss_w) || u->own.upload(ssb.data(), ssb.size(), &u->ss_b)) return 1;
+    if (cfg.text_mode == DM_TEXT_CONCAT) {
+        if (up1(u, "text_proj.0.weight", &u->tp_w0) || up1(u, "text_proj.0.bias", &u->tp_b0) ||
+            up1(u, "text_proj.2.weight", &u->tp_w2) || up1(u, "text_proj.2.bias", &u->tp_b2) ||
+            up1(u, "text_concat_proj.weight", &u->tc_w) || up1(u, "text_concat_proj.bias", &u->tc_b))
+            return 1;
+    } else if (cfg.text_mode == DM_TEXT_CROSS) {
+        if (build_cross(u, u->cross_mid, "cross_attn", mid) || build_cross(u, u->cross_down, "cross_attn_down", mid) ||
+            build_cross(u, u->cross_up, "cross_attn_up", mid))
+            return 1;
+    }
+    // the host copies are no longer needed
+    for (auto& kv : u->params) std::vector<float>().swap(kv.second.data);
+    u->finalized = true;
+    return 0;
+}
+
+int dm_unet_forward(dm_unet* u, const float* x, const int64_t* time, const float* ctx, int ctx_tokens, float* out,
+                    int B, int H, int W, void* stream) {
+    DM_REQUIRE(u && x && time && out, "null argument");
+    DM_REQUIRE(u->finalized, "dm_unet_finalize has not been called");
+    DM_REQUIRE(B > 0, "empty batch");
+    if (check_hw(u, H, W)) return 1;
+    DM_CHECK_HIP(hipSetDevice(u->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Arena dry;
+    dry.dry = true;
+    if (unet_forward_impl(u, dry, x, time, nullptr, nullptr, ctx, ctx_tokens, out, B, H, W, s)) return 1;
+    if (ensure_workspace(u, dry.off)) return 1;
+    Arena A;
+    A.base = u->ws;
+    A.cap = u->ws_cap;
+    return unet_forward_impl(u, A, x, time, nullptr, nullptr, ctx, ctx_tokens, out, B, H, W, s);
+}
+
+int dm_sample(dm_unet* u, int kind, int n_steps, const int64_t* times_host, const float* coefs_host,
+              const float* x_T, const float* noise, uint64_t seed, const float* ctx, int ctx_tokens, float* out,
+              float* all_steps, int B, int H, int W, int unnormalize, int use_graph, void* stream) {
+    DM_REQUIRE(u && times_host && coefs_host && x_T && out, "null argument");
+    DM_REQUIRE(u->finalized, "dm_unet_finalize has not been called");
+    DM_REQUIRE(kind == DM_SAMPLER_DDPM || kind == DM_SAMPLER_DDIM, "unknown sampler kind");
+    DM_REQUIRE(n_steps > 0 && B > 0, "empty run");
+    DM_REQUIRE(u->out_dim == u->cfg.channels, "sampler needs out_dim == channels (DD/denoising_diffusion.py:456)");
+    DM_REQUIRE(u->cfg.input_channels == u->cfg.channels, "sampler drives the unconditional / text U-Net input");
+    if (check_hw(u, H, W)) return 1;
+    DM_CHECK_HIP(hipSetDevice(u->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int C = u->cfg.channels;
+    const int64_t n = (int64_t)B * C * H * W;
+
+    if (n_steps > u->sampler_cap) {
+        DM_CHECK_HIP(hipDeviceSynchronize());
+        if (u->times_dev) (void)hipFree(u->times_dev);
+        if (u->coefs_dev) (void)hipFree(u->coefs_dev);
+        if (!u->step_dev) DM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&u->step_dev), 64));
+        DM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&u->times_dev), n_steps * sizeof(int64_t)));
+        DM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&u->coefs_dev), (size_t)n_steps * DM_COEFS * sizeof(float)));
+        u->sampler_cap = n_steps;
+    }
+    // workspace: [x | eps | forward arena]
+    Arena dry;
+    dry.dry = true;
+    dry.alloc(n);
+    dry.alloc(n);
+    if (unet_forward_impl(u, dry, nullptr, nullptr, u->times_dev, u->step_dev, ctx, ctx_tokens, nullptr, B, H, W, s))
+        return 1;
+    if (ensure_workspace(u, dry.off)) return 1;
+
+    DM_CHECK_HIP(hipMemcpyAsync(u->times_dev, times_host, n_steps * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    DM_CHECK_HIP(hipMemcpyAsync(u->coefs_dev, coefs_host, (size_t)n_steps * DM_COEFS * sizeof(float),
+                                hipMemcpyHostToDevice, s));
+    DM_CHECK_HIP(hipMemsetAsync(u->step_dev, 0, sizeof(int), s));
+    DM_CHECK_HIP(hipStreamSynchronize(s));  // host tables may be freed by the caller after return anyway
+
+    Arena A;
+    A.base = u->ws;
+    A.cap = u->ws_cap;
+    float* xbuf = A.alloc(n);
+    float* eps = A.alloc(n);
+    const size_t arena_mark = A.off;
+    DM_CHECK_HIP(hipMemcpyAsync(xbuf, x_T, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (all_steps) DM_CHECK_HIP(hipMemcpyAsync(all_steps, x_T, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+
+    auto one_step = [&](hipStream_t st) -> int {
+        A.off = arena_mark;
+        if (unet_forward_impl(u, A, xbuf, nullptr, u->times_dev, u->step_dev, ctx, ctx_tokens, eps, B, H, W, st))
+            return 1;
+        if (launch_sampler_update(kind, xbuf, eps, noise, u->coefs_dev, u->step_dev, n, seed, xbuf, all_steps, out,
+                                  unnormalize, n_steps, n, st))
+            return 1;
+        return launch_step_advance(u->step_dev, st);
+    };
+
+    if (!use_graph) {
+        for (int i = 0; i < n_steps; ++i)
+            if (one_step(s)) return 1;
+        return 0;
+    }
+    // capture one denoise step (all pointers and shapes are static; t, coefficients and the
+    // noise row are read through the device-side step counter) and replay it n_steps times
+    hipStream_t cs = s;
+    bool own_stream = false;
+    if (cs == nullptr) {  // the legacy default stream cannot be captured
+        DM_CHECK_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        own_stream = true;
+        DM_CHECK_HIP(hipStreamSynchronize(s));
+    }
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    DM_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    int rc = one_step(cs);
+    hipError_t ce = hipStreamEndCapture(cs, &graph);
+    if (rc || ce != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        if (own_stream) (void)hipStreamDestroy(cs);
+        if (!rc) set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+        return 1;
+    }
+    DM_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    for (int i = 0; i < n_steps; ++i) DM_CHECK_HIP(hipGraphLaunch(exec, cs));
+    DM_CHECK_HIP(hipStreamSynchronize(cs));
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    if (own_stream) (void)hipStreamDestroy(cs);
+    return 0;
+}
+
+int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, void* stream) {
+    DM_REQUIRE(out && n >= 0, "bad argument");
+    return launch_randn(out, n, seed, draw, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"
+
+// single-operator entry points (dm_op_*) and the VAE decoder share the helpers above
+#include "dm_ops.inc"
+#include "dm_vae.inc"

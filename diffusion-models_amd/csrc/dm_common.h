@@ -1,0 +1,132 @@
+// Internal declarations shared by the HIP translation units of libdm_hip.so.
+// gfx950 (MI355X) only: 64-wide wavefronts, f32-input MFMA, 160 KiB LDS per CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+namespace dm {
+
+void set_error(const std::string& msg);
+
+#define DM_CHECK_HIP(expr)                                                                  \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            dm::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));               \
+            return 1;                                                                       \
+        }                                                                                   \
+    } while (0)
+
+#define DM_REQUIRE(cond, msg)                                                               \
+    do {                                                                                    \
+        if (!(cond)) {                                                                      \
+            dm::set_error(std::string(msg) + " [" #cond "]");                                \
+            return 1;                                                                       \
+        }                                                                                   \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on the f32 MFMA (conv_mfma.hip)
+// ---------------------------------------------------------------------------------------
+// Activations are NHWC fp32 inside the library.  A convolution is
+//   D[pixel][cout] = sum_{tap, cin} A[pixel + tap][cin] * W[tap][cin][cout]
+// Pixels are the MFMA rows, output channels the MFMA columns, (tap, cin) the reduction.
+
+enum ConvEpilogue : int {
+    EPI_BIAS = 1,        // + bias[cout]
+    EPI_NORM = 2,        // RMSNorm over cout: v / max(||v||, 1e-12) * g[cout] * sqrt(Cout)   (needs NT >= Cout)
+    EPI_SCALE_SHIFT = 4, // v * (scale[b][cout] + 1) + shift[b][cout]
+    EPI_SILU = 8,        // v * sigmoid(v)
+    EPI_RESIDUAL = 16,   // + residual[pixel][cout]
+};
+
+struct ConvGeom {
+    // tiling of the output, chosen on the host (conv_plan)
+    int WM, WN;          // waves along pixels / couts (WM*WN == 4); tile = (64*WM) x (64*WN)
+    int CK;              // channels per K chunk: 16, or 4 for thin inputs
+    int TW, TH, NB;      // output tile: NB images x TH rows x TW cols (TW, TH powers of two)
+    int lTW, lTH;        // log2
+    int tiles_x, tiles_y, groups, n_tiles_n;
+    int IH, IW;          // staged input window per image
+    int halo_floats;     // LDS floats for the activation window (multiple of 4)
+    int lds_bytes;
+};
+
+struct ConvParams {
+    const float* in0;
+    const float* in1;
+    int C0, C1;          // real channels of each source (concat along C)
+    int chunks0;         // K chunks that come from source 0
+    int n_chunks;        // total K chunks
+    int Hin, Win;        // spatial size the convolution sees (after nearest x2 if up)
+    int up;              // sources are (Hin/2, Win/2), nearest-upsampled on the fly
+    int in_nchw;         // source 0 is NCHW (boundary tensors); requires C1 == 0
+    const float* w;      // packed [n_tile][chunk][ky][kx][NT][CK]
+    const float* bias;
+    int Cout, KH, KW, stride, pad;
+    int B, Ho, Wo;
+    float* out;
+    int out_nchw;
+    int epi;
+    const float* residual;   // NHWC [pixel][Cout]
+    const float* g;          // [Cout]
+    const float* scale;      // scale[b * ss_stride + c], shift = scale + Cout
+    int ss_stride;
+    ConvGeom geo;
+};
+
+// choose tiling for an output of (B, Ho, Wo, Cout) and a KHxKW/stride window
+ConvGeom conv_plan(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, int Cin_total, bool want_norm);
+// NT (couts per tile) the packer must use for a layer with Cout output channels
+int conv_nt_for(int Cout, bool want_norm);
+int conv_ck_for(int C0, int C1);
+// floats needed for packed weights
+size_t conv_packed_floats(int Cout, int C0, int C1, int KH, int KW, bool want_norm);
+// pack OIHW (Cout, C0+C1, KH, KW) -> kernel layout (host side)
+void conv_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1, int KH, int KW, bool want_norm);
+int conv_launch(const ConvParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// Elementwise / reduction kernels (elementwise.hip); all NHWC unless noted
+// ---------------------------------------------------------------------------------------
+int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t s);
+int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t s);
+// y = [silu]( rmsnorm(x)*g*sqrt(C) [*(scale+1)+shift] ) [+ residual]; rows = pixels
+int launch_norm_act(const float* x, const float* g, const float* scale, int ss_stride, int pix_per_image,
+                    const float* residual, float* y, int64_t rows, int C, int flags, hipStream_t s);
+// y[r][o] = act_out(bias[o] + sum_i act_in(x[r][i]) * W[o][i]);  act: 0 none, 1 silu, 2 gelu(erf)
+int launch_linear_rows(const float* x, int ldx, const float* W, const float* bias, float* y, int ldy, int R, int I,
+                       int O, int act_in, int act_out, hipStream_t s);
+// e[r] = cat(sin(t[r]*f), cos(t[r]*f)); t int64; if step_times != nullptr t = step_times[*step]
+int launch_sinusoid(const int64_t* t, const int64_t* step_times, const int* step, const float* freqs, float* e,
+                    int R, int half, hipStream_t s);
+// GroupNorm(32 groups) + optional swish, NHWC
+int launch_group_norm(const float* x, const float* w, const float* b, float* y, float* stats_ws, int B, int HW,
+                      int C, int groups, float eps, int swish, hipStream_t s);
+int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s);
+
+struct StepState;  // device-resident sampler state (see dm_api.hip)
+int launch_sampler_update(int kind, const float* x, const float* eps, const float* noise, const float* coefs_dev,
+                          const int* step_dev, int64_t noise_step_stride, uint64_t seed, float* out,
+                          float* all_steps, float* final_out, int unnormalize, int n_steps, int64_t n,
+                          hipStream_t s);
+int launch_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, hipStream_t s);
+int launch_step_advance(int* step_dev, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// Attention cores (attention.hip); qkv is NHWC (B, n, 3*heads*dh) = [q | k | v] per pixel
+// ---------------------------------------------------------------------------------------
+// LinearAttention core: out (B, n, heads*dh)
+int launch_linear_attention_core(const float* qkv, const float* mem_kv, float* ctx_ws, float* out, int B, int n,
+                                 int heads, int dh, hipStream_t s);
+// softmax(q k^T * scale) v with `n_mem` learned key/value rows prepended.
+//   q: rows of length ldq per query token (head h at column h*dh), k/v likewise with ldk
+//   mem_k/mem_v: (heads, n_mem, dh) or nullptr
+int launch_attention_core(const float* q, int ldq, const float* k, const float* v, int ldk, const float* mem_k,
+                          const float* mem_v, int n_mem, float* out, int ldo, int B, int nq, int nk, int heads,
+                          int dh, float scale, hipStream_t s);
+
+}  // namespace dm

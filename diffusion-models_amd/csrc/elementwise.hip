@@ -1,0 +1,345 @@
+// Bandwidth-bound kernels of the sampling path (gfx950): layout changes at the NCHW boundary,
+// RMSNorm / GroupNorm, the small Linear layers of the time embedding, the DDPM/DDIM update and
+// the Philox noise generator.  One wavefront = 64 lanes throughout.
+#include "dm_common.h"
+
+namespace dm {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float gelu_erf_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// ---------------------------------------------------------------------------------------
+// NCHW <-> NHWC (boundary tensors only: 3-4 channels)
+// ---------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = i % C;
+    int64_t r = i / C;
+    int p = r % HW;
+    int64_t b = r / HW;
+    out[i] = in[(b * C + c) * HW + p];
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int p = i % HW;
+    int64_t r = i / HW;
+    int c = r % C;
+    int64_t b = r / C;
+    out[i] = in[(b * HW + p) * C + c];
+}
+int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t s) {
+    int64_t n = (int64_t)B * C * HW;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, C, HW, n);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t s) {
+    int64_t n = (int64_t)B * C * HW;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, C, HW, n);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// RMSNorm (+ scale/shift, SiLU, residual): one wavefront per pixel row of C channels.
+// Restates RMSNorm.forward (DD/denoising_diffusion.py:66-67) and the tail of Block.forward
+// (:115-121) for layers whose output channels do not fit one conv workgroup.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void norm_act_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                       const float* __restrict__ scale, int ss_stride,
+                                                       int pix_per_image, const float* __restrict__ residual,
+                                                       float* __restrict__ y, int64_t rows, int C, int flags) {
+    const int lane = threadIdx.x & 63;
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    float* yr = y + row * C;
+    float rn = 1.0f;
+    if (flags & EPI_NORM) {
+        float ss = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            float v = xr[c];
+            ss += v * v;
+        }
+        ss = wave_sum(ss);
+        rn = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
+    }
+    const float* sp = nullptr;
+    if (flags & EPI_SCALE_SHIFT) sp = scale + (row / pix_per_image) * (int64_t)ss_stride;
+    for (int c = lane; c < C; c += 64) {
+        float v = xr[c];
+        if (flags & EPI_NORM) v = v * rn * g[c];
+        if (flags & EPI_SCALE_SHIFT) v = v * (sp[c] + 1.0f) + sp[C + c];
+        if (flags & EPI_SILU) v = silu_f(v);
+        if (flags & EPI_RESIDUAL) v += residual[row * C + c];
+        yr[c] = v;
+    }
+}
+int launch_norm_act(const float* x, const float* g, const float* scale, int ss_stride, int pix_per_image,
+                    const float* residual, float* y, int64_t rows, int C, int flags, hipStream_t s) {
+    hipLaunchKernelGGL(norm_act_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, scale, ss_stride,
+                       pix_per_image, residual, y, rows, C, flags);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// y[r][o] = act_out(bias[o] + sum_i act_in(x[r][i]) * W[o][i])   (nn.Linear layout, wave per output)
+// time_mlp (DD/denoising_diffusion.py:280-285), ResnetBlock.mlp (:127-130), CrossAttention k/v
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, int ldx,
+                                                          const float* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          int ldy, int I, int O, int act_in, int act_out) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = blockIdx.y;
+    if (o >= O) return;
+    const float* xr = x + (size_t)r * ldx;
+    const float* wr = W + (size_t)o * I;
+    float acc = 0.f;
+    for (int i = lane; i < I; i += 64) {
+        float v = xr[i];
+        if (act_in == 1) v = silu_f(v);
+        else if (act_in == 2) v = gelu_erf_f(v);
+        acc += v * wr[i];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        if (bias) acc += bias[o];
+        if (act_out == 1) acc = silu_f(acc);
+        else if (act_out == 2) acc = gelu_erf_f(acc);
+        y[(size_t)r * ldy + o] = acc;
+    }
+}
+int launch_linear_rows(const float* x, int ldx, const float* W, const float* bias, float* y, int ldy, int R, int I,
+                       int O, int act_in, int act_out, hipStream_t s) {
+    if (R == 0 || O == 0) return 0;
+    hipLaunchKernelGGL(linear_rows_kernel, dim3((O + 3) / 4, R), dim3(256), 0, s, x, ldx, W, bias, y, ldy, I, O,
+                       act_in, act_out);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// SinusoidalPosEmb.forward (DD/denoising_diffusion.py:77-84); freqs are computed on the host
+// exactly as the reference computes them (fp32) so only sin/cos run here.
+__global__ void sinusoid_kernel(const int64_t* __restrict__ t, const int64_t* __restrict__ step_times,
+                                const int* __restrict__ step, const float* __restrict__ freqs,
+                                float* __restrict__ e, int R, int half) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * half) return;
+    int r = i / half, k = i - r * half;
+    int64_t tv = step_times ? step_times[*step] : t[r];
+    float a = (float)tv * freqs[k];
+    e[(size_t)r * 2 * half + k] = sinf(a);
+    e[(size_t)r * 2 * half + half + k] = cosf(a);
+}
+int launch_sinusoid(const int64_t* t, const int64_t* step_times, const int* step, const float* freqs, float* e,
+                    int R, int half, hipStream_t s) {
+    int n = R * half;
+    hipLaunchKernelGGL(sinusoid_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, step_times, step, freqs, e, R,
+                       half);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// GroupNorm(32, eps) [+ swish], NHWC (VAE decoder only; LD/modules/diffusionmodules/model.py:55-56)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void group_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                          int HW, int C, int groups, float eps) {
+    const int b = blockIdx.y, grp = blockIdx.x;
+    const int cg = C / groups;
+    const int64_t n = (int64_t)HW * cg;
+    const float* xb = x + (size_t)b * HW * C + grp * cg;
+    __shared__ float red[4];
+    __shared__ float mean_s;
+    float sum = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        int64_t p = i / cg;
+        int j = i - p * cg;
+        sum += xb[p * C + j];
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) mean_s = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+    __syncthreads();
+    const float mean = mean_s;
+    float var = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        int64_t p = i / cg;
+        int j = i - p * cg;
+        float d = xb[p * C + j] - mean;
+        var += d * d;
+    }
+    var = wave_sum(var);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = var;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+        stats[((size_t)b * groups + grp) * 2 + 0] = mean;
+        stats[((size_t)b * groups + grp) * 2 + 1] = 1.0f / sqrtf(v + eps);
+    }
+}
+__global__ void group_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                   float* __restrict__ y, int HW, int C, int groups, int swish, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = i % C;
+    int64_t b = i / ((int64_t)HW * C);
+    int grp = c / (C / groups);
+    const float* st = stats + (b * groups + grp) * 2;
+    float v = (x[i] - st[0]) * st[1] * w[c] + bias[c];
+    if (swish) v = v / (1.0f + __expf(-v));
+    y[i] = v;
+}
+int launch_group_norm(const float* x, const float* w, const float* b, float* y, float* stats_ws, int B, int HW,
+                      int C, int groups, float eps, int swish, hipStream_t s) {
+    // stats_ws: B*groups*2 floats of scratch (mean, rstd)
+    hipLaunchKernelGGL(group_stats_kernel, dim3(groups, B), dim3(256), 0, s, x, stats_ws, HW, C, groups, eps);
+    int64_t n = (int64_t)B * HW * C;
+    hipLaunchKernelGGL(group_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, stats_ws, w, b, y, HW, C,
+                       groups, swish, n);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = a[i] + b[i];
+}
+int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(add_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, y, n);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t draw, uint64_t idx4, float z[4]) {
+    uint32_t c[4] = {(uint32_t)idx4, (uint32_t)(idx4 >> 32), (uint32_t)draw, (uint32_t)(draw >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float inv = 2.3283064365386963e-10f;  // 2^-32
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float u1 = ((float)c[2 * h] + 1.0f) * inv;  // (0, 1]
+        float u2 = (float)c[2 * h + 1] * inv;
+        float rad = sqrtf(-2.0f * logf(fminf(u1, 1.0f)));
+        float ang = 6.283185307179586f * u2;
+        z[2 * h] = rad * cosf(ang);
+        z[2 * h + 1] = rad * sinf(ang);
+    }
+}
+__global__ void randn_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t draw) {
+    int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 * 4 >= n) return;
+    float z[4];
+    philox_normal4(seed, draw, (uint64_t)i4, z);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (i4 * 4 + j < n) out[i4 * 4 + j] = z[j];
+}
+int launch_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, hipStream_t s) {
+    int64_t n4 = (n + 3) / 4;
+    hipLaunchKernelGGL(randn_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, out, n, seed, draw);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// One sampler update (elementwise, layout-agnostic).  Restates, for objective pred_noise:
+//   DDPM  DD/denoising_diffusion.py:570-574 (x0), :633 (clamp), :594-598 (posterior mean), :643-644
+//   DDIM  DD/denoising_diffusion.py:607-613 (x0, clamp, re-derived eps), :686-701
+// Contraction is off so that the expression tree rounds exactly like the reference's tensor ops.
+// ---------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__global__ void sampler_update_kernel(int kind, const float* __restrict__ x, const float* __restrict__ eps,
+                                      const float* __restrict__ noise, const float* __restrict__ coefs,
+                                      const int* __restrict__ step_dev, int64_t noise_step_stride, uint64_t seed,
+                                      float* __restrict__ out, float* __restrict__ all_steps,
+                                      float* __restrict__ final_out, int unnormalize, int n_steps, int64_t n) {
+    const int step = step_dev ? *step_dev : 0;
+    const float* c = coefs + (size_t)step * 8;
+    const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4];
+    const bool flag = c[5] != 0.0f;
+    int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 * 4 >= n) return;
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (flag) {
+        if (noise) {
+            const float* np = noise + (size_t)step * noise_step_stride;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i4 * 4 + j < n) z[j] = np[i4 * 4 + j];
+        } else if (c4 != 0.0f) {
+            philox_normal4(seed, (uint64_t)step + 1, (uint64_t)i4, z);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int64_t i = i4 * 4 + j;
+        if (i >= n) break;
+        float xv = x[i], ev = eps[i];
+        float x0 = c0 * xv - c1 * ev;
+        x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        float r;
+        if (kind == 0) {
+            float mean = c2 * x0 + c3 * xv;
+            r = flag ? mean + c4 * z[j] : mean + c4 * 0.0f;
+        } else {
+            float e2 = (c0 * xv - x0) / c1;
+            r = flag ? (x0 * c2 + c3 * e2) + c4 * z[j] : x0;
+        }
+        out[i] = r;
+        if (all_steps) all_steps[(size_t)(step + 1) * n + i] = r;
+        if (final_out && step == n_steps - 1) final_out[i] = unnormalize ? (r + 1.0f) * 0.5f : r;
+    }
+}
+#pragma clang fp contract(fast)
+
+int launch_sampler_update(int kind, const float* x, const float* eps, const float* noise, const float* coefs_dev,
+                          const int* step_dev, int64_t noise_step_stride, uint64_t seed, float* out,
+                          float* all_steps, float* final_out, int unnormalize, int n_steps, int64_t n,
+                          hipStream_t s) {
+    int64_t n4 = (n + 3) / 4;
+    hipLaunchKernelGGL(sampler_update_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, kind, x, eps, noise,
+                       coefs_dev, step_dev, noise_step_stride, seed, out, all_steps, final_out, unnormalize,
+                       n_steps, n);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void step_advance_kernel(int* step) { *step += 1; }
+int launch_step_advance(int* step_dev, hipStream_t s) {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, step_dev);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dm

@@ -1,0 +1,293 @@
+"""Host-side mirror of the reference diffusion wrappers: same method names,
+arguments, return shapes and assertions, with the loop executed by
+``dm_sample`` in libdm_hip.so (hipGraph-replayed denoise step).
+
+Reference surface mirrored (paths relative to the reference checkout):
+  denoising-diffusion-pytorch/denoising_diffusion/denoising_diffusion.py
+      :435-568  DenoisingDiffusion.__init__ / buffers / device
+      :638-664  p_sample, p_sample_loop      :666-708 ddim_sample     :779-783 sample
+  denoising-diffusion-pytorch/denoising_diffusion/denoising_diffusion_text_conditional.py
+      :264-453  TextConditionalDenoisingDiffusion (text_emb threaded through the loop)
+  latent-diffusion/ldm/models/latent_diffusion.py:9-66  LatentDiffusion
+
+Extensions (keyword-only, default to the reference behaviour): ``noise`` injects
+the N(0,1) draws (a callable ``shape -> cpu tensor`` called in the reference's
+draw order, e.g. ``oracle.sampler_oracle.NoiseStream``) for parity tests;
+``seed`` selects the device Philox stream used otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pickle
+import random
+from pathlib import Path
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .spec import SCHEDULE_BUFFERS, ddim_step_table, ddpm_step_table, make_schedule
+
+DDPM, DDIM = 0, 1
+
+
+def _identity(t, *a, **k):
+    return t
+
+
+class DenoisingDiffusion:
+    def __init__(
+        self,
+        model,
+        *,
+        image_size,
+        timesteps=1000,
+        sampling_timesteps=None,
+        objective="pred_noise",
+        beta_schedule="linear",
+        schedule_fn_kwargs=dict(),
+        ddim_sampling_eta=0.0,
+        auto_normalize=True,
+        use_graph=True,
+        **_training_only,  # offset_noise_strength, min_snr_*, immiscible, ddpm, hybrid_loss: training half
+    ):
+        assert not (type(self) == DenoisingDiffusion and model.channels != model.out_dim)
+        assert not getattr(model, "random_or_learned_sinusoidal_cond", False)
+        self.model = model
+        self.channels = model.channels
+        self.self_condition = model.self_condition
+        if isinstance(image_size, int):
+            image_size = (image_size, image_size)
+        assert isinstance(image_size, (tuple, list)) and len(image_size) == 2, (
+            "image size must be a integer or a tuple/list of two integers"
+        )
+        self.image_size = tuple(image_size)
+        assert objective in {"pred_noise", "pred_x0", "pred_v"}, "objective must be pred_noise, pred_x0 or pred_v"
+        if objective != "pred_noise":
+            raise NotImplementedError("the HIP sampling path implements objective='pred_noise' (the reference default)")
+        if self.self_condition:
+            raise NotImplementedError("self-conditioning is not on the accelerated sampling path")
+        self.objective = objective
+        sched = make_schedule(timesteps, beta_schedule, **schedule_fn_kwargs)  # raises ValueError on unknown name
+        self.num_timesteps = int(sched["betas"].shape[0])
+        self.sampling_timesteps = sampling_timesteps if sampling_timesteps is not None else self.num_timesteps
+        assert self.sampling_timesteps <= self.num_timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < self.num_timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+        self._sched = sched  # fp32 CPU tensors; the per-step scalars are derived from them on the host
+        for k, v in sched.items():
+            setattr(self, k, v)
+        self.normalize = (lambda img: img * 2 - 1) if auto_normalize else _identity
+        self.unnormalize = (lambda t: (t + 1) * 0.5) if auto_normalize else _identity
+        self._unnormalize_flag = 1 if auto_normalize else 0
+        self.use_graph = use_graph
+        self._lib = _lib.load()
+
+    # -- module-ish surface the reference's callers touch -------------------------------------------
+    @property
+    def device(self):
+        return self.model.device
+
+    def eval(self):
+        return self
+
+    def state_dict(self):
+        return {k: getattr(self, k) for k in SCHEDULE_BUFFERS}
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts ``DenoisingDiffusion.state_dict()``: 13 schedule buffers + ``model.*``."""
+        model_sd = {k[len("model."):]: v for k, v in state_dict.items() if k.startswith("model.")}
+        for k in SCHEDULE_BUFFERS:
+            if k in state_dict:
+                if tuple(state_dict[k].shape) != tuple(self._sched[k].shape):
+                    raise RuntimeError(f"size mismatch for {k}")
+                self._sched[k] = state_dict[k].detach().to("cpu", torch.float32).clone()
+                setattr(self, k, self._sched[k])
+            elif strict:
+                raise RuntimeError(f"missing schedule buffer {k}")
+        self.model.load_state_dict(model_sd, strict=strict)
+        return self
+
+    # -- per-step scalars, computed as the reference computes them (fp32 tensor arithmetic) --------
+    def _ddpm_tables(self) -> Tuple[List[int], torch.Tensor]:
+        return ddpm_step_table(self._sched)
+
+    def _ddim_tables(self, S: int) -> Tuple[List[int], torch.Tensor]:
+        return ddim_step_table(self._sched, S, self.ddim_sampling_eta)
+
+    # -- the loop --------------------------------------------------------------------------------------
+    def _randn(self, shape, seed: int, draw: int) -> torch.Tensor:
+        out = torch.empty(tuple(shape), device=self.device, dtype=torch.float32)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.dm_randn(_lib.ptr(out), out.numel(), seed, draw, stream))
+        return out
+
+    def _run(self, kind, shape, times, coefs, takes_noise: Sequence[bool], return_all_timesteps, noise, seed,
+             text_emb=None, max_steps=None):
+        shape = tuple(int(v) for v in shape)
+        B, Cc, H, W = shape
+        assert Cc == self.channels, f"shape has {Cc} channels, the model {self.channels}"
+        n_steps = len(times)
+        if seed is None:
+            seed = random.getrandbits(63)
+        if noise is not None:
+            x_T = noise(shape).to(self.device, torch.float32).contiguous()
+            rows = []
+            zero = None
+            for flag in takes_noise:
+                if flag:
+                    rows.append(noise(shape).to(torch.float32))
+                else:
+                    zero = zero if zero is not None else torch.zeros(shape, dtype=torch.float32)
+                    rows.append(zero)
+            noise_dev = torch.stack(rows, dim=0).to(self.device).contiguous()
+        else:
+            x_T = self._randn(shape, seed, 0)
+            noise_dev = None
+        if max_steps is not None:  # bounded run (bench / smoke): first `max_steps` iterations only
+            n_steps = min(n_steps, int(max_steps))
+        ctx, m = (None, 0)
+        if text_emb is not None:
+            ctx, m = self.model._ctx(text_emb, B)
+        out = torch.empty(shape, device=self.device, dtype=torch.float32)
+        all_steps = (torch.empty((n_steps + 1,) + shape, device=self.device, dtype=torch.float32)
+                     if return_all_timesteps else None)
+        times_arr = (C.c_int64 * n_steps)(*[int(t) for t in times[:n_steps]])
+        coefs = coefs[:n_steps].contiguous()
+        coefs_ptr = C.cast(coefs.data_ptr(), C.POINTER(C.c_float))
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.dm_sample(
+            self.model._handle, kind, n_steps, times_arr, coefs_ptr, _lib.ptr(x_T), _lib.ptr(noise_dev),
+            C.c_uint64(seed), _lib.ptr(ctx), m, _lib.ptr(out), _lib.ptr(all_steps), B, H, W,
+            self._unnormalize_flag, 1 if self.use_graph else 0, stream))
+        if not return_all_timesteps:
+            return out
+        ret = all_steps.permute(1, 0, 2, 3, 4).contiguous()  # (B, n_steps+1, C, H, W) like torch.stack(imgs, dim=1)
+        return self.unnormalize(ret)
+
+    @torch.inference_mode()
+    def p_sample_loop(self, shape, return_all_timesteps=False, *, noise=None, seed=None, max_steps=None, text_emb=None):
+        times, coefs = self._ddpm_tables()
+        takes = [t > 0 for t in times]
+        return self._run(DDPM, shape, times, coefs, takes, return_all_timesteps, noise, seed, text_emb, max_steps)
+
+    @torch.inference_mode()
+    def ddim_sample(self, shape, sampling_timesteps=None, return_all_timesteps=False, *, noise=None, seed=None,
+                    max_steps=None, text_emb=None):
+        if sampling_timesteps is None:
+            sampling_timesteps = self.sampling_timesteps
+        times, coefs = self._ddim_tables(sampling_timesteps)
+        takes = [bool(c[5] != 0) for c in coefs]
+        return self._run(DDIM, shape, times, coefs, takes, return_all_timesteps, noise, seed, text_emb, max_steps)
+
+    @torch.inference_mode()
+    def sample(self, batch_size=16, return_all_timesteps=False, **kw):
+        (h, w), channels = self.image_size, self.channels
+        sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
+        return sample_fn((batch_size, channels, h, w), return_all_timesteps=return_all_timesteps, **kw)
+
+    @torch.inference_mode()
+    def p_sample(self, x, t: int, x_self_cond=None, *, noise=None, text_emb=None):
+        """One reverse step (denoising_diffusion.py:638-645): returns (pred_img, x_start)."""
+        b = x.shape[0]
+        bt = torch.full((b,), t, device=self.device, dtype=torch.long)
+        eps = self.model(x, bt, text_emb=text_emb) if text_emb is not None else self.model(x, bt)
+        s = self._sched
+        c0, c1 = s["sqrt_recip_alphas_cumprod"][t], s["sqrt_recipm1_alphas_cumprod"][t]
+        x = x.to(self.device, torch.float32).contiguous()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        # x_start through the DDIM form of the update kernel with the "last step" flag (returns clamp(x0))
+        coef0 = (C.c_float * _lib.DM_COEFS)(float(c0), float(c1), 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+        x_start = torch.empty_like(x)
+        _lib.check(self._lib.dm_op_sampler_update(DDIM, _lib.ptr(x), _lib.ptr(eps), None, coef0, _lib.ptr(x_start),
+                                                  x.numel(), stream))
+        coef = (C.c_float * _lib.DM_COEFS)(float(c0), float(c1), float(s["posterior_mean_coef1"][t]),
+                                           float(s["posterior_mean_coef2"][t]),
+                                           float((0.5 * s["posterior_log_variance_clipped"][t]).exp()),
+                                           1.0 if t > 0 else 0.0, 0.0, 0.0)
+        z = None
+        if t > 0:
+            z = (noise(x.shape).to(self.device, torch.float32).contiguous() if noise is not None
+                 else self._randn(x.shape, random.getrandbits(63), 1))
+        out = torch.empty_like(x)
+        _lib.check(self._lib.dm_op_sampler_update(DDPM, _lib.ptr(x), _lib.ptr(eps), _lib.ptr(z), coef, _lib.ptr(out),
+                                                  x.numel(), stream))
+        return out, x_start
+
+
+class TextConditionalDenoisingDiffusion(DenoisingDiffusion):
+    """Pipes ``text_emb`` through the U-Net at every step
+    (denoising_diffusion_text_conditional.py:264-453)."""
+
+    def __init__(self, *, model, embedding_file=None, **kwargs):
+        super().__init__(model, **kwargs)
+        if embedding_file is not None:
+            assert os.path.exists(embedding_file), "Pre-computed caption embeddings file not found."
+        self.embedding_file = Path(embedding_file) if embedding_file is not None else None
+
+    def get_random_text_condition(self, batch, device):
+        """Random caption embeddings from the pickle the training pipeline wrote (:320-363)."""
+        assert self.embedding_file is not None, "no embedding_file given; pass text_emb= to sample()"
+        with open(self.embedding_file, "rb") as f:
+            table = pickle.load(f)  # the user's own precomputed file, as in the reference
+        keys = list(table.keys())
+        embs, texts = [], []
+        for key in random.choices(keys, k=batch):
+            data = table[key]
+            i = random.randint(0, data["embeddings"].shape[0] - 1)
+            embs.append(torch.tensor(data["embeddings"][i], dtype=torch.float))
+            texts.append(data["captions"][i])
+        return torch.stack(embs, dim=0).to(device), texts
+
+    def _text(self, batch, save_path_for_text, text_emb):
+        if text_emb is None:
+            text_emb, texts = self.get_random_text_condition(batch, self.device)
+            if save_path_for_text is not None:
+                mode = "a" if os.path.exists(save_path_for_text) else "w"
+                with open(save_path_for_text, mode) as f:
+                    for t in texts:
+                        f.write(t + "\n")
+        return text_emb
+
+    @torch.inference_mode()
+    def p_sample_loop(self, shape, save_path_for_text=None, return_all_timesteps=False, *, text_emb=None, **kw):
+        text_emb = self._text(shape[0], save_path_for_text, text_emb)
+        return super().p_sample_loop(shape, return_all_timesteps, text_emb=text_emb, **kw)
+
+    @torch.inference_mode()
+    def ddim_sample(self, shape, save_path_for_text=None, sampling_timesteps=None, return_all_timesteps=False, *,
+                    text_emb=None, **kw):
+        text_emb = self._text(shape[0], save_path_for_text, text_emb)
+        return super().ddim_sample(shape, sampling_timesteps, return_all_timesteps, text_emb=text_emb, **kw)
+
+    @torch.inference_mode()
+    def sample(self, batch_size=16, save_path_for_text=None, return_all_timesteps=False, **kw):
+        (h, w), channels = self.image_size, self.channels
+        sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
+        return sample_fn((batch_size, channels, h, w), save_path_for_text, return_all_timesteps=return_all_timesteps,
+                         **kw)
+
+
+class LatentDiffusion(DenoisingDiffusion):
+    """Diffusion on VAE latents, then decode (latent_diffusion.py:9-66)."""
+
+    def __init__(self, model, vae, latent_shape, **kwargs):
+        kwargs.setdefault("auto_normalize", True)
+        super().__init__(model, image_size=latent_shape[1], **kwargs)
+        self.vae = vae
+        self.latent_channels = latent_shape[0]
+        self.model.channels = self.latent_channels
+        self.normalize = _identity  # latent_diffusion.py:25-26
+        self.unnormalize = _identity
+        self._unnormalize_flag = 0
+
+    def decode(self, latents):
+        return self.vae.decode(latents)
+
+    @torch.inference_mode()
+    def sample(self, batch_size=16, return_all_timesteps=False, **kw):
+        (h, w), channels = self.image_size, self.channels
+        sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
+        latents = sample_fn((batch_size, channels, h, w), return_all_timesteps=return_all_timesteps, **kw)
+        return self.decode(latents)

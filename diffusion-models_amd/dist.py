@@ -1,0 +1,50 @@
+"""Batch-sharded sampling across the GPUs of one node: one process per GPU, every
+rank samples its slice of the batch with the full weight replica, and ONE
+collective (all-gather over RCCL/xGMI; gloo in CPU tests) assembles the result.
+
+The reference never shards sampling (it runs on the main process only,
+denoising_diffusion.py:1188-1198); samples are independent through the whole
+loop, so there is no exchange step inside it."""
+from __future__ import annotations
+
+from typing import Callable, List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(batch_size: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous slice [lo, hi) of the global batch owned by `rank` (sizes differ by at most 1)."""
+    base, rem = divmod(batch_size, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_sizes(batch_size: int, world_size: int) -> List[int]:
+    return [shard_bounds(batch_size, world_size, r)[1] - shard_bounds(batch_size, world_size, r)[0]
+            for r in range(world_size)]
+
+
+def gather_shards(local: torch.Tensor, batch_size: int, group=None) -> torch.Tensor:
+    """All-gather per-rank shards (dim 0) into the (batch_size, ...) tensor on every rank."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world = dist.get_world_size(group)
+    sizes = shard_sizes(batch_size, world)
+    mx = max(sizes)
+    pad = local
+    if local.shape[0] < mx:  # ragged tail: pad to the common size for the collective
+        pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad.contiguous(), group=group)
+    return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
+
+
+def sample_sharded(sample_fn: Callable[[int, int], torch.Tensor], batch_size: int, group=None) -> torch.Tensor:
+    """`sample_fn(lo, hi)` produces samples [lo, hi) of the global batch on this rank's GPU
+    (key any randomness by the GLOBAL sample index so the result does not depend on the world size)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return sample_fn(0, batch_size)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_bounds(batch_size, world, rank)
+    return gather_shards(sample_fn(lo, hi), batch_size, group)

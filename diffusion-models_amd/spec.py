@@ -288,14 +288,46 @@ def ddim_time_pairs(total_timesteps: int, sampling_timesteps: int) -> List[Tuple
     return list(zip(times[:-1], times[1:]))
 
 
-def ddim_step_coefficients(alphas_cumprod: torch.Tensor, t: int, t_next: int, eta: float) -> Tuple[float, float, float]:
-    """(sqrt(alpha_next), c, sigma) as fp32 numbers, computed the way the
-    reference does on 0-dim fp32 tensors (denoising_diffusion.py:691-695)."""
-    alpha = alphas_cumprod[t]
-    alpha_next = alphas_cumprod[t_next]
-    sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
-    c = (1 - alpha_next - sigma ** 2).sqrt()
-    return float(alpha_next.sqrt()), float(c), float(sigma)
+DM_COEFS = 8  # floats per step row handed to dm_sample (include/dm_hip.h)
+
+
+def ddpm_step_table(sched: Dict[str, torch.Tensor]) -> Tuple[List[int], torch.Tensor]:
+    """Per-step scalars of p_sample_loop, computed with the reference's own fp32
+    tensor arithmetic (denoising_diffusion.py:570-574, :594-601, :643-644).
+    Row i (t = T-1-i): [sqrt_recip_ac, sqrt_recipm1_ac, coef1, coef2, exp(0.5*logvar), t>0, 0, 0]."""
+    T = int(sched["betas"].shape[0])
+    times = list(reversed(range(T)))
+    idx = torch.tensor(times)
+    c = torch.zeros(T, DM_COEFS, dtype=torch.float32)
+    c[:, 0] = sched["sqrt_recip_alphas_cumprod"][idx]
+    c[:, 1] = sched["sqrt_recipm1_alphas_cumprod"][idx]
+    c[:, 2] = sched["posterior_mean_coef1"][idx]
+    c[:, 3] = sched["posterior_mean_coef2"][idx]
+    c[:, 4] = (0.5 * sched["posterior_log_variance_clipped"][idx]).exp()
+    c[:, 5] = (idx > 0).to(torch.float32)
+    return times, c
+
+
+def ddim_step_table(sched: Dict[str, torch.Tensor], sampling_timesteps: int, eta: float) -> Tuple[List[int], torch.Tensor]:
+    """Per-step scalars of ddim_sample (denoising_diffusion.py:684-701) on 0-dim fp32 tensors.
+    Row i: [sqrt_recip_ac[t], sqrt_recipm1_ac[t], sqrt(alpha_next), c, sigma, t_next>=0, 0, 0]."""
+    T = int(sched["betas"].shape[0])
+    pairs = ddim_time_pairs(T, sampling_timesteps)
+    ac = sched["alphas_cumprod"]
+    c = torch.zeros(len(pairs), DM_COEFS, dtype=torch.float32)
+    for i, (t, tn) in enumerate(pairs):
+        c[i, 0] = sched["sqrt_recip_alphas_cumprod"][t]
+        c[i, 1] = sched["sqrt_recipm1_alphas_cumprod"][t]
+        if tn < 0:
+            continue  # flag 0: img = x_start (:686-689)
+        alpha, alpha_next = ac[t], ac[tn]
+        sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+        cc = (1 - alpha_next - sigma ** 2).sqrt()
+        c[i, 2] = alpha_next.sqrt()
+        c[i, 3] = cc
+        c[i, 4] = sigma
+        c[i, 5] = 1.0
+    return [p[0] for p in pairs], c
 
 
 # ----------------------------------------------------------------------------

@@ -1,0 +1,175 @@
+"""Host-side mirror of the reference ``Unet`` (and its text / image-conditional
+subclasses) in front of the HIP library.
+
+Same constructor arguments, ``forward`` signature, ``state_dict`` key names and
+error behaviour as
+  denoising-diffusion-pytorch/denoising_diffusion/denoising_diffusion.py:233-390
+  denoising-diffusion-pytorch/denoising_diffusion/denoising_diffusion_text_conditional.py:86-214
+  denoising-diffusion-pytorch/denoising_diffusion/denoising_diffusion_image_conditional.py:31-55
+but no torch compute: torch tensors are only the owners of device memory.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .spec import UnetConfig, unet_param_spec
+
+
+def _device_index(device) -> int:
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise RuntimeError(f"the HIP path needs a GPU device, got {d}; there is no CPU fallback")
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+class Unet:
+    """``Unet(dim, dim_mults=..., channels=...)`` -- drop-in for the reference class.
+
+    Weights are supplied with :meth:`load_state_dict` (reference key names).  The
+    object is callable: ``eps = unet(x, time)``.
+    """
+
+    def __init__(
+        self,
+        dim,
+        init_dim=None,
+        out_dim=None,
+        dim_mults=(1, 2, 4, 8),
+        channels=3,
+        self_condition=False,
+        learned_variance=False,
+        learned_sinusoidal_cond=False,
+        random_fourier_features=False,
+        learned_sinusoidal_dim=16,
+        sinusoidal_pos_emb_theta=10000,
+        dropout=0.0,
+        attn_dim_head=32,
+        attn_heads=4,
+        full_attn=None,
+        flash_attn=False,
+        text_condition=False,
+        text_emb_dim=512,
+        use_cross_attn=False,
+        cond_channels=0,
+        device="cuda:0",
+    ):
+        if learned_sinusoidal_cond or random_fourier_features:
+            # DenoisingDiffusion asserts this combination away (denoising_diffusion.py:457)
+            raise NotImplementedError("random / learned sinusoidal embeddings are not on the sampling path")
+        if not isinstance(attn_heads, int) or not isinstance(attn_dim_head, int):
+            raise NotImplementedError("per-stage attention head settings are not supported by the HIP path")
+        self.cfg = UnetConfig(
+            dim=dim, init_dim=init_dim, out_dim=out_dim, dim_mults=tuple(dim_mults), channels=channels,
+            self_condition=self_condition, learned_variance=learned_variance,
+            sinusoidal_pos_emb_theta=float(sinusoidal_pos_emb_theta), attn_dim_head=attn_dim_head,
+            attn_heads=attn_heads, full_attn=tuple(full_attn) if full_attn else None,
+            cond_channels=cond_channels, text_condition=text_condition, use_cross_attn=use_cross_attn,
+            text_emb_dim=text_emb_dim,
+        )
+        cfg = self.cfg
+        self.channels = channels
+        self.self_condition = self_condition
+        self.out_dim = cfg.out_dim_
+        self.text_condition = text_condition
+        self.use_cross_attn = use_cross_attn
+        self.random_or_learned_sinusoidal_cond = False
+        self.device = torch.device(device)
+        self._dev_index = _device_index(device)
+        self._lib = _lib.load()
+        self._handle = C.c_void_p()
+        self._loaded = False
+
+        c = _lib.UnetCfg()
+        c.dim, c.init_dim, c.out_dim = cfg.dim, cfg.init_dim or 0, cfg.out_dim_
+        c.channels, c.input_channels, c.n_stages = cfg.channels, cfg.input_channels, cfg.num_stages
+        for i, m in enumerate(cfg.dim_mults):
+            c.dim_mults[i] = m
+        for i, f in enumerate(cfg.full_attn_):
+            c.full_attn[i] = int(f)
+        c.attn_heads, c.attn_dim_head = cfg.attn_heads, cfg.attn_dim_head
+        c.text_mode = 0 if not text_condition else (2 if use_cross_attn else 1)
+        c.text_emb_dim = text_emb_dim
+        c.sinusoidal_theta = float(sinusoidal_pos_emb_theta)
+        _lib.check(self._lib.dm_unet_create(C.byref(c), self._dev_index, C.byref(self._handle)))
+
+    # -- lifecycle -------------------------------------------------------------------------
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            self._lib.dm_unet_destroy(h)
+            h.value = None
+
+    @property
+    def downsample_factor(self) -> int:
+        return self.cfg.downsample_factor
+
+    def eval(self):
+        return self
+
+    def param_spec(self):
+        return unet_param_spec(self.cfg)
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        """Accepts ``Unet.state_dict()`` of the reference (same names, OIHW / [out,in] layouts)."""
+        if self._loaded:
+            raise RuntimeError("weights were already loaded into this handle; build a new Unet")
+        spec = dict(self.param_spec())
+        unexpected = [k for k in state_dict if k not in spec]
+        missing = [k for k in spec if k not in state_dict]
+        if strict and (unexpected or missing):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        for name, shape in spec.items():
+            if name not in state_dict:
+                continue
+            t = state_dict[name].detach().to(device="cpu", dtype=torch.float32).contiguous()
+            if tuple(t.shape) != tuple(shape):
+                raise RuntimeError(f"size mismatch for {name}: {tuple(t.shape)} vs {tuple(shape)}")
+            shp = (C.c_int64 * t.dim())(*t.shape)
+            _lib.check(self._lib.dm_unet_set_param(self._handle, name.encode(), t.data_ptr(), shp, t.dim()))
+        _lib.check(self._lib.dm_unet_finalize(self._handle))
+        self._loaded = True
+        return self
+
+    # -- forward ---------------------------------------------------------------------------
+    def _ctx(self, text_emb: Optional[torch.Tensor], batch: int):
+        if text_emb is None or not self.text_condition:
+            return None, 0
+        t = text_emb
+        if t.dim() == 2:
+            t = t.unsqueeze(1)
+        if t.shape[0] != batch or t.shape[2] != self.cfg.text_emb_dim:
+            raise RuntimeError(f"text_emb shape {tuple(text_emb.shape)} does not match batch / text_emb_dim")
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        return t, t.shape[1]
+
+    def forward(self, x, time, x_self_cond=None, text_emb=None, cond=None):
+        if not self._loaded:
+            raise RuntimeError("load_state_dict() must be called before forward()")
+        f = self.downsample_factor
+        assert all(d % f == 0 for d in x.shape[-2:]), (
+            f"your input dimensions {tuple(x.shape[-2:])} need to be divisible by {f}, given the unet"
+        )
+        x = x.to(device=self.device, dtype=torch.float32)
+        if self.self_condition:
+            if x_self_cond is None:
+                x_self_cond = torch.zeros_like(x)
+            x = torch.cat((x_self_cond.to(x), x), dim=1)
+        if cond is not None:
+            x = torch.cat((x, cond.to(x)), dim=1)
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        if Cin != self.cfg.input_channels:
+            raise RuntimeError(f"expected {self.cfg.input_channels} input channels, got {Cin}")
+        t = time.to(device=self.device, dtype=torch.int64).contiguous()
+        ctx, m = self._ctx(text_emb, B)
+        out = torch.empty((B, self.out_dim, H, W), device=self.device, dtype=torch.float32)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.dm_unet_forward(self._handle, _lib.ptr(x), _lib.ptr(t), _lib.ptr(ctx), m,
+                                             _lib.ptr(out), B, H, W, stream))
+        return out
+
+    __call__ = forward

@@ -1,0 +1,174 @@
+/*
+ * dm_hip.h -- C ABI of the MI355X-native sampling path (libdm_hip.so).
+ *
+ * The reference (lbarseghyan/diffusion-models) has no FFI or plugin interface: its
+ * boundary is a Python method surface on nn.Module subclasses.  Each entry point
+ * below names the reference method it stands behind (paths relative to the
+ * reference checkout; DD = denoising-diffusion-pytorch/denoising_diffusion,
+ * LD = latent-diffusion/ldm).  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message is
+ *     available from dm_last_error() (thread-local).  Nothing throws across the ABI.
+ *   - `const float*` tensor arguments are DEVICE pointers, contiguous fp32, NCHW at
+ *     this boundary (the reference's layout), unless the name says `_host`.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - a handle is bound to one device and is not thread-safe.
+ *   - PyTorch (or any caller) owns inputs and outputs; the library owns only its
+ *     repacked weights and a workspace that grows outside graph capture.
+ */
+#ifndef DM_HIP_H
+#define DM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DM_MAX_STAGES 8
+
+/* text_mode */
+#define DM_TEXT_NONE 0
+#define DM_TEXT_CONCAT 1 /* DD/denoising_diffusion_text_conditional.py:108-115,146-152 */
+#define DM_TEXT_CROSS 2  /* DD/denoising_diffusion_text_conditional.py:120-125,173-198 */
+
+/* Constructor arguments of the reference Unet that fix shapes
+ * (DD/denoising_diffusion.py:234-252; text variant
+ * DD/denoising_diffusion_text_conditional.py:97). */
+typedef struct dm_unet_cfg {
+    int32_t dim;
+    int32_t init_dim;       /* 0 = dim */
+    int32_t out_dim;        /* 0 = channels */
+    int32_t channels;       /* image / latent channels the model predicts */
+    int32_t input_channels; /* channels init_conv sees (self-cond / image-cond widen it) */
+    int32_t n_stages;
+    int32_t dim_mults[DM_MAX_STAGES];
+    int32_t full_attn[DM_MAX_STAGES];
+    int32_t attn_heads;
+    int32_t attn_dim_head;
+    int32_t text_mode;
+    int32_t text_emb_dim;
+    float sinusoidal_theta;
+} dm_unet_cfg;
+
+typedef struct dm_unet dm_unet;
+
+const char* dm_last_error(void);
+/* ABI version of this header; bump on any signature change. */
+int dm_abi_version(void);
+
+/* ---- U-Net (replaces DD/denoising_diffusion.py:233-390 `Unet`) -------------------- */
+
+int dm_unet_create(const dm_unet_cfg* cfg, int device, dm_unet** out);
+void dm_unet_destroy(dm_unet* u);
+
+/* One call per state_dict() entry of the reference Unet (names without the
+ * `model.` prefix, e.g. "downs.0.0.block1.proj.weight"); data is a HOST pointer
+ * to contiguous fp32 in the reference's own layout (OIHW conv weights, [out,in]
+ * linear weights).  Shapes are checked against the configuration. */
+int dm_unet_set_param(dm_unet* u, const char* name, const float* data_host, const int64_t* shape, int ndim);
+/* number of parameters still missing (0 = complete) */
+int dm_unet_missing_params(dm_unet* u);
+/* repack weights into kernel layouts and upload; must follow the last set_param */
+int dm_unet_finalize(dm_unet* u);
+
+/* Unet.forward(x, time, x_self_cond=None) DD/denoising_diffusion.py:349-390 and the
+ * text variant forward(x, time, text_emb) DD/denoising_diffusion_text_conditional.py:131-214.
+ *   x      (B, input_channels, H, W)   time (B,) int64 device   ctx (B, ctx_tokens, text_emb_dim) or NULL
+ *   out    (B, out_dim, H, W)
+ * H and W must be divisible by 2^(n_stages-1) (assert at :350). */
+int dm_unet_forward(dm_unet* u, const float* x, const int64_t* time, const float* ctx, int ctx_tokens,
+                    float* out, int B, int H, int W, void* stream);
+
+/* ---- samplers (replace DenoisingDiffusion.p_sample_loop / ddim_sample,
+ *      DD/denoising_diffusion.py:647-664 and :666-708) ------------------------------------
+ *
+ * The per-step scalar coefficients are computed by the HOST exactly as the reference
+ * computes them (fp32 tensor arithmetic on the schedule buffers) and passed in:
+ *   DDPM step i (t = times[i]):   c[0]=sqrt_recip_alphas_cumprod[t]  c[1]=sqrt_recipm1_alphas_cumprod[t]
+ *                                 c[2]=posterior_mean_coef1[t]       c[3]=posterior_mean_coef2[t]
+ *                                 c[4]=exp(0.5*posterior_log_variance_clipped[t])   c[5]= (t>0) ? 1 : 0
+ *   DDIM step i (t, t_next):      c[0], c[1] as above  c[2]=sqrt(alpha_next)  c[3]=c  c[4]=sigma
+ *                                 c[5]= (t_next<0) ? 0 : 1   (0: img = x_start, :686-689)
+ * coefs_host has n_steps rows of DM_COEFS floats.
+ *
+ *   x_T        (B,C,H,W) start noise (draw #0 of the reference)
+ *   noise      NULL -> device Philox noise from `seed`; else (n_steps, B,C,H,W) injected noise,
+ *              row i used by step i (rows of steps that take no noise are ignored)
+ *   out        (B,C,H,W); (x+1)/2 applied when unnormalize != 0 (:663,:707)
+ *   all_steps  NULL, or (n_steps+1, B,C,H,W) receiving x_T and every iterate
+ *              (return_all_timesteps; the caller permutes to (B, n_steps+1, ...))
+ *   use_graph  capture one denoise step into a hipGraph and replay it n_steps times
+ */
+#define DM_COEFS 8
+#define DM_SAMPLER_DDPM 0
+#define DM_SAMPLER_DDIM 1
+
+int dm_sample(dm_unet* u, int kind, int n_steps, const int64_t* times_host, const float* coefs_host,
+              const float* x_T, const float* noise, uint64_t seed, const float* ctx, int ctx_tokens,
+              float* out, float* all_steps, int B, int H, int W, int unnormalize, int use_graph, void* stream);
+
+/* N(0,1) noise from the library's Philox4x32-10 stream (what dm_sample uses when noise == NULL);
+ * element e of the tensor of draw `draw` uses counter (e/4, draw) under key `seed`. */
+int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, void* stream);
+
+/* ---- VAE decode (replaces VQModel.decode, LD/models/autoencoder.py:113-116 ->
+ *      Decoder.forward LD/modules/diffusionmodules/model.py:552-585) ----------------------- */
+typedef struct dm_decoder_cfg {
+    int32_t ch;
+    int32_t out_ch;
+    int32_t n_levels;
+    int32_t ch_mult[DM_MAX_STAGES];
+    int32_t num_res_blocks;
+    int32_t n_attn_res;
+    int32_t attn_resolutions[DM_MAX_STAGES];
+    int32_t resolution;
+    int32_t z_channels;
+    int32_t embed_dim;
+} dm_decoder_cfg;
+
+typedef struct dm_decoder dm_decoder;
+int dm_decoder_create(const dm_decoder_cfg* cfg, int device, dm_decoder** out);
+void dm_decoder_destroy(dm_decoder* d);
+int dm_decoder_set_param(dm_decoder* d, const char* name, const float* data_host, const int64_t* shape, int ndim);
+int dm_decoder_missing_params(dm_decoder* d);
+int dm_decoder_finalize(dm_decoder* d);
+/* z (B, embed_dim, h, w) -> out (B, out_ch, h*2^(n_levels-1), w*2^(n_levels-1)) */
+int dm_decoder_forward(dm_decoder* d, const float* z, float* out, int B, int h, int w, void* stream);
+
+/* ---- single operators (the kernels behind the calls above, exposed so that parity tests
+ *      can check each one against the reference module it replaces) -------------------------
+ * All tensors NCHW fp32 device pointers; weights in the reference layout, DEVICE pointers. */
+
+/* nn.Conv2d forward (stride 1) with optional fused extras used by the U-Net:
+ *   in = cat(in0, in1) along C (in1 may be NULL);  up2: nearest x2 before the conv
+ *   (DD/denoising_diffusion.py:48-52);  residual (B,Cout,Ho,Wo) added to the result or NULL. */
+int dm_op_conv2d(const float* in0, int C0, const float* in1, int C1, const float* weight, const float* bias,
+                 const float* residual, float* out, int B, int H, int W, int Cout, int ksize, int pad, int up2,
+                 void* stream);
+/* Downsample: pixel-unshuffle(2) + conv1x1 (DD/denoising_diffusion.py:54-58); weight (Cout, 4*C, 1, 1) */
+int dm_op_downsample(const float* in, int C, const float* weight, const float* bias, float* out, int B, int H,
+                     int W, int Cout, void* stream);
+/* RMSNorm.forward (DD/denoising_diffusion.py:66-67) */
+int dm_op_rmsnorm(const float* x, const float* g, float* out, int B, int C, int H, int W, void* stream);
+/* Block.forward (DD/denoising_diffusion.py:113-122); scale/shift (B,Cout) or NULL */
+int dm_op_block(const float* x, int Cin, const float* weight, const float* bias, const float* g,
+                const float* scale, const float* shift, float* out, int B, int H, int W, int Cout, void* stream);
+/* LinearAttention.forward (DD/denoising_diffusion.py:173-193) */
+int dm_op_linear_attention(const float* x, const float* norm_g, const float* mem_kv, const float* w_qkv,
+                           const float* w_out, const float* b_out, const float* out_g, float* out, int B, int C,
+                           int H, int W, int heads, int dim_head, void* stream);
+/* Attention.forward (DD/denoising_diffusion.py:215-229, DD/attend.py:109-124) */
+int dm_op_attention(const float* x, const float* norm_g, const float* mem_kv, const float* w_qkv,
+                    const float* w_out, const float* b_out, float* out, int B, int C, int H, int W, int heads,
+                    int dim_head, void* stream);
+/* one DDPM / DDIM update on (n) elements given eps = model output; c = DM_COEFS floats (host) */
+int dm_op_sampler_update(int kind, const float* x, const float* eps, const float* noise, const float* c_host,
+                         float* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DM_HIP_H */

@@ -1,0 +1,189 @@
+"""GPU parity of the whole path (through dm_unet_forward / dm_sample / dm_decoder_forward) against
+the golden vectors generated from the reference (tests/golden/*.pt) and against the oracle.
+
+Tolerances (rel-L2, fp32): one U-Net forward <= 1e-4; whole sampling loops <= 1e-3
+(BASELINE.json north_star); measured values are printed with -s."""
+import pytest
+import torch
+
+import diffusion_models_amd as dm
+from diffusion_models_amd.spec import DecoderConfig, UnetConfig
+from oracle import sampler_oracle as so
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FWD_TOL = 1e-4
+LOOP_TOL = 1e-3
+
+
+def build_unet(salt=0, **kw):
+    u = dm.Unet(device=DEV, **kw)
+    u.load_state_dict(dm.synth_state_dict(u.param_spec(), salt=salt))
+    return u
+
+
+@pytest.fixture(scope="module")
+def small_unet():
+    return build_unet(salt=1, dim=32, dim_mults=(1, 2), channels=3)
+
+
+@pytest.fixture(scope="module")
+def full_unet():
+    return build_unet(salt=0, dim=64, dim_mults=(1, 2, 4, 8), channels=3)
+
+
+def test_unet_small_forward(golden_blocks, small_unet):
+    b = golden_blocks["unet_small"]
+    y = small_unet(b["x"], b["t"]).cpu()
+    err = rel_l2(y, b["y"])
+    print("unet_small rel-L2", err)
+    assert err < FWD_TOL
+
+
+def test_unet_rejects_bad_size(small_unet):
+    with pytest.raises(AssertionError):
+        small_unet(torch.zeros(1, 3, 15, 16), torch.zeros(1, dtype=torch.long))
+
+
+def test_unet_text_variants(golden_blocks):
+    g = golden_blocks
+    u = build_unet(salt=2, dim=32, dim_mults=(1, 2), channels=3, text_condition=True, use_cross_attn=True)
+    for key in ("unet_text_cross", "unet_text_cross_m3"):
+        b = g[key]
+        err = rel_l2(u(b["x"], b["t"], text_emb=b["ctx"]).cpu(), b["y"])
+        print(key, err)
+        assert err < FWD_TOL
+    u = build_unet(salt=3, dim=32, dim_mults=(1, 2), channels=3, text_condition=True, use_cross_attn=False)
+    b = g["unet_text_concat"]
+    err = rel_l2(u(b["x"], b["t"], text_emb=b["ctx"]).cpu(), b["y"])
+    print("unet_text_concat", err)
+    assert err < FWD_TOL
+
+
+def test_unet_full_forward(golden_samplers, full_unet):
+    for key in ("unet_full_32", "unet_full_64"):
+        b = golden_samplers[key]
+        err = rel_l2(full_unet(b["x"], b["t"]).cpu(), b["y"])
+        print(key, err)
+        assert err < FWD_TOL
+
+
+def test_unet_latent_and_text_full(golden_samplers):
+    u = build_unet(salt=0, dim=64, channels=4)
+    b = golden_samplers["unet_latent4_32"]
+    err = rel_l2(u(b["x"], b["t"]).cpu(), b["y"])
+    print("latent4", err)
+    assert err < FWD_TOL
+    del u
+    u = build_unet(salt=0, dim=64, text_condition=True, use_cross_attn=True)
+    b = golden_samplers["unet_text_full_32"]
+    err = rel_l2(u(b["x"], b["t"], text_emb=b["ctx"]).cpu(), b["y"])
+    print("text_full", err)
+    assert err < FWD_TOL
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_small_samplers(golden_samplers, small_unet, use_graph):
+    g = golden_samplers
+    d = dm.DenoisingDiffusion(small_unet, image_size=16, timesteps=1000, use_graph=use_graph)
+    b = g["small_ddim50"]
+    y = d.ddim_sample(b["shape"], sampling_timesteps=b["S"], noise=so.NoiseStream(b["seed"])).cpu()
+    print("small_ddim50", use_graph, rel_l2(y, b["y"]))
+    assert rel_l2(y, b["y"]) < LOOP_TOL
+    d.ddim_sampling_eta = 0.5
+    b = g["small_ddim20_eta"]
+    y = d.ddim_sample(b["shape"], sampling_timesteps=b["S"], noise=so.NoiseStream(b["seed"])).cpu()
+    print("small_ddim20_eta", use_graph, rel_l2(y, b["y"]))
+    assert rel_l2(y, b["y"]) < LOOP_TOL
+    d50 = dm.DenoisingDiffusion(small_unet, image_size=16, timesteps=50, use_graph=use_graph)
+    b = g["small_ddpm50_all"]
+    y = d50.p_sample_loop(b["shape"], return_all_timesteps=True, noise=so.NoiseStream(b["seed"])).cpu()
+    assert y.shape == b["y"].shape
+    print("small_ddpm50_all", use_graph, rel_l2(y, b["y"]))
+    assert rel_l2(y, b["y"]) < LOOP_TOL
+    assert rel_l2(y[:, 1], b["y"][:, 1]) < 1e-4  # first iterate: one step of drift only
+
+
+def test_small_ddpm1000(golden_samplers, small_unet):
+    b = golden_samplers["small_ddpm1000"]
+    d = dm.DenoisingDiffusion(small_unet, image_size=16, timesteps=1000)
+    y = d.sample(batch_size=2, noise=so.NoiseStream(b["seed"])).cpu()
+    print("small_ddpm1000", rel_l2(y, b["y"]))
+    assert rel_l2(y, b["y"]) < LOOP_TOL
+
+
+def test_full_samplers(golden_samplers, full_unet):
+    g = golden_samplers
+    d = dm.DenoisingDiffusion(full_unet, image_size=32, timesteps=1000, sampling_timesteps=50)
+    assert d.is_ddim_sampling
+    b = g["full_ddim50"]
+    y = d.sample(batch_size=2, noise=so.NoiseStream(b["seed"])).cpu()
+    print("full_ddim50", rel_l2(y, b["y"]))
+    assert rel_l2(y, b["y"]) < LOOP_TOL
+    d = dm.DenoisingDiffusion(full_unet, image_size=32, timesteps=1000)
+    b = g["full_ddpm1000"]
+    y = d.sample(batch_size=2, noise=so.NoiseStream(b["seed"])).cpu()
+    print("full_ddpm1000", rel_l2(y, b["y"]))
+    assert rel_l2(y, b["y"]) < LOOP_TOL
+
+
+def test_sampling_properties_at_bench_size(full_unet):
+    """Size-independent properties at the benchmark batch (B=256, 32x32, DDIM):
+    determinism under a fixed Philox seed, range of the unnormalised output, and batch-shard
+    independence (a sample does not depend on which other samples share its batch)."""
+    d = dm.DenoisingDiffusion(full_unet, image_size=32, timesteps=1000, sampling_timesteps=50)
+    a = d.ddim_sample((256, 3, 32, 32), sampling_timesteps=4, seed=7)
+    b = d.ddim_sample((256, 3, 32, 32), sampling_timesteps=4, seed=7)
+    assert torch.equal(a, b)
+    assert torch.isfinite(a).all() and a.min() >= 0.0 and a.max() <= 1.0  # last DDIM step returns clamp(x0)
+    c = d.ddim_sample((256, 3, 32, 32), sampling_timesteps=4, seed=8)
+    assert not torch.equal(a, c)
+
+    class Slice:  # injected noise: the same global rows whether sampled as 8 or as 2x4
+        def __init__(self, lo, hi):
+            self.s, self.lo, self.hi = so.NoiseStream(99), lo, hi
+
+        def __call__(self, shape):
+            return self.s((8,) + tuple(shape[1:]))[self.lo:self.hi]
+
+    whole = d.ddim_sample((8, 3, 32, 32), sampling_timesteps=6, noise=Slice(0, 8))
+    lo = d.ddim_sample((4, 3, 32, 32), sampling_timesteps=6, noise=Slice(0, 4))
+    hi = d.ddim_sample((4, 3, 32, 32), sampling_timesteps=6, noise=Slice(4, 8))
+    assert rel_l2(torch.cat((lo, hi)), whole) < 1e-5
+
+
+def test_vae_decode(golden_vae):
+    cfg = DecoderConfig()
+    vae = dm.VQDecoder(dict(ch=64, out_ch=3, ch_mult=(1, 2), num_res_blocks=2, attn_resolutions=(), resolution=32,
+                            z_channels=3), embed_dim=3, device=DEV)
+    vae.load_state_dict(dm.synth_state_dict(dm.decoder_param_spec(cfg), salt=4))
+    b = golden_vae["decode_cifar"]
+    err = rel_l2(vae.decode(b["z"]).cpu(), b["y"])
+    print("vae decode_cifar", err)
+    assert err < FWD_TOL
+    cfg2 = DecoderConfig(ch=32, ch_mult=(1, 2, 4), num_res_blocks=1, attn_resolutions=(8,), resolution=16,
+                         z_channels=4, embed_dim=4)
+    vae2 = dm.VQDecoder(dict(ch=32, out_ch=3, ch_mult=(1, 2, 4), num_res_blocks=1, attn_resolutions=(8,),
+                             resolution=16, z_channels=4), embed_dim=4, device=DEV)
+    vae2.load_state_dict(dm.synth_state_dict(dm.decoder_param_spec(cfg2), salt=5))
+    b = golden_vae["decode_attn3"]
+    err = rel_l2(vae2.decode(b["z"]).cpu(), b["y"])
+    print("vae decode_attn3", err)
+    assert err < FWD_TOL
+
+
+def test_latent_diffusion_sample_shape(golden_vae):
+    """LatentDiffusion.sample = latent loop (no (x+1)/2) + decode (latent_diffusion.py:59-66)."""
+    u = build_unet(salt=6, dim=32, dim_mults=(1, 2), channels=3)
+    cfg = DecoderConfig()
+    vae = dm.VQDecoder(dict(ch=64, out_ch=3, ch_mult=(1, 2), num_res_blocks=2, attn_resolutions=(), resolution=32,
+                            z_channels=3), embed_dim=3, device=DEV)
+    vae.load_state_dict(dm.synth_state_dict(dm.decoder_param_spec(cfg), salt=4))
+    ld = dm.LatentDiffusion(u, vae, latent_shape=(3, 16, 16), timesteps=1000, sampling_timesteps=5)
+    lat = ld.ddim_sample((2, 3, 16, 16), noise=so.NoiseStream(3))
+    img = ld.sample(batch_size=2, noise=so.NoiseStream(3))
+    assert img.shape == (2, 3, 32, 32)
+    assert lat.min() >= -1.0 and lat.max() <= 1.0  # identity unnormalize: clamp(x0) stays in [-1, 1]
+    assert rel_l2(vae.decode(lat), img) < 1e-6

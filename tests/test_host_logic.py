@@ -1,0 +1,72 @@
+"""Host-side logic of the product path on CPU: the per-step coefficient tables handed to
+dm_sample, replayed through a scalar restatement of the update kernel, must reproduce the
+oracle's samplers (which are pinned to the reference) on identical noise."""
+import torch
+
+import diffusion_models_amd as dm
+from diffusion_models_amd.spec import UnetConfig, ddim_step_table, ddpm_step_table
+from oracle import sampler_oracle as so
+from oracle import unet_oracle as uo
+
+from conftest import rel_l2
+
+SMALL = UnetConfig(dim=32, dim_mults=(1, 2), channels=3)
+
+
+def _update(kind, c, x, eps, z):
+    """What sampler_update_kernel computes (csrc/elementwise.hip), in torch fp32."""
+    c0, c1, c2, c3, c4, flag = (c[i] for i in range(6))
+    x0 = (c0 * x - c1 * eps).clamp(-1.0, 1.0)
+    if kind == 0:
+        mean = c2 * x0 + c3 * x
+        return mean + c4 * z if flag != 0 else mean + c4 * 0.0
+    e2 = (c0 * x - x0) / c1
+    return (x0 * c2 + c3 * e2) + c4 * z if flag != 0 else x0
+
+
+def _replay(kind, times, coefs, model, shape, stream):
+    x = stream(shape)
+    for i, t in enumerate(times):
+        bt = torch.full((shape[0],), t, dtype=torch.long)
+        eps = model(x, bt)
+        z = stream(shape) if coefs[i, 5] != 0 else torch.zeros(shape)
+        x = _update(kind, coefs[i], x, eps, z)
+    return (x + 1) * 0.5
+
+
+def test_tables_replay_matches_oracle_samplers():
+    sd = dm.synth_state_dict(dm.unet_param_spec(SMALL), salt=1)
+    model = lambda x, t: uo.unet_forward(sd, SMALL, x, t)  # noqa: E731
+    shape = (1, 3, 16, 16)
+    with torch.inference_mode():
+        sched = dm.make_schedule(1000, "linear")
+        for S, eta in ((10, 0.0), (7, 0.7)):
+            times, coefs = ddim_step_table(sched, S, eta)
+            got = _replay(1, times, coefs, model, shape, so.NoiseStream(5))
+            want = so.ddim_sample(model, sched, shape, so.NoiseStream(5), S, eta=eta)
+            assert rel_l2(got, want) < 1e-6
+        sched = dm.make_schedule(30, "cosine")
+        times, coefs = ddpm_step_table(sched)
+        assert times == list(range(29, -1, -1)) and coefs[-1, 5] == 0 and bool((coefs[:-1, 5] == 1).all())
+        got = _replay(0, times, coefs, model, shape, so.NoiseStream(6))
+        want = so.p_sample_loop(model, sched, shape, so.NoiseStream(6))
+        assert rel_l2(got, want) < 1e-6
+
+
+def test_ddim_table_shape_and_flags():
+    sched = dm.make_schedule(1000, "linear")
+    times, c = ddim_step_table(sched, 50, 0.0)
+    assert times[0] == 999 and times[-1] == 19 and len(times) == 50
+    assert c.shape == (50, 8) and c[-1, 5] == 0 and bool((c[:-1, 5] == 1).all())
+    assert bool((c[:, 4] == 0).all())  # eta = 0 -> sigma = 0
+
+
+def test_shard_bounds_cover_batch():
+    from diffusion_models_amd.dist import shard_bounds, shard_sizes
+
+    for B in (1, 7, 8, 64, 257):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(B, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert sum(shard_sizes(B, w)) == B and max(shard_sizes(B, w)) - min(shard_sizes(B, w)) <= 1
