@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                         v.x = src[o];
                         if (c + 1 < Cs) v.y = src[o + 1];
                         if (c + 2 < Cs) v.z = src[o + 2];
+                        if (c + 3 < Cs) v.w = src[o + 3];
                     }
                 }
             }
