@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: sampled images/sec of the 32x32 denoising U-Net on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1 via torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch: a complete ``sample()`` call
+(BASELINE.json configs[1]: 32x32 U-Net dim 64 mults (1,2,4,8), DDIM 50 steps, eta 0, batch 256
+per GPU, hipGraph-captured denoise step, device Philox noise, name-seeded random-init weights).
+With N>1 every rank samples its own 256 images (weak scaling) and ONE all-gather over RCCL
+assembles the (256*N) batch at the end of each step, inside the timed region.
+
+Rank 0 prints ONE JSON line.  `value` is whole-job images/s with all inputs resident in HBM.
+Also reported: denoise image-steps/s, the DDPM-1000 equivalent (same per-step cost, 1000 steps),
+the roofline of the dominant kernel (HIP-event timed inside this script) and the CPU baseline
+(the oracle on this box's host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_TFLOPS = 157.3  # MI355X f32 vector == f32-input MFMA peak (MI355X_MICROARCH.md)
+IMAGE, CHANNELS, T = 32, 3, 1000
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per sample() call")
+    ap.add_argument("--workload", default="ddim50", choices=["ddim50", "ddpm1000"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=4, help="denoise steps of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, cfg, batch, n_steps, sampler_steps):
+    """The oracle (CPU restatement pinned to the reference) on the host cores: `n_steps` DDIM
+    iterations at the benchmark batch, extrapolated linearly to the full loop (steps are homogeneous)."""
+    import diffusion_models_amd as dm
+    from oracle import sampler_oracle as so
+    from oracle import unet_oracle as uo
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    torch.set_num_threads(cores)
+    sched = dm.make_schedule(T, "linear")
+    pairs = so.ddim_pairs(T, 50)
+    stream = so.NoiseStream(0)
+    shape = (batch, CHANNELS, IMAGE, IMAGE)
+    with torch.inference_mode():
+        x = stream(shape)
+        bt = torch.full((batch,), pairs[0][0], dtype=torch.long)
+        uo.unet_forward(sd, cfg, x[:8], bt[:8])  # warm the thread pool / allocator
+        t0 = time.perf_counter()
+        for t, tn in pairs[:n_steps]:
+            bt = torch.full((batch,), t, dtype=torch.long)
+            eps = uo.unet_forward(sd, cfg, x, bt)
+            x0 = so.predict_start_from_noise(sched, x, t, eps).clamp(-1.0, 1.0)
+            eps = so.predict_noise_from_start(sched, x, t, x0)
+            a, an = sched["alphas_cumprod"][t], sched["alphas_cumprod"][tn]
+            x = x0 * an.sqrt() + (1 - an).sqrt() * eps
+        dt = time.perf_counter() - t0
+    img_steps_per_s = batch * n_steps / dt
+    return {
+        "value": img_steps_per_s / sampler_steps,
+        "unit": "images/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{n_steps} of {sampler_steps} denoise steps at batch {batch} ({dt:.1f} s), linear extrapolation; "
+                  f"{img_steps_per_s:.1f} image-steps/s; torch {torch.__version__} CPU ops, fp32",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import diffusion_models_amd as dm
+    from diffusion_models_amd import _lib
+    from diffusion_models_amd.spec import UnetConfig
+
+    cfg = UnetConfig(dim=64, dim_mults=(1, 2, 4, 8), channels=CHANNELS)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=0)
+    unet = dm.Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=CHANNELS, device=dev)
+    unet.load_state_dict(sd)
+    S = 50 if args.workload == "ddim50" else T
+    diff = dm.DenoisingDiffusion(unet, image_size=IMAGE, timesteps=T,
+                                 sampling_timesteps=S if S < T else None, use_graph=not args.no_graph)
+    B = args.batch
+
+    def step(i):
+        # key the Philox stream by (step, global shard) so no two ranks draw the same noise
+        local = diff.sample(batch_size=B, seed=1 + i * world + rank)
+        return dm.gather_shards(local, B * world) if world > 1 else local
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(-1 - i)
+    barrier()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(args.steps):
+        out = step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert out.shape == (B * world, CHANNELS, IMAGE, IMAGE) and bool(torch.isfinite(out).all())
+
+    images = B * world * args.steps
+    value = images / elapsed
+    result = {
+        "metric": "sampled images/sec, 32x32 U-Net (dim 64, mults 1-2-4-8), DDIM-50" if S == 50
+                  else "sampled images/sec, 32x32 U-Net (dim 64, mults 1-2-4-8), DDPM-1000",
+        "value": value,
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (name-seeded random-init weights, device Philox noise)",
+        "config": {
+            "workload": f"{args.workload}_32x32_unet64_b{B}_per_gpu",
+            "sampler_steps": S,
+            "batch_per_gpu": B,
+            "global_batch": B * world,
+            "hip_graph": not args.no_graph,
+            "parallelism": f"batch-shard x{world}, one all-gather per sample()",
+        },
+        "image_steps_per_s": value * S,
+        "ddpm1000_equiv_images_per_s": value * S / 1000.0,
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # roofline leg: the same workload, eager launches, every conv bracketed by HIP events on its stream
+        diff_e = dm.DenoisingDiffusion(unet, image_size=IMAGE, timesteps=T, sampling_timesteps=50, use_graph=False)
+        _lib.profile_enable(True)
+        diff_e.ddim_sample((B, CHANNELS, IMAGE, IMAGE), sampling_timesteps=50, seed=3, max_steps=4)
+        rows = _lib.profile_read()
+        _lib.profile_enable(False)
+        rows.sort(key=lambda r: -r["total_ms"])
+        kern = []
+        for r in rows:
+            avg_ms = r["total_ms"] / r["launches"]
+            tf = r["total_flops"] / (r["total_ms"] * 1e-3) / 1e12
+            kern.append({"kernel": r["kernel"], "launches_per_unet_fwd": r["launches"] // 4,
+                         "avg_ms": avg_ms, "tflops": tf, "frac_f32_peak": tf / PEAK_F32_TFLOPS,
+                         "algorithmic_GBps": r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e9})
+        top = kern[0]
+        result["roofline"] = {
+            "bound": "mfma",
+            "kernel": top["kernel"],
+            "achieved": top["tflops"],
+            "peak": PEAK_F32_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": top["tflops"] / PEAK_F32_TFLOPS,
+            "traffic": None,
+            "avg_launch_ms": top["avg_ms"],
+            "note": "f32-input MFMA peak == f32 vector peak; algorithmic FLOPs 2*k*k*Cin*Cout*pixels per launch",
+        }
+        result["kernels"] = kern
+        conv_ms = sum(r["total_ms"] for r in rows) / 4
+        result["conv_ms_per_unet_fwd"] = conv_ms
+        result["unet_fwd_ms_graph"] = 1e3 * elapsed / args.steps / S
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(sd, cfg, B, args.cpu_steps, S)
+        result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

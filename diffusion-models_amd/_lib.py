@@ -24,6 +24,7 @@ EXPORTS = (
     "dm_decoder_finalize", "dm_decoder_forward",
     "dm_op_conv2d", "dm_op_downsample", "dm_op_rmsnorm", "dm_op_block", "dm_op_linear_attention",
     "dm_op_attention", "dm_op_sampler_update",
+    "dm_profile_enable", "dm_profile_read",
 )
 
 
@@ -43,6 +44,11 @@ class DecoderCfg(C.Structure):
         ("num_res_blocks", C.c_int32), ("n_attn_res", C.c_int32), ("attn_resolutions", C.c_int32 * DM_MAX_STAGES),
         ("resolution", C.c_int32), ("z_channels", C.c_int32), ("embed_dim", C.c_int32),
     ]
+
+
+class ProfileRow(C.Structure):
+    _fields_ = [("kernel", C.c_char * 64), ("launches", C.c_int64), ("total_ms", C.c_double),
+                ("total_flops", C.c_double), ("total_bytes", C.c_double)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -77,6 +83,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_op_linear_attention.argtypes = [fp, fp, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, vp]
     lib.dm_op_attention.argtypes = [fp, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, vp]
     lib.dm_op_sampler_update.argtypes = [i32, fp, fp, fp, C.POINTER(C.c_float), fp, i64, vp]
+    lib.dm_profile_enable.argtypes = [i32]
+    lib.dm_profile_read.argtypes = [C.POINTER(ProfileRow), i32, C.POINTER(i32)]
 
 
 def load() -> C.CDLL:
@@ -96,6 +104,20 @@ def load() -> C.CDLL:
         raise RuntimeError(f"libdm_hip.so ABI {lib.dm_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
     _lib = lib
     return lib
+
+
+def profile_enable(on: bool) -> None:
+    check(load().dm_profile_enable(1 if on else 0))
+
+
+def profile_read():
+    """[{kernel, launches, total_ms, total_flops, total_bytes}] since the last read (synchronises)."""
+    rows = (ProfileRow * 64)()
+    n = C.c_int(0)
+    check(load().dm_profile_read(rows, 64, C.byref(n)))
+    return [dict(kernel=rows[i].kernel.decode(), launches=int(rows[i].launches), total_ms=float(rows[i].total_ms),
+                 total_flops=float(rows[i].total_flops), total_bytes=float(rows[i].total_bytes))
+            for i in range(n.value)]
 
 
 def check(rc: int) -> None:

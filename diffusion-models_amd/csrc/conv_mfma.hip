@@ -22,6 +22,7 @@
 #include "dm_common.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -390,8 +391,22 @@ static int launch_one(const ConvParams& p, hipStream_t s) {
     }
     const ConvGeom& g = p.geo;
     int blocks = g.n_tiles_n * g.tiles_x * g.tiles_y * g.groups;
+    const bool timed = prof::enabled();
+    if (timed) {
+        // algorithmic work of this launch: 2*k*k*Cin*Cout*pixels FLOP;
+        // read input once + write output once + weights once
+        const double pix = (double)p.B * p.Ho * p.Wo;
+        const double cin = p.C0 + p.C1;
+        const double in_pix = (double)p.B * (p.up ? (p.Hin / 2) * (p.Win / 2) : p.Hin * p.Win);
+        const double flops = 2.0 * p.KH * p.KW * cin * p.Cout * pix;
+        const double bytes = 4.0 * (cin * in_pix + p.Cout * pix + (double)p.KH * p.KW * cin * p.Cout);
+        char name[64];
+        snprintf(name, sizeof(name), "conv_mfma_kernel<%d,%d,%d>", WM, WN, CK);
+        if (prof::begin(name, flops, bytes, s)) return 1;
+    }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), g.lds_bytes, s, p);
     DM_CHECK_HIP(hipGetLastError());
+    if (timed && prof::end(s)) return 1;
     return 0;
 }
 

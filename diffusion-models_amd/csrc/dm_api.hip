@@ -18,6 +18,46 @@ static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 
 // ---------------------------------------------------------------------------------------
+// per-kernel event timing (bench.py roofline leg)
+// ---------------------------------------------------------------------------------------
+namespace prof {
+struct Rec {
+    std::string kernel;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+static bool g_on = false;
+static std::vector<Rec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+
+bool enabled() { return g_on; }
+
+static int get_event(hipEvent_t* e) {
+    if (!g_pool.empty()) {
+        *e = g_pool.back();
+        g_pool.pop_back();
+        return 0;
+    }
+    DM_CHECK_HIP(hipEventCreate(e));
+    return 0;
+}
+
+int begin(const char* kernel, double flops, double bytes, hipStream_t s) {
+    Rec r{kernel, flops, bytes, nullptr, nullptr};
+    if (get_event(&r.e0) || get_event(&r.e1)) return 1;
+    DM_CHECK_HIP(hipEventRecord(r.e0, s));
+    g_recs.push_back(r);
+    return 0;
+}
+
+int end(hipStream_t s) {
+    DM_REQUIRE(!g_recs.empty(), "prof::end without begin");
+    DM_CHECK_HIP(hipEventRecord(g_recs.back().e1, s));
+    return 0;
+}
+}  // namespace prof
+
+// ---------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------
 struct HostTensor {

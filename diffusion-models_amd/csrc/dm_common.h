@@ -90,6 +90,17 @@ void conv_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C
 int conv_launch(const ConvParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
+// Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
+// Off by default; never enabled while a graph is being captured.
+// ---------------------------------------------------------------------------------------
+namespace prof {
+bool enabled();
+// bracket one launch: begin() records an event on `s`, end() records the closing one
+int begin(const char* kernel, double flops, double bytes, hipStream_t s);
+int end(hipStream_t s);
+}  // namespace prof
+
+// ---------------------------------------------------------------------------------------
 // Elementwise / reduction kernels (elementwise.hip); all NHWC unless noted
 // ---------------------------------------------------------------------------------------
 int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t s);

@@ -168,6 +168,22 @@ int dm_op_attention(const float* x, const float* norm_g, const float* mem_kv, co
 int dm_op_sampler_update(int kind, const float* x, const float* eps, const float* noise, const float* c_host,
                          float* out, int64_t n, void* stream);
 
+/* ---- measurement (bench.py's roofline leg; not part of the reference surface) -------------
+ * While enabled, every convolution launch is bracketed by two HIP events recorded on the stream
+ * the kernel is launched on.  Do not combine with use_graph.  dm_profile_read synchronises the
+ * device, aggregates the recorded launches per kernel instance, and clears the records.
+ * total_flops / total_bytes are ALGORITHMIC (2*k*k*Cin*Cout*pixels; input + output + weights
+ * each moved once), see DESIGN.md. */
+typedef struct dm_profile_row {
+    char kernel[64];
+    int64_t launches;
+    double total_ms;
+    double total_flops;
+    double total_bytes;
+} dm_profile_row;
+int dm_profile_enable(int on);
+int dm_profile_read(dm_profile_row* rows, int max_rows, int* n_rows);
+
 #ifdef __cplusplus
 }
 #endif
