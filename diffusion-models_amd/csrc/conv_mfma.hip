@@ -17,12 +17,18 @@
 //                           cout (lane&31) of col-tile p.
 // LDS: the input window of the tile (NB images x IH x IW pixels x CK channels, row padded to CK+4
 // floats so that ds_read_b128 of 16 consecutive pixels is bank-conflict free) is staged ONCE per
-// channel chunk and re-used by all KH*KW taps; the weight slab of one kernel row
-// ([KW][NT][CK+4]) is staged per (chunk, ky).
+// channel chunk and re-used by all KH*KW taps.  Weights stream through two LDS buffers, one
+// "slab" = (chunk, ky, TPS taps) at a time.
+// Pipeline: the global loads of slab i+1 (and of the next chunk's input window) are issued into
+// registers BEFORE the MFMAs of slab i and written to LDS after them, so HBM/L2 latency hides under
+// the matrix work of the same wave; one barrier per slab.
+// Split-K: blockIdx.y owns a contiguous range of channel chunks and writes raw partial sums; the
+// epilogue then runs in norm_act_kernel (elementwise.hip), which sums the partials.
 #include "dm_common.h"
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -40,27 +46,58 @@ static inline int ilog2(int v) {
     while ((1 << l) < v) ++l;
     return l;
 }
-
-int conv_nt_for(int Cout, bool) {
-    if (Cout <= 64) return 64;
-    if (Cout <= 128) return 128;
-    if (Cout % 256 == 0) return 256;
-    if (Cout % 128 == 0) return 128;
-    return 256;
+static inline int ckp_for(int CK) { return CK == 4 ? 4 : CK + 4; }
+static inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+static inline int env_int(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
 }
 
 int conv_ck_for(int C0, int C1) { return (C0 % 16 == 0 && C1 % 16 == 0) ? 16 : 4; }
 
-static inline int ckp_for(int CK) { return CK == 4 ? 4 : CK + 4; }
-static inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+// halo / weight staging registers (float4 per thread) per instantiation
+static constexpr int hregs_for(int WM) { return WM == 4 ? 9 : (WM == 2 ? 5 : 3); }
+static constexpr int wregs_for(int WN, int CK) { return CK == 16 ? 3 * WN : 2 * WN; }
 
-ConvGeom conv_plan(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, int Cin_total, bool want_norm) {
-    ConvGeom g{};
-    (void)Cin_total;
-    int NT = conv_nt_for(Cout, want_norm);
-    g.WN = NT / 64;
-    g.WM = 4 / g.WN;
-    int MT = 64 * g.WM;
+// ---- packing: OIHW -> [chunk][ky][kx][CoutP][CK], CoutP = Cout padded to 64, zero filled ----------
+size_t conv_packed_floats(int Cout, int C0, int C1, int KH, int KW) {
+    int CK = conv_ck_for(C0, C1);
+    int chunks = pad_to(C0, CK) / CK + (C1 ? pad_to(C1, CK) / CK : 0);
+    return (size_t)chunks * KH * KW * pad_to(Cout, 64) * CK;
+}
+
+void conv_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1, int KH, int KW) {
+    int CK = conv_ck_for(C0, C1);
+    int chunks0 = pad_to(C0, CK) / CK;
+    int chunks1 = C1 ? pad_to(C1, CK) / CK : 0;
+    int chunks = chunks0 + chunks1;
+    int Cin = C0 + C1;
+    int CoutP = pad_to(Cout, 64);
+    std::memset(packed, 0, conv_packed_floats(Cout, C0, C1, KH, KW) * sizeof(float));
+    for (int ch = 0; ch < chunks; ++ch)
+        for (int ky = 0; ky < KH; ++ky)
+            for (int kx = 0; kx < KW; ++kx) {
+                float* dst = packed + (((size_t)ch * KH + ky) * KW + kx) * CoutP * CK;
+                for (int co = 0; co < Cout; ++co)
+                    for (int kk = 0; kk < CK; ++kk) {
+                        int cin;
+                        if (ch < chunks0) {
+                            int c = ch * CK + kk;
+                            if (c >= C0) continue;
+                            cin = c;
+                        } else {
+                            int c = (ch - chunks0) * CK + kk;
+                            if (c >= C1) continue;
+                            cin = C0 + c;
+                        }
+                        dst[(size_t)co * CK + kk] = oihw[(((size_t)co * Cin + cin) * KH + ky) * KW + kx];
+                    }
+            }
+}
+
+// ---- tiling policy ----------------------------------------------------------------------------------
+static void fill_tile(ConvGeom& g, int B, int Ho, int Wo, int Cout, int KH, int KW, int stride) {
+    const int MT = 64 * g.WM, NT = 64 * g.WN;
     g.TW = std::min(std::min(pow2ceil(Wo), 32), MT);
     g.TH = std::min(pow2ceil(Ho), MT / g.TW);
     g.NB = MT / (g.TW * g.TH);
@@ -72,50 +109,77 @@ ConvGeom conv_plan(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, 
     g.n_tiles_n = (Cout + NT - 1) / NT;
     g.IH = (g.TH - 1) * stride + KH;
     g.IW = (g.TW - 1) * stride + KW;
+}
+static int wgs_of(const ConvGeom& g) { return g.tiles_x * g.tiles_y * g.groups * g.n_tiles_n; }
+
+ConvGeom conv_plan(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, int C0, int C1, bool want_norm,
+                   bool allow_split) {
+    static const int target_wgs = env_int("DM_CONV_TARGET_WGS", 512);
+    static const int min_fused_wgs = env_int("DM_CONV_MIN_FUSED_WGS", 512);
+    static const int force_tps = env_int("DM_CONV_TPS", 0);
+    static const int max_splits = env_int("DM_CONV_MAX_SPLITS", 8);
+    ConvGeom g{};
+    g.CK = conv_ck_for(C0, C1);
+    const int CKP = ckp_for(g.CK);
+    const int n_chunks = pad_to(C0, g.CK) / g.CK + (C1 ? pad_to(C1, g.CK) / g.CK : 0);
+    const double M = (double)B * Ho * Wo;
+    const double K = (double)KH * KW * (C0 + C1);
+    bool chosen = false;
+    g.fused_norm = 0;
+    if (want_norm && Cout <= 256) {
+        g.WN = Cout <= 64 ? 1 : (Cout <= 128 ? 2 : 4);
+        g.WM = 4 / g.WN;
+        fill_tile(g, B, Ho, Wo, Cout, KH, KW, stride);
+        if (wgs_of(g) >= min_fused_wgs) {
+            chosen = true;
+            g.fused_norm = 1;
+        }
+    }
+    if (!chosen) {
+        // rough cost: padded MFMA work + L2 traffic (activations re-read per N tile, weights per M tile)
+        double best = 1e300;
+        int best_wn = 1;
+        for (int wn = 1; wn <= 4; wn *= 2) {
+            if (wn > 1 && Cout <= 64 * (wn / 2)) break;
+            ConvGeom t = g;
+            t.WN = wn;
+            t.WM = 4 / wn;
+            fill_tile(t, B, Ho, Wo, Cout, KH, KW, stride);
+            double m_tiles = (double)t.tiles_x * t.tiles_y * t.groups;
+            double flops = 2.0 * m_tiles * (64 * t.WM) * t.n_tiles_n * (64 * wn) * K;
+            double bytes = 4.0 * (M * stride * stride * (C0 + C1) * t.n_tiles_n + K * Cout * m_tiles);
+            double cost = flops / 100e12 + bytes / 4e12;
+            if (cost < best) {
+                best = cost;
+                best_wn = wn;
+            }
+        }
+        g.WN = best_wn;
+        g.WM = 4 / best_wn;
+        fill_tile(g, B, Ho, Wo, Cout, KH, KW, stride);
+    }
+    // taps per weight slab: a whole kernel row when two buffers + the window leave room for 2 WGs/CU
+    const int NT = 64 * g.WN;
+    g.halo_floats = pad_to(g.NB * g.IH * g.IW * CKP, 4);
+    g.TPS = KW;
+    if (g.WN > 1 && (g.halo_floats + 2 * KW * NT * CKP) * 4 > 80 * 1024) g.TPS = 1;
+    if (KW * NT * (g.CK / 4) > 256 * wregs_for(g.WN, g.CK)) g.TPS = 1;
+    if (force_tps == 1) g.TPS = 1;
+    if (force_tps == 3) g.TPS = KW;
+    g.w_floats = g.TPS * NT * CKP;
+    // split-K over channel chunks when the grid would leave CUs idle
+    g.splits = 1;
+    if (!g.fused_norm && allow_split) {
+        int wgs = wgs_of(g);
+        if (wgs < target_wgs && n_chunks >= 4) {
+            int s = (target_wgs + wgs - 1) / wgs;
+            s = std::min(s, std::min(max_splits, n_chunks / 2));
+            g.splits = std::max(1, s);
+        }
+    }
+    g.chunks_per_split = (n_chunks + g.splits - 1) / g.splits;
+    g.splits = (n_chunks + g.chunks_per_split - 1) / g.chunks_per_split;
     return g;
-}
-
-size_t conv_packed_floats(int Cout, int C0, int C1, int KH, int KW, bool want_norm) {
-    int NT = conv_nt_for(Cout, want_norm);
-    int CK = conv_ck_for(C0, C1);
-    int n_tiles = (Cout + NT - 1) / NT;
-    int chunks = pad_to(C0, CK) / CK + (C1 ? pad_to(C1, CK) / CK : 0);
-    return (size_t)n_tiles * chunks * KH * KW * NT * CK;
-}
-
-void conv_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1, int KH, int KW, bool want_norm) {
-    int NT = conv_nt_for(Cout, want_norm);
-    int CK = conv_ck_for(C0, C1);
-    int n_tiles = (Cout + NT - 1) / NT;
-    int chunks0 = pad_to(C0, CK) / CK;
-    int chunks1 = C1 ? pad_to(C1, CK) / CK : 0;
-    int chunks = chunks0 + chunks1;
-    int Cin = C0 + C1;
-    size_t total = (size_t)n_tiles * chunks * KH * KW * NT * CK;
-    std::memset(packed, 0, total * sizeof(float));
-    for (int nt = 0; nt < n_tiles; ++nt)
-        for (int ch = 0; ch < chunks; ++ch)
-            for (int ky = 0; ky < KH; ++ky)
-                for (int kx = 0; kx < KW; ++kx) {
-                    float* dst = packed + ((((size_t)nt * chunks + ch) * KH + ky) * KW + kx) * NT * CK;
-                    for (int j = 0; j < NT; ++j) {
-                        int co = nt * NT + j;
-                        if (co >= Cout) continue;
-                        for (int kk = 0; kk < CK; ++kk) {
-                            int cin;
-                            if (ch < chunks0) {
-                                int c = ch * CK + kk;
-                                if (c >= C0) continue;
-                                cin = c;
-                            } else {
-                                int c = (ch - chunks0) * CK + kk;
-                                if (c >= C1) continue;
-                                cin = C0 + c;
-                            }
-                            dst[j * CK + kk] = oihw[(((size_t)co * Cin + cin) * KH + ky) * KW + kx];
-                        }
-                    }
-                }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -153,16 +217,71 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     return v;
 }
 
+// source pixel (b*Hs + sy)*Ws + sx behind window pixel hp of this tile, or -1 (padding / outside the batch).
+// Chunk independent, so a thread computes it once per kernel for the window items it stages.
+__device__ __forceinline__ int window_pixel(const ConvParams& p, int hp, int b0, int iy0, int ix0) {
+    const ConvGeom& g = p.geo;
+    const int img_pix = g.IH * g.IW;
+    int nb = hp / img_pix;
+    int rem = hp - nb * img_pix;
+    int hy = rem / g.IW;
+    int hx = rem - hy * g.IW;
+    int b = b0 + nb;
+    int iy = iy0 + hy, ix = ix0 + hx;
+    if (b >= p.B || iy < 0 || iy >= p.Hin || ix < 0 || ix >= p.Win) return -1;
+    const int Hs = p.up ? (p.Hin >> 1) : p.Hin;
+    const int Ws = p.up ? (p.Win >> 1) : p.Win;
+    int sy = p.up ? (iy >> 1) : iy;
+    int sx = p.up ? (ix >> 1) : ix;
+    return (b * Hs + sy) * Ws + sx;
+}
+
+// one float4 of the input window: source pixel `pix`, channel quad q of chunk `chunk`
+template <int CK>
+__device__ __forceinline__ float4 load_window_px(const ConvParams& p, int pix, int q, int chunk) {
+    const bool src1 = chunk >= p.chunks0;
+    const float* __restrict__ src = src1 ? p.in1 : p.in0;
+    const int Cs = src1 ? p.C1 : p.C0;
+    const int c = (src1 ? chunk - p.chunks0 : chunk) * CK + 4 * q;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pix >= 0 && c < Cs) {
+        if (p.in_nchw) {
+            const int HWs = (p.up ? (p.Hin >> 1) * (p.Win >> 1) : p.Hin * p.Win);
+            const int b = pix / HWs;
+            const int sp = pix - b * HWs;
+            size_t o = ((size_t)b * Cs + c) * HWs + sp;
+            v.x = src[o];
+            if (c + 1 < Cs) v.y = src[o + HWs];
+            if (c + 2 < Cs) v.z = src[o + 2 * (size_t)HWs];
+            if (c + 3 < Cs) v.w = src[o + 3 * (size_t)HWs];
+        } else {
+            size_t o = (size_t)pix * Cs + c;
+            if ((Cs & 3) == 0) {
+                v = *reinterpret_cast<const float4*>(src + o);
+            } else {
+                v.x = src[o];
+                if (c + 1 < Cs) v.y = src[o + 1];
+                if (c + 2 < Cs) v.z = src[o + 2];
+                if (c + 3 < Cs) v.w = src[o + 3];
+            }
+        }
+    }
+    return v;
+}
+
 template <int WM, int WN, int CK>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     constexpr int NT = WN * 64;
     constexpr int CKP = (CK == 4) ? 4 : CK + 4;
     constexpr int HALF = CK / 2;
     constexpr int QPP = CK / 4;  // float4 items per pixel / weight row
+    constexpr int HREGS = hregs_for(WM);
+    constexpr int WREGS = wregs_for(WN, CK);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ConvGeom& g = p.geo;
     float* halo = smem;
-    float* wl = smem + g.halo_floats;
+    float* wbuf0 = smem + g.halo_floats;
+    float* wbuf1 = wbuf0 + g.w_floats;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -172,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int l31 = lane & 31;
     const int lh = lane >> 5;
 
-    // block -> (n_tile, tile_x, tile_y, group)
+    // block -> (n_tile, tile_x, tile_y, group); blockIdx.y = K split
     int bid = blockIdx.x;
     const int n_tile = bid % g.n_tiles_n;
     bid /= g.n_tiles_n;
@@ -182,6 +301,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int group = bid / g.tiles_y;
     const int x0 = tile_x * g.TW, y0 = tile_y * g.TH, b0 = group * g.NB;
     const int ix0 = x0 * p.stride - p.pad, iy0 = y0 * p.stride - p.pad;
+    const int split = blockIdx.y;
+    const int cb = split * g.chunks_per_split;
+    const int ce = min(cb + g.chunks_per_split, p.n_chunks);
 
     // per-lane LDS read bases (floats)
     int a_base[2], b_base[2];
@@ -205,82 +327,138 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
             for (int e = 0; e < 16; ++e) acc[r][q][e] = 0.f;
 
     const int halo_items = g.NB * g.IH * g.IW * QPP;
-    const int w_items = p.KW * NT * QPP;
-    const int Hs = p.up ? (p.Hin >> 1) : p.Hin;
-    const int Ws = p.up ? (p.Win >> 1) : p.Win;
-    const int img_pix = g.IH * g.IW;
+    const bool halo_in_regs = halo_items <= 256 * HREGS;
+    const int TPS = g.TPS;
+    const int w_items = TPS * NT * QPP;
+    const int kxg = p.KW / TPS;           // tap groups per kernel row
+    const int spc = p.KH * kxg;           // slabs per chunk
+    const int n_slabs = (ce - cb) * spc;
+    const int CoutP = (p.Cout + 63) & ~63;
+    const float* __restrict__ wtile = p.w + (size_t)n_tile * NT * CK;
 
-    for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
-        const bool src1 = chunk >= p.chunks0;
-        const float* __restrict__ src = src1 ? p.in1 : p.in0;
-        const int Cs = src1 ? p.C1 : p.C0;
-        const int cbase = (src1 ? chunk - p.chunks0 : chunk) * CK;
-        __syncthreads();  // previous chunk's readers are done with halo and wl
-        // ---- stage the input window of this channel chunk ----
+    float4 wreg[WREGS];
+    float4 hreg[HREGS];
+
+    auto load_w = [&](int slab) {
+        const int chunk = cb + slab / spc;
+        const int rem = slab % spc;
+        const int ky = rem / kxg;
+        const int kx0 = (rem - ky * kxg) * TPS;
+        const float* __restrict__ src =
+            wtile + ((((size_t)chunk * p.KH + ky) * p.KW + kx0) * (size_t)CoutP) * CK;
+#pragma unroll
+        for (int i = 0; i < WREGS; ++i) {
+            int it = tid + 256 * i;
+            if (it < w_items) {
+                int t = it / (NT * QPP);
+                int rq = it - t * (NT * QPP);
+                // rows past CoutP (last N tile of a Cout that is not a multiple of NT) are zero
+                wreg[i] = (n_tile * NT + rq / QPP < CoutP)
+                              ? *reinterpret_cast<const float4*>(src + (size_t)t * CoutP * CK + rq * 4)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_w = [&](float* wb) {
+#pragma unroll
+        for (int i = 0; i < WREGS; ++i) {
+            int it = tid + 256 * i;
+            if (it < w_items) {
+                int row = it / QPP;  // t*NT + cout row
+                int q = it - row * QPP;
+                *reinterpret_cast<float4*>(wb + row * CKP + 4 * q) = wreg[i];
+            }
+        }
+    };
+    int hpix[HREGS];  // source pixel of each window item this thread stages (chunk independent)
+    if (halo_in_regs) {
+#pragma unroll
+        for (int i = 0; i < HREGS; ++i) {
+            int it = tid + 256 * i;
+            hpix[i] = it < halo_items ? window_pixel(p, it / QPP, b0, iy0, ix0) : -1;
+        }
+    }
+    // global pixel index of every output row of the tile (or -1), shared by all waves in the epilogue
+    int* ptab = reinterpret_cast<int*>(wbuf1 + g.w_floats);
+    if (tid < WM * 64) {
+        int tx = tid & (g.TW - 1);
+        int ty = (tid >> g.lTW) & (g.TH - 1);
+        int nb = tid >> (g.lTW + g.lTH);
+        int b = b0 + nb, y = y0 + ty, x = x0 + tx;
+        ptab[tid] = (b < p.B && y < p.Ho && x < p.Wo) ? (b * p.Ho + y) * p.Wo + x : -1;
+    }
+    auto load_h = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < HREGS; ++i) {
+            int it = tid + 256 * i;
+            if (it < halo_items) hreg[i] = load_window_px<CK>(p, hpix[i], it & (QPP - 1), chunk);
+        }
+    };
+    auto store_h = [&]() {
+#pragma unroll
+        for (int i = 0; i < HREGS; ++i) {
+            int it = tid + 256 * i;
+            if (it < halo_items) {
+                int hp = it / QPP;
+                int q = it - hp * QPP;
+                *reinterpret_cast<float4*>(halo + hp * CKP + 4 * q) = hreg[i];
+            }
+        }
+    };
+    auto stage_h_direct = [&](int chunk) {
         for (int it = tid; it < halo_items; it += 256) {
             int hp = it / QPP;
             int q = it - hp * QPP;
-            int nb = hp / img_pix;
-            int rem = hp - nb * img_pix;
-            int hy = rem / g.IW;
-            int hx = rem - hy * g.IW;
-            int b = b0 + nb;
-            int iy = iy0 + hy, ix = ix0 + hx;
-            int c = cbase + 4 * q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win && c < Cs) {
-                int sy = p.up ? (iy >> 1) : iy;
-                int sx = p.up ? (ix >> 1) : ix;
-                if (p.in_nchw) {
-                    size_t o = (((size_t)b * Cs + c) * Hs + sy) * Ws + sx;
-                    size_t cs = (size_t)Hs * Ws;
-                    v.x = src[o];
-                    if (c + 1 < Cs) v.y = src[o + cs];
-                    if (c + 2 < Cs) v.z = src[o + 2 * cs];
-                    if (c + 3 < Cs) v.w = src[o + 3 * cs];
-                } else {
-                    size_t o = (((size_t)b * Hs + sy) * Ws + sx) * Cs + c;
-                    if ((Cs & 3) == 0) {
-                        v = *reinterpret_cast<const float4*>(src + o);
-                    } else {
-                        v.x = src[o];
-                        if (c + 1 < Cs) v.y = src[o + 1];
-                        if (c + 2 < Cs) v.z = src[o + 2];
-                        if (c + 3 < Cs) v.w = src[o + 3];
-                    }
-                }
-            }
+            float4 v = load_window_px<CK>(p, window_pixel(p, hp, b0, iy0, ix0), q, chunk);
             *reinterpret_cast<float4*>(halo + hp * CKP + 4 * q) = v;
         }
-        for (int ky = 0; ky < p.KH; ++ky) {
-            if (ky > 0) __syncthreads();  // readers of the previous weight slab are done
-            // ---- stage the weight slab (chunk, ky): KW x NT rows of CK floats, contiguous in HBM ----
-            const float* __restrict__ wsrc =
-                p.w + ((((size_t)n_tile * p.n_chunks + chunk) * p.KH + ky) * p.KW) * (size_t)(NT * CK);
-            for (int it = tid; it < w_items; it += 256) {
-                int row = it / QPP;
-                int q = it - row * QPP;
-                float4 v = *reinterpret_cast<const float4*>(wsrc + (size_t)it * 4);
-                *reinterpret_cast<float4*>(wl + row * CKP + 4 * q) = v;
-            }
+    };
+
+    // ---- prologue: slab 0 ----
+    load_w(0);
+    if (halo_in_regs) {
+        load_h(cb);
+        store_h();
+    } else {
+        stage_h_direct(cb);
+    }
+    store_w(wbuf0);
+    __syncthreads();
+
+    for (int slab = 0; slab < n_slabs; ++slab) {
+        const int next = slab + 1;
+        const bool has_next = next < n_slabs;
+        const bool chunk_ends = has_next && (next % spc == 0);
+        const int next_chunk = cb + next / spc;
+        if (has_next) load_w(next);
+        if (chunk_ends && halo_in_regs) load_h(next_chunk);
+
+        const int rem = slab % spc;
+        const int ky = rem / kxg;
+        const int kx0 = (rem - ky * kxg) * TPS;
+        const float* wb = (slab & 1) ? wbuf1 : wbuf0;
+        for (int t = 0; t < TPS; ++t) {
+            const int a_off = (ky * g.IW + kx0 + t) * CKP;
+            const int b_off = t * NT * CKP;
+            Frag<CK> fa[2], fb[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) lds_read_frag<CK>(halo + a_base[r] + a_off, fa[r]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) lds_read_frag<CK>(wb + b_base[q] + b_off, fb[q]);
+#pragma unroll
+            for (int s = 0; s < HALF; ++s)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        acc[r][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[r].v[s], fb[q].v[s], acc[r][q], 0, 0, 0);
+        }
+        if (has_next) store_w((next & 1) ? wbuf1 : wbuf0);
+        __syncthreads();  // slab done everywhere: its weight buffer and (at a chunk end) the window are free
+        if (chunk_ends) {
+            if (halo_in_regs) store_h();
+            else stage_h_direct(next_chunk);
             __syncthreads();
-            // ---- MFMA over the KW taps of this kernel row ----
-            for (int kx = 0; kx < p.KW; ++kx) {
-                const int a_off = (ky * g.IW + kx) * CKP;
-                const int b_off = kx * NT * CKP;
-                Frag<CK> fa[2], fb[2];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) lds_read_frag<CK>(halo + a_base[r] + a_off, fa[r]);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) lds_read_frag<CK>(wl + b_base[q] + b_off, fb[q]);
-#pragma unroll
-                for (int s = 0; s < HALF; ++s)
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q)
-                            acc[r][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[r].v[s], fb[q].v[s], acc[r][q], 0, 0, 0);
-            }
         }
     }
 
@@ -288,13 +466,34 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int epi = p.epi;
     int co[2];
     bool cok[2];
-    float bias[2] = {0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         co[q] = n_tile * NT + wn * 64 + q * 32 + l31;
         cok[q] = co[q] < p.Cout;
-        if ((epi & EPI_BIAS) && cok[q]) bias[q] = p.bias[co[q]];
     }
+
+    if (p.partial) {
+        // raw partial sums of this K split: out[split][pixel][cout]
+        const size_t M = (size_t)p.B * p.Ho * p.Wo;
+        float* po = p.out + (size_t)split * M * p.Cout;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int pixi = ptab[wm * 64 + r * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh];
+                if (pixi < 0) continue;
+                const size_t pix = (size_t)pixi;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    if (cok[q]) po[pix * p.Cout + co[q]] = acc[r][q][e];
+            }
+        return;
+    }
+
+    float bias[2] = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if ((epi & EPI_BIAS) && cok[q]) bias[q] = p.bias[co[q]];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -313,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                 ss[r][e] = half_wave_sum(v);
             }
         if constexpr (WN > 1) {
-            __syncthreads();  // all waves finished reading halo/wl; reuse smem as [WN][MT] scratch
+            // the loop ended with a barrier, so LDS is free: reuse it as [WN][MT] scratch
             float* red = smem;
             constexpr int MT = WM * 64;
             if (l31 == 0) {
@@ -351,31 +550,46 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
             }
     }
 
+    // scale/shift are per (image, cout): one pair per lane when the tile holds one image or t is shared
+    const bool ss_uniform = (epi & EPI_SCALE_SHIFT) && (g.NB == 1 || p.ss_stride == 0);
+    float sc1[2] = {1.f, 1.f}, sh[2] = {0.f, 0.f};
+    if (ss_uniform) {
+        const float* sp = p.scale + (size_t)min(b0, p.B - 1) * p.ss_stride;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (cok[q]) {
+                sc1[q] = sp[co[q]] + 1.0f;
+                sh[q] = sp[p.Cout + co[q]];
+            }
+    }
+    const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            int m = wm * 64 + r * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            int tx = m & (g.TW - 1);
-            int ty = (m >> g.lTW) & (g.TH - 1);
-            int nb = m >> (g.lTW + g.lTH);
-            int b = b0 + nb, y = y0 + ty, x = x0 + tx;
-            if (b >= p.B || y >= p.Ho || x >= p.Wo) continue;
-            size_t pix = ((size_t)b * p.Ho + y) * p.Wo + x;
+            const int pixi = ptab[wm * 64 + r * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh];
+            if (pixi < 0) continue;
+            const size_t pix = (size_t)pixi;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 if (!cok[q]) continue;
                 float v = acc[r][q][e];
                 if (epi & EPI_SCALE_SHIFT) {
-                    const float* sp = p.scale + (size_t)b * p.ss_stride;
-                    v = v * (sp[co[q]] + 1.0f) + sp[p.Cout + co[q]];
+                    if (ss_uniform) {
+                        v = v * sc1[q] + sh[q];
+                    } else {
+                        const float* sp = p.scale + (size_t)(pixi / HoWo) * p.ss_stride;
+                        v = v * (sp[co[q]] + 1.0f) + sp[p.Cout + co[q]];
+                    }
                 }
                 if (epi & EPI_SILU) v = v / (1.0f + __expf(-v));
                 if (epi & EPI_RESIDUAL) v += p.residual[pix * p.Cout + co[q]];
-                if (p.out_nchw)
-                    p.out[(((size_t)b * p.Cout + co[q]) * p.Ho + y) * p.Wo + x] = v;
-                else
+                if (p.out_nchw) {
+                    const int b = pixi / HoWo;
+                    p.out[((size_t)b * p.Cout + co[q]) * HoWo + (pixi - b * HoWo)] = v;
+                } else {
                     p.out[pix * p.Cout + co[q]] = v;
+                }
             }
         }
 }
@@ -390,6 +604,7 @@ static int launch_one(const ConvParams& p, hipStream_t s) {
         attr_set = true;
     }
     const ConvGeom& g = p.geo;
+    DM_REQUIRE(g.TPS * (WN * 64) * (CK / 4) <= 256 * wregs_for(WN, CK), "conv: weight slab exceeds staging registers");
     int blocks = g.n_tiles_n * g.tiles_x * g.tiles_y * g.groups;
     const bool timed = prof::enabled();
     if (timed) {
@@ -401,10 +616,14 @@ static int launch_one(const ConvParams& p, hipStream_t s) {
         const double flops = 2.0 * p.KH * p.KW * cin * p.Cout * pix;
         const double bytes = 4.0 * (cin * in_pix + p.Cout * pix + (double)p.KH * p.KW * cin * p.Cout);
         char name[64];
-        snprintf(name, sizeof(name), "conv_mfma_kernel<%d,%d,%d>", WM, WN, CK);
+        if (prof::detail())
+            snprintf(name, sizeof(name), "conv<%d,%d,%d> %dx%d s%d %d+%d->%d @%dx%d%s e%d k%d t%d", WM, WN, CK, p.KH,
+                     p.KW, p.stride, p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.up ? " up" : "", p.epi, g.splits, g.TPS);
+        else
+            snprintf(name, sizeof(name), "conv_mfma_kernel<%d,%d,%d>", WM, WN, CK);
         if (prof::begin(name, flops, bytes, s)) return 1;
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), g.lds_bytes, s, p);
+    hipLaunchKernelGGL(kern, dim3(blocks, g.splits), dim3(256), g.lds_bytes, s, p);
     DM_CHECK_HIP(hipGetLastError());
     if (timed && prof::end(s)) return 1;
     return 0;
@@ -414,18 +633,17 @@ int conv_launch(const ConvParams& pin, hipStream_t s) {
     ConvParams p = pin;
     ConvGeom& g = p.geo;
     const int CK = g.CK;
-    const int CKP = ckp_for(CK);
-    const int NT = g.WN * 64;
     DM_REQUIRE(g.WM * g.WN == 4, "conv: bad wave grid");
     DM_REQUIRE(CK == 16 || CK == 4, "conv: bad CK");
-    DM_REQUIRE(!(p.epi & EPI_NORM) || g.n_tiles_n == 1, "conv: fused RMSNorm needs one N tile");
+    DM_REQUIRE(!(p.epi & EPI_NORM) || (g.n_tiles_n == 1 && g.splits == 1), "conv: fused RMSNorm needs one N tile");
+    DM_REQUIRE(g.splits == 1 || p.partial, "conv: split-K writes partial sums");
+    DM_REQUIRE(!p.partial || !p.out_nchw, "conv: partial sums are NHWC");
     DM_REQUIRE(!p.in_nchw || p.C1 == 0, "conv: NCHW input supports one source");
     DM_REQUIRE(!p.up || ((p.Hin % 2 == 0) && (p.Win % 2 == 0)), "conv: upsampled input must be even");
+    DM_REQUIRE(p.KW % g.TPS == 0, "conv: taps per slab must divide KW");
     if (CK == 16) DM_REQUIRE(p.C0 % 4 == 0 && p.C1 % 4 == 0, "conv: CK16 needs C % 4 == 0");
-    g.halo_floats = pad_to(g.NB * g.IH * g.IW * CKP, 4);
-    int w_floats = p.KW * NT * CKP;
     int red_floats = (p.epi & EPI_NORM) && g.WN > 1 ? g.WN * g.WM * 64 : 0;
-    g.lds_bytes = std::max(g.halo_floats + w_floats, red_floats) * 4;
+    g.lds_bytes = std::max(g.halo_floats + 2 * g.w_floats + 64 * g.WM /* ptab */, red_floats) * 4;
     DM_REQUIRE(g.lds_bytes <= 160 * 1024, "conv: tile does not fit LDS");
     if (CK == 16) {
         if (g.WN == 1) return launch_one<4, 1, 16>(p, s);

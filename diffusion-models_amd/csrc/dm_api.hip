@@ -27,10 +27,12 @@ struct Rec {
     hipEvent_t e0, e1;
 };
 static bool g_on = false;
+static bool g_detail = false;
 static std::vector<Rec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 
 bool enabled() { return g_on; }
+bool detail() { return g_detail; }
 
 static int get_event(hipEvent_t* e) {
     if (!g_pool.empty()) {
@@ -224,8 +226,8 @@ static std::string idx(const std::string& a, int i) { return a + "." + std::to_s
 static int make_conv(DeviceOwner& own, ConvLayer& L, const float* oihw, const float* bias, int Cout, int C0, int C1, int KH,
                      int KW, int stride, int pad, bool up) {
     L.C0 = C0; L.C1 = C1; L.Cout = Cout; L.KH = KH; L.KW = KW; L.stride = stride; L.pad = pad; L.up = up;
-    std::vector<float> packed(conv_packed_floats(Cout, C0, C1, KH, KW, false));
-    conv_pack_weights(oihw, packed.data(), Cout, C0, C1, KH, KW, false);
+    std::vector<float> packed(conv_packed_floats(Cout, C0, C1, KH, KW));
+    conv_pack_weights(oihw, packed.data(), Cout, C0, C1, KH, KW);
     if (own.upload(packed.data(), packed.size(), &L.w)) return 1;
     L.bias = nullptr;
     if (bias && own.upload(bias, Cout, &L.bias)) return 1;
@@ -305,10 +307,12 @@ struct Ctx {
 static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* in1, int Hin, int Win, float* out,
                     int epi, const float* g, const float* scale, const float* residual, bool in_nchw = false,
                     bool out_nchw = false) {
-    if (c.dry()) return 0;
+    // One convolution with its epilogue (epi = EPI_* requested by the caller; bias is implied by the layer).
+    // The plan decides whether the epilogue runs inside the conv kernel (one workgroup owns all couts of a
+    // pixel and K is not split) or in norm_act_kernel on the raw / K-split partial sums.
     ConvParams p{};
     p.in0 = in0; p.in1 = in1; p.C0 = L.C0; p.C1 = L.C1;
-    int CK = conv_ck_for(L.C0, L.C1);
+    const int CK = conv_ck_for(L.C0, L.C1);
     p.chunks0 = (L.C0 + CK - 1) / CK;
     p.n_chunks = p.chunks0 + (L.C1 ? (L.C1 + CK - 1) / CK : 0);
     p.Hin = Hin; p.Win = Win; p.up = L.up ? 1 : 0; p.in_nchw = in_nchw ? 1 : 0;
@@ -317,25 +321,32 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
     p.B = c.B;
     p.Ho = (Hin + 2 * L.pad - L.KH) / L.stride + 1;
     p.Wo = (Win + 2 * L.pad - L.KW) / L.stride + 1;
-    p.out = out; p.out_nchw = out_nchw ? 1 : 0;
-    p.epi = epi | (L.bias ? EPI_BIAS : 0);
+    p.out_nchw = out_nchw ? 1 : 0;
     p.residual = residual; p.g = g; p.scale = scale; p.ss_stride = c.ss_stride;
-    p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, L.KH, L.KW, L.stride, L.C0 + L.C1, false);
-    p.geo.CK = CK;
-    return conv_launch(p, c.s);
+    const bool want_norm = (epi & EPI_NORM) != 0;
+    p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, L.KH, L.KW, L.stride, L.C0, L.C1, want_norm && !out_nchw, !out_nchw);
+    const int full_epi = epi | (L.bias ? EPI_BIAS : 0);
+    const bool in_kernel = p.geo.splits == 1 && (!want_norm || p.geo.fused_norm);
+    if (in_kernel) {
+        if (c.dry()) return 0;
+        p.out = out; p.partial = 0; p.epi = full_epi;
+        return conv_launch(p, c.s);
+    }
+    DM_REQUIRE(!out_nchw, "split / unfused epilogue writes NHWC");
+    const size_t M = (size_t)c.B * p.Ho * p.Wo;
+    float* part = c.A->alloc((size_t)p.geo.splits * M * L.Cout);
+    if (c.dry()) return 0;
+    p.out = part; p.partial = 1; p.epi = 0;
+    if (conv_launch(p, c.s)) return 1;
+    return launch_norm_act(part, p.geo.splits, (int64_t)(M * L.Cout), L.bias, g, scale, c.ss_stride, p.Ho * p.Wo,
+                           residual, out, (int64_t)M, L.Cout, full_epi, c.s);
 }
-
-static bool can_fuse_norm(int Cout) { return Cout <= 256; }
 
 // Block.forward: conv3x3 -> RMSNorm -> (scale+1, shift) -> SiLU [-> + residual]
 static int run_block(Ctx& c, const ConvLayer& L, const float* in0, const float* in1, int H, int W, const float* g,
                      const float* scale, const float* residual, float* out) {
     int flags = EPI_NORM | EPI_SILU | (scale ? EPI_SCALE_SHIFT : 0) | (residual ? EPI_RESIDUAL : 0);
-    if (can_fuse_norm(L.Cout)) return run_conv(c, L, in0, in1, H, W, out, flags, g, scale, residual);
-    float* raw = c.A->alloc((size_t)c.B * H * W * L.Cout);
-    if (run_conv(c, L, in0, in1, H, W, raw, 0, nullptr, nullptr, nullptr)) return 1;
-    if (c.dry()) return 0;
-    return launch_norm_act(raw, g, scale, c.ss_stride, H * W, residual, out, (int64_t)c.B * H * W, L.Cout, flags, c.s);
+    return run_conv(c, L, in0, in1, H, W, out, flags, g, scale, residual);
 }
 
 // ResnetBlock.forward (DD/denoising_diffusion.py:136-148); x = cat(x0, x1)
@@ -368,7 +379,8 @@ static int run_attn(Ctx& c, const AttnLayer& At, const float* x, int H, int W, f
     float* qkv = c.A->alloc(rows * 3 * hidden);
     float* o = c.A->alloc(rows * hidden);
     float* y = c.A->alloc(rows * At.dim);
-    if (!c.dry() && launch_norm_act(x, At.norm_g, nullptr, 0, n, nullptr, xn, (int64_t)rows, At.dim, EPI_NORM, c.s))
+    if (!c.dry() && launch_norm_act(x, 1, 0, nullptr, At.norm_g, nullptr, 0, n, nullptr, xn, (int64_t)rows, At.dim,
+                                    EPI_NORM, c.s))
         return 1;
     if (run_conv(c, At.qkv, xn, nullptr, H, W, qkv, 0, nullptr, nullptr, nullptr)) return 1;
     if (At.full) {
@@ -383,15 +395,7 @@ static int run_attn(Ctx& c, const AttnLayer& At, const float* x, int H, int W, f
     } else {
         float* ctxws = c.A->alloc((size_t)c.B * u->heads * u->dh * u->dh);
         if (!c.dry() && launch_linear_attention_core(qkv, At.mem_kv, ctxws, o, c.B, n, u->heads, u->dh, c.s)) return 1;
-        if (can_fuse_norm(At.dim)) {
-            if (run_conv(c, At.out, o, nullptr, H, W, y, EPI_NORM | res_flag, At.out_g, nullptr, xres)) return 1;
-        } else {
-            float* raw = c.A->alloc(rows * At.dim);
-            if (run_conv(c, At.out, o, nullptr, H, W, raw, 0, nullptr, nullptr, nullptr)) return 1;
-            if (!c.dry() && launch_norm_act(raw, At.out_g, nullptr, 0, n, xres, y, (int64_t)rows, At.dim,
-                                            EPI_NORM | res_flag, c.s))
-                return 1;
-        }
+        if (run_conv(c, At.out, o, nullptr, H, W, y, EPI_NORM | res_flag, At.out_g, nullptr, xres)) return 1;
     }
     *out = y;
     return 0;
@@ -416,14 +420,7 @@ static int run_cross(Ctx& c, const CrossLayer& Cr, const float* x, int H, int W,
                                   1.0f / sqrtf((float)u->dh), c.s))
             return 1;
     }
-    if (can_fuse_norm(dim)) {
-        if (run_conv(c, Cr.out, o, nullptr, H, W, y, EPI_NORM, Cr.g, nullptr, nullptr)) return 1;
-    } else {
-        float* raw = c.A->alloc(rows * dim);
-        if (run_conv(c, Cr.out, o, nullptr, H, W, raw, 0, nullptr, nullptr, nullptr)) return 1;
-        if (!c.dry() && launch_norm_act(raw, Cr.g, nullptr, 0, n, nullptr, y, (int64_t)rows, dim, EPI_NORM, c.s))
-            return 1;
-    }
+    if (run_conv(c, Cr.out, o, nullptr, H, W, y, EPI_NORM, Cr.g, nullptr, nullptr)) return 1;
     *out = y;
     return 0;
 }

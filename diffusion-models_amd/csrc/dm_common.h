@@ -52,6 +52,11 @@ struct ConvGeom {
     int tiles_x, tiles_y, groups, n_tiles_n;
     int IH, IW;          // staged input window per image
     int halo_floats;     // LDS floats for the activation window (multiple of 4)
+    int w_floats;        // LDS floats of one weight slab buffer (two are allocated)
+    int TPS;             // taps (along kx) per weight slab: KW or 1
+    int splits;          // K splits (blockIdx.y); > 1 writes partial sums
+    int chunks_per_split;
+    int fused_norm;      // the plan keeps all couts of a pixel in one workgroup (EPI_NORM allowed)
     int lds_bytes;
 };
 
@@ -64,12 +69,13 @@ struct ConvParams {
     int Hin, Win;        // spatial size the convolution sees (after nearest x2 if up)
     int up;              // sources are (Hin/2, Win/2), nearest-upsampled on the fly
     int in_nchw;         // source 0 is NCHW (boundary tensors); requires C1 == 0
-    const float* w;      // packed [n_tile][chunk][ky][kx][NT][CK]
+    const float* w;      // packed [chunk][ky][kx][Cout padded to 64][CK]
     const float* bias;
     int Cout, KH, KW, stride, pad;
     int B, Ho, Wo;
     float* out;
     int out_nchw;
+    int partial;         // out is [splits][pixel][Cout] raw partial sums, no epilogue
     int epi;
     const float* residual;   // NHWC [pixel][Cout]
     const float* g;          // [Cout]
@@ -78,15 +84,15 @@ struct ConvParams {
     ConvGeom geo;
 };
 
-// choose tiling for an output of (B, Ho, Wo, Cout) and a KHxKW/stride window
-ConvGeom conv_plan(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, int Cin_total, bool want_norm);
-// NT (couts per tile) the packer must use for a layer with Cout output channels
-int conv_nt_for(int Cout, bool want_norm);
+// choose wave grid, tile, weight-slab size and K splits for an output of (B, Ho, Wo, Cout);
+// want_norm: the caller would like RMSNorm fused (granted when plan.fused_norm != 0)
+ConvGeom conv_plan(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, int C0, int C1, bool want_norm,
+                   bool allow_split);
 int conv_ck_for(int C0, int C1);
 // floats needed for packed weights
-size_t conv_packed_floats(int Cout, int C0, int C1, int KH, int KW, bool want_norm);
+size_t conv_packed_floats(int Cout, int C0, int C1, int KH, int KW);
 // pack OIHW (Cout, C0+C1, KH, KW) -> kernel layout (host side)
-void conv_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1, int KH, int KW, bool want_norm);
+void conv_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1, int KH, int KW);
 int conv_launch(const ConvParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
@@ -95,6 +101,7 @@ int conv_launch(const ConvParams& p, hipStream_t s);
 // ---------------------------------------------------------------------------------------
 namespace prof {
 bool enabled();
+bool detail();  // per-shape kernel names (tools/layer_report.py)
 // bracket one launch: begin() records an event on `s`, end() records the closing one
 int begin(const char* kernel, double flops, double bytes, hipStream_t s);
 int end(hipStream_t s);
@@ -105,9 +112,11 @@ int end(hipStream_t s);
 // ---------------------------------------------------------------------------------------
 int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t s);
 int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t s);
-// y = [silu]( rmsnorm(x)*g*sqrt(C) [*(scale+1)+shift] ) [+ residual]; rows = pixels
-int launch_norm_act(const float* x, const float* g, const float* scale, int ss_stride, int pix_per_image,
-                    const float* residual, float* y, int64_t rows, int C, int flags, hipStream_t s);
+// v = sum_{s<nsplit} x[s*split_stride + row*C + c] [+ bias[c]];
+// y = [silu]( rmsnorm(v)*g*sqrt(C) [*(scale+1)+shift] ) [+ residual]; rows = pixels; flags = EPI_*
+int launch_norm_act(const float* x, int nsplit, int64_t split_stride, const float* bias, const float* g,
+                    const float* scale, int ss_stride, int pix_per_image, const float* residual, float* y,
+                    int64_t rows, int C, int flags, hipStream_t s);
 // y[r][o] = act_out(bias[o] + sum_i act_in(x[r][i]) * W[o][i]);  act: 0 none, 1 silu, 2 gelu(erf)
 int launch_linear_rows(const float* x, int ldx, const float* W, const float* bias, float* y, int ldy, int R, int I,
                        int O, int act_in, int act_out, hipStream_t s);

@@ -53,7 +53,10 @@ int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipSt
 // Restates RMSNorm.forward (DD/denoising_diffusion.py:66-67) and the tail of Block.forward
 // (:115-121) for layers whose output channels do not fit one conv workgroup.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void norm_act_kernel(const float* __restrict__ x, const float* __restrict__ g,
+// Also the landing kernel of split-K convolutions: sums the K-split partial tiles and adds the bias first.
+template <int MAXV>  // MAXV > 0: the row (C <= 64*MAXV) is held in registers; 0: re-read (any C)
+__global__ __launch_bounds__(256) void norm_act_kernel(const float* __restrict__ x, int nsplit, int64_t split_stride,
+                                                       const float* __restrict__ bias, const float* __restrict__ g,
                                                        const float* __restrict__ scale, int ss_stride,
                                                        int pix_per_image, const float* __restrict__ residual,
                                                        float* __restrict__ y, int64_t rows, int C, int flags) {
@@ -62,31 +65,64 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const float* __restrict__
     if (row >= rows) return;
     const float* xr = x + row * C;
     float* yr = y + row * C;
-    float rn = 1.0f;
-    if (flags & EPI_NORM) {
-        float ss = 0.f;
+    auto value = [&](int c) {
+        float v = xr[c];
+        for (int sp = 1; sp < nsplit; ++sp) v += xr[(size_t)sp * split_stride + c];
+        if (flags & EPI_BIAS) v += bias[c];
+        return v;
+    };
+    float vals[MAXV > 0 ? MAXV : 1];
+    float ss = 0.f;
+    if constexpr (MAXV > 0) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            int c = lane + 64 * i;
+            vals[i] = c < C ? value(c) : 0.f;
+            ss += vals[i] * vals[i];
+        }
+    } else if (flags & EPI_NORM) {
         for (int c = lane; c < C; c += 64) {
-            float v = xr[c];
+            float v = value(c);
             ss += v * v;
         }
+    }
+    float rn = 1.0f;
+    if (flags & EPI_NORM) {
         ss = wave_sum(ss);
         rn = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
     }
     const float* sp = nullptr;
     if (flags & EPI_SCALE_SHIFT) sp = scale + (row / pix_per_image) * (int64_t)ss_stride;
-    for (int c = lane; c < C; c += 64) {
-        float v = xr[c];
+    auto finish = [&](int c, float v) {
         if (flags & EPI_NORM) v = v * rn * g[c];
         if (flags & EPI_SCALE_SHIFT) v = v * (sp[c] + 1.0f) + sp[C + c];
         if (flags & EPI_SILU) v = silu_f(v);
         if (flags & EPI_RESIDUAL) v += residual[row * C + c];
         yr[c] = v;
+    };
+    if constexpr (MAXV > 0) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            int c = lane + 64 * i;
+            if (c < C) finish(c, vals[i]);
+        }
+    } else {
+        for (int c = lane; c < C; c += 64) finish(c, value(c));
     }
 }
-int launch_norm_act(const float* x, const float* g, const float* scale, int ss_stride, int pix_per_image,
-                    const float* residual, float* y, int64_t rows, int C, int flags, hipStream_t s) {
-    hipLaunchKernelGGL(norm_act_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, scale, ss_stride,
-                       pix_per_image, residual, y, rows, C, flags);
+int launch_norm_act(const float* x, int nsplit, int64_t split_stride, const float* bias, const float* g,
+                    const float* scale, int ss_stride, int pix_per_image, const float* residual, float* y,
+                    int64_t rows, int C, int flags, hipStream_t s) {
+    dim3 grid((rows + 3) / 4), block(256);
+    if (C <= 128)
+        hipLaunchKernelGGL(norm_act_kernel<2>, grid, block, 0, s, x, nsplit, split_stride, bias, g, scale, ss_stride,
+                           pix_per_image, residual, y, rows, C, flags);
+    else if (C <= 512)
+        hipLaunchKernelGGL(norm_act_kernel<8>, grid, block, 0, s, x, nsplit, split_stride, bias, g, scale, ss_stride,
+                           pix_per_image, residual, y, rows, C, flags);
+    else
+        hipLaunchKernelGGL(norm_act_kernel<0>, grid, block, 0, s, x, nsplit, split_stride, bias, g, scale, ss_stride,
+                           pix_per_image, residual, y, rows, C, flags);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
