@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdm_hip.so")
+# DM_LIB selects another build of the same ABI (tools/conv_stamps.py loads the stamped diagnostic build)
+LIB_PATH = os.environ.get("DM_LIB") or os.path.join(_HERE, "libdm_hip.so")
 DM_MAX_STAGES = 8
 DM_COEFS = 8
 ABI_VERSION = 1

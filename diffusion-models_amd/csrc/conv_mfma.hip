@@ -35,6 +35,42 @@
 namespace dm {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+// 16-byte staging values are NATIVE vectors, not HIP's float4 struct: arrays of the struct are copied with
+// llvm.memcpy between address spaces, which keeps them in scratch memory (one synchronous round trip per
+// global load) instead of registers.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ f32x4 make_f32x4(float a, float b, float c, float d) { return f32x4{a, b, c, d}; }
+
+// In-kernel cycle stamps: DIAGNOSTIC build only (make STAMPS=1 -> libdm_hip_stamps.so, tools/conv_stamps.py).
+// Wave 0 of every workgroup sums the s_memtime cycles it spends per phase into p.stamps[block][8]; nothing
+// the kernel outputs depends on them.  In the shipped library every macro below is empty.
+#ifdef DM_STAMPS
+__device__ __forceinline__ unsigned long long dm_stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define DM_STAMP_DECL unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DM_STAMP(k) st_prev = dm_stamp_now();
+#define DM_STAMP_ADD(k)                              \
+    {                                                \
+        unsigned long long st_now = dm_stamp_now();  \
+        st_acc[k] += st_now - st_prev;               \
+        st_prev = st_now;                            \
+    }
+#define DM_STAMP_FLUSH                                                                              \
+    if (threadIdx.x == 0 && p.stamps) {                                                             \
+        unsigned long long* sp_ = p.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;     \
+        for (int k_ = 0; k_ < 8; ++k_) sp_[k_] = st_acc[k_];                                        \
+    }
+#else
+#define DM_STAMP_DECL
+#define DM_STAMP(k)
+#define DM_STAMP_ADD(k)
+#define DM_STAMP_FLUSH
+#endif
 
 static inline int pow2ceil(int v) {
     int p = 1;
@@ -55,7 +91,7 @@ static inline int env_int(const char* name, int dflt) {
 
 int conv_ck_for(int C0, int C1) { return (C0 % 16 == 0 && C1 % 16 == 0) ? 16 : 4; }
 
-// halo / weight staging registers (float4 per thread) per instantiation
+// halo / weight staging registers (f32x4 per thread) per instantiation
 static constexpr int hregs_for(int WM) { return WM == 4 ? 9 : (WM == 2 ? 5 : 3); }
 static constexpr int wregs_for(int WN, int CK) { return CK == 16 ? 3 * WN : 2 * WN; }
 
@@ -63,7 +99,7 @@ static constexpr int wregs_for(int WN, int CK) { return CK == 16 ? 3 * WN : 2 * 
 size_t conv_packed_floats(int Cout, int C0, int C1, int KH, int KW) {
     int CK = conv_ck_for(C0, C1);
     int chunks = pad_to(C0, CK) / CK + (C1 ? pad_to(C1, CK) / CK : 0);
-    return (size_t)chunks * KH * KW * pad_to(Cout, 64) * CK;
+    return (size_t)chunks * KH * KW * pad_to(Cout, 256) * CK;
 }
 
 void conv_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1, int KH, int KW) {
@@ -72,7 +108,7 @@ void conv_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C
     int chunks1 = C1 ? pad_to(C1, CK) / CK : 0;
     int chunks = chunks0 + chunks1;
     int Cin = C0 + C1;
-    int CoutP = pad_to(Cout, 64);
+    int CoutP = pad_to(Cout, 256);
     std::memset(packed, 0, conv_packed_floats(Cout, C0, C1, KH, KW) * sizeof(float));
     for (int ch = 0; ch < chunks; ++ch)
         for (int ky = 0; ky < KH; ++ky)
@@ -160,7 +196,8 @@ ConvGeom conv_plan(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, 
     }
     // taps per weight slab: a whole kernel row when two buffers + the window leave room for 2 WGs/CU
     const int NT = 64 * g.WN;
-    g.halo_floats = pad_to(g.NB * g.IH * g.IW * CKP, 4);
+    // CK == 16 stages the window in whole 256-thread passes of 64 pixel rows (unpredicated LDS stores)
+    g.halo_floats = g.CK == 16 ? pad_to(g.NB * g.IH * g.IW, 64) * CKP : pad_to(g.NB * g.IH * g.IW * CKP, 4);
     g.TPS = KW;
     if (g.WN > 1 && (g.halo_floats + 2 * KW * NT * CKP) * 4 > 80 * 1024) g.TPS = 1;
     if (KW * NT * (g.CK / 4) > 256 * wregs_for(g.WN, g.CK)) g.TPS = 1;
@@ -184,38 +221,43 @@ ConvGeom conv_plan(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, 
 
 // ---------------------------------------------------------------------------------------
 
-template <int CK>
-struct Frag {
-    float v[CK / 2];
-};
-
-template <int CK>
-__device__ __forceinline__ void lds_read_frag(const float* p, Frag<CK>& f) {
-    if constexpr (CK == 4) {
-        float2 t = *reinterpret_cast<const float2*>(p);
-        f.v[0] = t.x;
-        f.v[1] = t.y;
-    } else {
-#pragma unroll
-        for (int q = 0; q < CK / 8; ++q) {
-            float4 t = *reinterpret_cast<const float4*>(p + 4 * q);
-            f.v[4 * q + 0] = t.x;
-            f.v[4 * q + 1] = t.y;
-            f.v[4 * q + 2] = t.z;
-            f.v[4 * q + 3] = t.w;
+// E consecutive k-values of one MFMA operand row/column (one ds_read_b128 or ds_read_b64)
+template <int E>
+struct MicroFrag {
+    float v[E];
+    __device__ __forceinline__ void load(const float* p) {
+        if constexpr (E == 2) {
+            float2 t = *reinterpret_cast<const float2*>(p);
+            v[0] = t.x;
+            v[1] = t.y;
+        } else {
+            f32x4 t = *reinterpret_cast<const f32x4*>(p);
+            v[0] = t.x;
+            v[1] = t.y;
+            v[2] = t.z;
+            v[3] = t.w;
         }
     }
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
 __device__ __forceinline__ float half_wave_sum(float v) {
-    // sum over the 32 lanes that share lane>>5 (xor masks stay inside a 32-lane half)
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
+    // sum over the 32 lanes that share lane>>5; every lane ends with the total.
+    // Four DPP steps inside each 16-lane row (they fuse into v_add_f32_dpp), one swizzle across the two rows.
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]  : lane ^ 1
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]  : lane ^ 2
+    v += dpp_f<0x141>(v);  // row_half_mirror      : pairs the two quads of each 8 lanes
+    v += dpp_f<0x140>(v);  // row_mirror           : pairs the two halves of the row
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // lane ^ 16
     return v;
 }
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
 // source pixel (b*Hs + sy)*Ws + sx behind window pixel hp of this tile, or -1 (padding / outside the batch).
 // Chunk independent, so a thread computes it once per kernel for the window items it stages.
@@ -236,14 +278,14 @@ __device__ __forceinline__ int window_pixel(const ConvParams& p, int hp, int b0,
     return (b * Hs + sy) * Ws + sx;
 }
 
-// one float4 of the input window: source pixel `pix`, channel quad q of chunk `chunk`
+// one f32x4 of the input window: source pixel `pix`, channel quad q of chunk `chunk`
 template <int CK>
-__device__ __forceinline__ float4 load_window_px(const ConvParams& p, int pix, int q, int chunk) {
+__device__ __forceinline__ f32x4 load_window_px(const ConvParams& p, int pix, int q, int chunk) {
     const bool src1 = chunk >= p.chunks0;
     const float* __restrict__ src = src1 ? p.in1 : p.in0;
     const int Cs = src1 ? p.C1 : p.C0;
     const int c = (src1 ? chunk - p.chunks0 : chunk) * CK + 4 * q;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 v = make_f32x4(0.f, 0.f, 0.f, 0.f);
     if (pix >= 0 && c < Cs) {
         if (p.in_nchw) {
             const int HWs = (p.up ? (p.Hin >> 1) * (p.Win >> 1) : p.Hin * p.Win);
@@ -257,7 +299,7 @@ __device__ __forceinline__ float4 load_window_px(const ConvParams& p, int pix, i
         } else {
             size_t o = (size_t)pix * Cs + c;
             if ((Cs & 3) == 0) {
-                v = *reinterpret_cast<const float4*>(src + o);
+                v = *reinterpret_cast<const f32x4*>(src + o);
             } else {
                 v.x = src[o];
                 if (c + 1 < Cs) v.y = src[o + 1];
@@ -274,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     constexpr int NT = WN * 64;
     constexpr int CKP = (CK == 4) ? 4 : CK + 4;
     constexpr int HALF = CK / 2;
-    constexpr int QPP = CK / 4;  // float4 items per pixel / weight row
+    constexpr int QPP = CK / 4;  // f32x4 items per pixel / weight row
     constexpr int HREGS = hregs_for(WM);
     constexpr int WREGS = wregs_for(WN, CK);
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -301,6 +343,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int group = bid / g.tiles_y;
     const int x0 = tile_x * g.TW, y0 = tile_y * g.TH, b0 = group * g.NB;
     const int ix0 = x0 * p.stride - p.pad, iy0 = y0 * p.stride - p.pad;
+    DM_STAMP_DECL
+    DM_STAMP(0);
+    __builtin_amdgcn_s_setprio(3);  // lowered to 0 only around the MFMA stream (see the slab loop)
     const int split = blockIdx.y;
     const int cb = split * g.chunks_per_split;
     const int ce = min(cb + g.chunks_per_split, p.n_chunks);
@@ -333,40 +378,52 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int kxg = p.KW / TPS;           // tap groups per kernel row
     const int spc = p.KH * kxg;           // slabs per chunk
     const int n_slabs = (ce - cb) * spc;
-    const int CoutP = (p.Cout + 63) & ~63;
+    const int CoutP = (p.Cout + 255) & ~255;  // packed rows are padded so every N tile reads in bounds
     const float* __restrict__ wtile = p.w + (size_t)n_tile * NT * CK;
 
-    float4 wreg[WREGS];
-    float4 hreg[HREGS];
+    f32x4 wreg[WREGS];
+    f32x4 hreg[HREGS];
 
-    auto load_w = [&](int slab) {
-        const int chunk = cb + slab / spc;
-        const int rem = slab % spc;
-        const int ky = rem / kxg;
-        const int kx0 = (rem - ky * kxg) * TPS;
+    // Weight slab (chunk, ky, kx0 .. kx0+TPS-1) -> registers -> LDS.  For CK == 16 a slab is a whole number
+    // of 256-thread passes (TPS*WN of them) and the packed rows are padded to 256 couts, so the code is
+    // branch-free apart from the uniform pass count: item i of a thread is tap i/WN, cout rows (i%WN)*64...
+    const int n_w = TPS * WN;  // CK == 16 passes
+    auto load_w = [&](int chunk, int ky, int kx0) {
         const float* __restrict__ src =
             wtile + ((((size_t)chunk * p.KH + ky) * p.KW + kx0) * (size_t)CoutP) * CK;
+        if constexpr (CK == 16) {
 #pragma unroll
-        for (int i = 0; i < WREGS; ++i) {
-            int it = tid + 256 * i;
-            if (it < w_items) {
-                int t = it / (NT * QPP);
-                int rq = it - t * (NT * QPP);
-                // rows past CoutP (last N tile of a Cout that is not a multiple of NT) are zero
-                wreg[i] = (n_tile * NT + rq / QPP < CoutP)
-                              ? *reinterpret_cast<const float4*>(src + (size_t)t * CoutP * CK + rq * 4)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < WREGS; ++i)
+                if (i < n_w)
+                    wreg[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(i / WN) * CoutP * CK +
+                                                               (i % WN) * 1024 + tid * 4);
+        } else {
+#pragma unroll
+            for (int i = 0; i < WREGS; ++i) {
+                int it = tid + 256 * i;
+                if (it < w_items) {
+                    int t = it / (NT * QPP);
+                    int rq = it - t * (NT * QPP);
+                    wreg[i] = *reinterpret_cast<const f32x4*>(src + (size_t)t * CoutP * CK + rq * 4);
+                }
             }
         }
     };
     auto store_w = [&](float* wb) {
+        if constexpr (CK == 16) {
+            float* dst = wb + (tid >> 2) * CKP + (tid & 3) * 4;
 #pragma unroll
-        for (int i = 0; i < WREGS; ++i) {
-            int it = tid + 256 * i;
-            if (it < w_items) {
-                int row = it / QPP;  // t*NT + cout row
-                int q = it - row * QPP;
-                *reinterpret_cast<float4*>(wb + row * CKP + 4 * q) = wreg[i];
+            for (int i = 0; i < WREGS; ++i)
+                if (i < n_w) *reinterpret_cast<f32x4*>(dst + i * 64 * CKP) = wreg[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < WREGS; ++i) {
+                int it = tid + 256 * i;
+                if (it < w_items) {
+                    int row = it / QPP;  // t*NT + cout row
+                    int q = it - row * QPP;
+                    *reinterpret_cast<f32x4*>(wb + row * CKP + 4 * q) = wreg[i];
+                }
             }
         }
     };
@@ -387,21 +444,44 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         int b = b0 + nb, y = y0 + ty, x = x0 + tx;
         ptab[tid] = (b < p.B && y < p.Ho && x < p.Wo) ? (b * p.Ho + y) * p.Wo + x : -1;
     }
+    // Input window of one channel chunk -> registers -> LDS.  CK == 16 (NHWC, C % 16 == 0): branch-free --
+    // padding pixels load pixel 0 and are zeroed by a select; the LDS region is padded to whole passes.
+    const int n_h = (halo_items + 255) >> 8;
     auto load_h = [&](int chunk) {
+        if constexpr (CK == 16) {
+            const bool src1 = chunk >= p.chunks0;
+            const float* __restrict__ src = (src1 ? p.in1 : p.in0) + (src1 ? chunk - p.chunks0 : chunk) * CK + (tid & 3) * 4;
+            const int Cs = src1 ? p.C1 : p.C0;
 #pragma unroll
-        for (int i = 0; i < HREGS; ++i) {
-            int it = tid + 256 * i;
-            if (it < halo_items) hreg[i] = load_window_px<CK>(p, hpix[i], it & (QPP - 1), chunk);
+            for (int i = 0; i < HREGS; ++i)
+                if (i < n_h)  // zeroing of padding pixels happens at store time: nothing here may touch the data,
+                              // or the wave would wait for the load right after issuing it
+                    hreg[i] = *reinterpret_cast<const f32x4*>(src + (size_t)max(hpix[i], 0) * Cs);
+        } else {
+#pragma unroll
+            for (int i = 0; i < HREGS; ++i) {
+                int it = tid + 256 * i;
+                if (it < halo_items) hreg[i] = load_window_px<CK>(p, hpix[i], it & (QPP - 1), chunk);
+            }
         }
     };
     auto store_h = [&]() {
+        if constexpr (CK == 16) {
+            float* dst = halo + (tid >> 2) * CKP + (tid & 3) * 4;
 #pragma unroll
-        for (int i = 0; i < HREGS; ++i) {
-            int it = tid + 256 * i;
-            if (it < halo_items) {
-                int hp = it / QPP;
-                int q = it - hp * QPP;
-                *reinterpret_cast<float4*>(halo + hp * CKP + 4 * q) = hreg[i];
+            for (int i = 0; i < HREGS; ++i)
+                if (i < n_h)
+                    *reinterpret_cast<f32x4*>(dst + i * 64 * CKP) =
+                        hpix[i] >= 0 ? hreg[i] : make_f32x4(0.f, 0.f, 0.f, 0.f);
+        } else {
+#pragma unroll
+            for (int i = 0; i < HREGS; ++i) {
+                int it = tid + 256 * i;
+                if (it < halo_items) {
+                    int hp = it / QPP;
+                    int q = it - hp * QPP;
+                    *reinterpret_cast<f32x4*>(halo + hp * CKP + 4 * q) = hreg[i];
+                }
             }
         }
     };
@@ -409,13 +489,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         for (int it = tid; it < halo_items; it += 256) {
             int hp = it / QPP;
             int q = it - hp * QPP;
-            float4 v = load_window_px<CK>(p, window_pixel(p, hp, b0, iy0, ix0), q, chunk);
-            *reinterpret_cast<float4*>(halo + hp * CKP + 4 * q) = v;
+            f32x4 v = load_window_px<CK>(p, window_pixel(p, hp, b0, iy0, ix0), q, chunk);
+            *reinterpret_cast<f32x4*>(halo + hp * CKP + 4 * q) = v;
         }
     };
 
     // ---- prologue: slab 0 ----
-    load_w(0);
+    load_w(cb, 0, 0);
     if (halo_in_regs) {
         load_h(cb);
         store_h();
@@ -424,42 +504,95 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     }
     store_w(wbuf0);
     __syncthreads();
+    DM_STAMP_ADD(0)
 
+    // slab counters (chunk, ky, tap group) advance incrementally: no integer division in the loop
+    int chunk = cb, ky = 0, kgi = 0;
     for (int slab = 0; slab < n_slabs; ++slab) {
-        const int next = slab + 1;
-        const bool has_next = next < n_slabs;
-        const bool chunk_ends = has_next && (next % spc == 0);
-        const int next_chunk = cb + next / spc;
-        if (has_next) load_w(next);
+        const bool has_next = slab + 1 < n_slabs;
+        int nchunk = chunk, nky = ky, nkgi = kgi + 1;
+        if (nkgi == kxg) {
+            nkgi = 0;
+            if (++nky == p.KH) {
+                nky = 0;
+                ++nchunk;
+            }
+        }
+        const bool chunk_ends = has_next && nchunk != chunk;
+        const int next_chunk = nchunk;
+        if (has_next) load_w(nchunk, nky, nkgi * TPS);
         if (chunk_ends && halo_in_regs) load_h(next_chunk);
+        DM_STAMP_ADD(1)
+        // The staging code of this wave competes for the SIMD's issue port with the MFMA stream of the
+        // co-resident workgroup's wave and loses about one slot per MFMA at equal priority (stamps: ~5k
+        // cycles for ~150 instructions).  Run everything except the MFMA stream at raised priority.
+        __builtin_amdgcn_s_setprio(0);
 
-        const int rem = slab % spc;
-        const int ky = rem / kxg;
-        const int kx0 = (rem - ky * kxg) * TPS;
+        const int kx0 = kgi * TPS;
         const float* wb = (slab & 1) ? wbuf1 : wbuf0;
-        for (int t = 0; t < TPS; ++t) {
-            const int a_off = (ky * g.IW + kx0 + t) * CKP;
-            const int b_off = t * NT * CKP;
-            Frag<CK> fa[2], fb[2];
+        // Micro-step = E consecutive channels of one tap for this lane half (E*4 MFMAs).  Fragment reads of
+        // micro-step u+1 are issued before the MFMAs of micro-step u (ping-pong registers), so the LDS
+        // latency hides under matrix work instead of stalling every tap.
+        constexpr int E = (CK == 16) ? 4 : 2;
+        constexpr int UPT = HALF / E;  // micro-steps per tap
+        const int nu = TPS * UPT;
+        const int a_row = (ky * g.IW + kx0) * CKP;
+        auto read_frags = [&](int u, MicroFrag<E> (&fa)[2], MicroFrag<E> (&fb)[2]) {
+            const int t = u / UPT, hh = u - t * UPT;
+            const int a_off = a_row + t * CKP + hh * E;
+            const int b_off = t * NT * CKP + hh * E;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) lds_read_frag<CK>(halo + a_base[r] + a_off, fa[r]);
+            for (int r = 0; r < 2; ++r) fa[r].load(halo + a_base[r] + a_off);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) lds_read_frag<CK>(wb + b_base[q] + b_off, fb[q]);
+            for (int q = 0; q < 2; ++q) fb[q].load(wb + b_base[q] + b_off);
+        };
+        auto mfma_block = [&](const MicroFrag<E> (&fa)[2], const MicroFrag<E> (&fb)[2]) {
 #pragma unroll
-            for (int s = 0; s < HALF; ++s)
+            for (int s = 0; s < E; ++s)
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
                         acc[r][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[r].v[s], fb[q].v[s], acc[r][q], 0, 0, 0);
+        };
+        MicroFrag<E> fa0[2], fb0[2], fa1[2], fb1[2];
+        read_frags(0, fa0, fb0);
+        // reads past the end are clamped to the last micro-step (a harmless re-read) so that the loop body
+        // has no branch between a ds_read and its MFMAs: the compiler can then wait with a COUNTED lgkmcnt
+        // sched_barrier(0) pins the order [reads of u+1][MFMAs of u]: without it the scheduler sinks the
+        // reads to the end of the MFMA block to save registers and the latency is exposed again.
+        for (int u = 0; u < nu; u += 2) {
+            read_frags(min(u + 1, nu - 1), fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (UPT % 2 == 0) {
+                read_frags(min(u + 2, nu - 1), fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_block(fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (u + 1 < nu) {
+                read_frags(min(u + 2, nu - 1), fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_block(fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (has_next) store_w((next & 1) ? wbuf1 : wbuf0);
+        __builtin_amdgcn_s_setprio(3);
+        DM_STAMP_ADD(2)
+        if (has_next) store_w((slab & 1) ? wbuf0 : wbuf1);
+        DM_STAMP_ADD(3)
         __syncthreads();  // slab done everywhere: its weight buffer and (at a chunk end) the window are free
+        DM_STAMP_ADD(4)
         if (chunk_ends) {
             if (halo_in_regs) store_h();
             else stage_h_direct(next_chunk);
             __syncthreads();
         }
+        DM_STAMP_ADD(5)
+        chunk = nchunk;
+        ky = nky;
+        kgi = nkgi;
     }
 
     // ------------------------------- epilogue -------------------------------
@@ -487,6 +620,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                 for (int q = 0; q < 2; ++q)
                     if (cok[q]) po[pix * p.Cout + co[q]] = acc[r][q][e];
             }
+        DM_STAMP_ADD(6)
+        DM_STAMP_FLUSH
         return;
     }
 
@@ -544,7 +679,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float rn = 1.0f / fmaxf(sqrtf(ss[r][e]), 1e-12f);
+                // 1 / max(||v||, 1e-12) as one v_rsq_f32 (1 ulp)
+                float rn = fast_rsq(fmaxf(ss[r][e], 1e-24f));
 #pragma unroll
                 for (int q = 0; q < 2; ++q) acc[r][q][e] = acc[r][q][e] * rn * gq[q];
             }
@@ -582,7 +718,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                         v = v * (sp[co[q]] + 1.0f) + sp[p.Cout + co[q]];
                     }
                 }
-                if (epi & EPI_SILU) v = v / (1.0f + __expf(-v));
+                if (epi & EPI_SILU) v = v * fast_rcp(1.0f + __expf(-v));
                 if (epi & EPI_RESIDUAL) v += p.residual[pix * p.Cout + co[q]];
                 if (p.out_nchw) {
                     const int b = pixi / HoWo;
@@ -592,6 +728,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                 }
             }
         }
+    DM_STAMP_ADD(6)
+    DM_STAMP_FLUSH
 }
 
 template <int WM, int WN, int CK>
@@ -623,6 +761,33 @@ static int launch_one(const ConvParams& p, hipStream_t s) {
             snprintf(name, sizeof(name), "conv_mfma_kernel<%d,%d,%d>", WM, WN, CK);
         if (prof::begin(name, flops, bytes, s)) return 1;
     }
+#ifdef DM_STAMPS
+    // diagnostic build: run the launch synchronously with a stamp buffer and print the phase averages
+    {
+        const size_t nblk = (size_t)blocks * g.splits;
+        unsigned long long* dbuf = nullptr;
+        DM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), nblk * 8 * sizeof(unsigned long long)));
+        DM_CHECK_HIP(hipMemsetAsync(dbuf, 0, nblk * 8 * sizeof(unsigned long long), s));
+        ConvParams ps = p;
+        ps.stamps = dbuf;
+        hipLaunchKernelGGL(kern, dim3(blocks, g.splits), dim3(256), g.lds_bytes, s, ps);
+        DM_CHECK_HIP(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h(nblk * 8);
+        DM_CHECK_HIP(hipMemcpy(h.data(), dbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        (void)hipFree(dbuf);
+        double avg[8] = {0};
+        for (size_t b = 0; b < nblk; ++b)
+            for (int k = 0; k < 8; ++k) avg[k] += (double)h[b * 8 + k] / nblk;
+        double tot = 0;
+        for (int k = 0; k < 7; ++k) tot += avg[k];
+        fprintf(stderr,
+                "STAMPS conv<%d,%d,%d> %dx%d %d+%d->%d @%dx%d e%d k%d: wgs=%zu total=%.0f | prologue %.0f issue %.0f "
+                "mfma %.0f storew %.0f barrier %.0f halo %.0f epilogue %.0f\n",
+                WM, WN, CK, p.KH, p.KW, p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.epi, g.splits, nblk, tot, avg[0], avg[1],
+                avg[2], avg[3], avg[4], avg[5], avg[6]);
+        return 0;
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3(blocks, g.splits), dim3(256), g.lds_bytes, s, p);
     DM_CHECK_HIP(hipGetLastError());
     if (timed && prof::end(s)) return 1;
@@ -631,6 +796,7 @@ static int launch_one(const ConvParams& p, hipStream_t s) {
 
 int conv_launch(const ConvParams& pin, hipStream_t s) {
     ConvParams p = pin;
+    p.stamps = nullptr;
     ConvGeom& g = p.geo;
     const int CK = g.CK;
     DM_REQUIRE(g.WM * g.WN == 4, "conv: bad wave grid");

@@ -76,6 +76,7 @@ struct ConvParams {
     float* out;
     int out_nchw;
     int partial;         // out is [splits][pixel][Cout] raw partial sums, no epilogue
+    unsigned long long* stamps;  // diagnostic build (-DDM_STAMPS) only: per-workgroup phase cycle sums
     int epi;
     const float* residual;   // NHWC [pixel][Cout]
     const float* g;          // [Cout]
