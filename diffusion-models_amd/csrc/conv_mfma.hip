@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         }
     }
     // global pixel index of every output row of the tile (or -1), shared by all waves in the epilogue
-    int* ptab = reinterpret_cast<int*>(wbuf1 + g.w_floats);
+    int* ptab = reinterpret_cast<int*>(smem + g.ptab_off);
     if (tid < WM * 64) {
         int tx = tid & (g.TW - 1);
         int ty = (tid >> g.lTW) & (g.TH - 1);
@@ -597,6 +597,124 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 
     // ------------------------------- epilogue -------------------------------
     const int epi = p.epi;
+    {
+        // Row-layout epilogue (each wave owns 64 pixels x 64 consecutive couts): the accumulators go
+        // through LDS once so that a pixel's 64 couts sit on 16 consecutive lanes as float4.  Every global
+        // access of the epilogue is then a 16-byte one covering whole 256-byte pixel rows (16 stores per lane
+        // instead of 64 dword stores), the RMSNorm reduction stays inside a 16-lane DPP row, and the
+        // per-cout vectors (bias, g, scale, shift) are one float4 per lane.
+        if (!p.out_nchw && (p.Cout & 3) == 0) {
+            constexpr int TS = 68;  // padded row stride (floats): conflict-free b32 writes and b128 reads
+            float* T = smem + wave * (64 * TS);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        T[(r * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * TS + q * 32 + l31] = acc[r][q][e];
+            __builtin_amdgcn_wave_barrier();
+            const int rsub = lane >> 4;          // row within a group of 4
+            const int c4 = (lane & 15) * 4;      // first of this lane's 4 couts inside the tile
+            const int cg = n_tile * NT + wn * 64 + c4;  // global cout
+            const bool cvalid = cg < p.Cout;
+            f32x4 v[16];
+            int pixv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                v[j] = *reinterpret_cast<const f32x4*>(T + (4 * j + rsub) * TS + c4);
+                pixv[j] = ptab[wm * 64 + 4 * j + rsub];
+            }
+            if (p.partial) {
+                const size_t M = (size_t)p.B * p.Ho * p.Wo;
+                float* po = p.out + (size_t)split * M * p.Cout + cg;
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (pixv[j] >= 0 && cvalid) *reinterpret_cast<f32x4*>(po + (size_t)pixv[j] * p.Cout) = v[j];
+                DM_STAMP_ADD(6)
+                DM_STAMP_FLUSH
+                return;
+            }
+            const int epi = p.epi;
+            const f32x4 zero4 = make_f32x4(0.f, 0.f, 0.f, 0.f);
+            f32x4 b4 = zero4;
+            if ((epi & EPI_BIAS) && cvalid) b4 = *reinterpret_cast<const f32x4*>(p.bias + cg);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = cvalid ? v[j] + b4 : zero4;
+            if (epi & EPI_NORM) {
+                const float sqrtc = sqrtf((float)p.Cout);
+                f32x4 g4 = cvalid ? *reinterpret_cast<const f32x4*>(p.g + cg) * sqrtc : zero4;
+                float ssv[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    float ss = v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+                    ss += dpp_f<0xB1>(ss);
+                    ss += dpp_f<0x4E>(ss);
+                    ss += dpp_f<0x141>(ss);
+                    ss += dpp_f<0x140>(ss);  // all 16 lanes of the pixel hold the sum over this wave's 64 couts
+                    ssv[j] = ss;
+                }
+                if constexpr (WN > 1) {
+                    // the pixel's couts are spread over WN waves: exchange the partial sums through LDS
+                    float* red = smem + g.ptab_off + 64 * WM;  // [WN][64*WM]
+                    if ((lane & 15) == 0) {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) red[wn * (64 * WM) + wm * 64 + 4 * j + rsub] = ssv[j];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int w = 0; w < WN; ++w) t += red[w * (64 * WM) + wm * 64 + 4 * j + rsub];
+                        ssv[j] = t;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = v[j] * (fast_rsq(fmaxf(ssv[j], 1e-24f))) * g4;
+            }
+            if (epi & EPI_SCALE_SHIFT) {
+                const int HoWo = p.Ho * p.Wo;
+                const bool uni = g.NB == 1 || p.ss_stride == 0;
+                f32x4 sc = make_f32x4(1.f, 1.f, 1.f, 1.f), sh = zero4;
+                if (uni && cvalid) {
+                    const float* sp = p.scale + (size_t)min(b0, p.B - 1) * p.ss_stride;
+                    sc = *reinterpret_cast<const f32x4*>(sp + cg) + 1.0f;
+                    sh = *reinterpret_cast<const f32x4*>(sp + p.Cout + cg);
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (!uni && cvalid && pixv[j] >= 0) {
+                        const float* sp = p.scale + (size_t)(pixv[j] / HoWo) * p.ss_stride;
+                        sc = *reinterpret_cast<const f32x4*>(sp + cg) + 1.0f;
+                        sh = *reinterpret_cast<const f32x4*>(sp + p.Cout + cg);
+                    }
+                    v[j] = v[j] * sc + sh;
+                }
+            }
+            if (epi & EPI_SILU) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    v[j].x = v[j].x * fast_rcp(1.0f + __expf(-v[j].x));
+                    v[j].y = v[j].y * fast_rcp(1.0f + __expf(-v[j].y));
+                    v[j].z = v[j].z * fast_rcp(1.0f + __expf(-v[j].z));
+                    v[j].w = v[j].w * fast_rcp(1.0f + __expf(-v[j].w));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (pixv[j] < 0 || !cvalid) continue;
+                const size_t o = (size_t)pixv[j] * p.Cout + cg;
+                f32x4 r4 = v[j];
+                if (epi & EPI_RESIDUAL) r4 += *reinterpret_cast<const f32x4*>(p.residual + o);
+                *reinterpret_cast<f32x4*>(p.out + o) = r4;
+            }
+            DM_STAMP_ADD(6)
+            DM_STAMP_FLUSH
+            return;
+        }
+    }
+
     int co[2];
     bool cok[2];
 #pragma unroll
@@ -809,7 +927,11 @@ int conv_launch(const ConvParams& pin, hipStream_t s) {
     DM_REQUIRE(p.KW % g.TPS == 0, "conv: taps per slab must divide KW");
     if (CK == 16) DM_REQUIRE(p.C0 % 4 == 0 && p.C1 % 4 == 0, "conv: CK16 needs C % 4 == 0");
     int red_floats = (p.epi & EPI_NORM) && g.WN > 1 ? g.WN * g.WM * 64 : 0;
-    g.lds_bytes = std::max(g.halo_floats + 2 * g.w_floats + 64 * g.WM /* ptab */, red_floats) * 4;
+    // the pixel table sits behind the staging buffers and behind the 4 x [64][68] transposed tiles of the
+    // row-layout epilogue (WN == 1), which reuse the staging space after the last barrier
+    g.ptab_off = std::max(g.halo_floats + 2 * g.w_floats, 4 * 64 * 68);
+    // [ staging | 4 transposed tiles ] [ pixel table: 64*WM ] [ cross-wave norm partials: WN * 64*WM = 256 ]
+    g.lds_bytes = std::max(g.ptab_off + 64 * g.WM + 256, red_floats) * 4;
     DM_REQUIRE(g.lds_bytes <= 160 * 1024, "conv: tile does not fit LDS");
     if (CK == 16) {
         if (g.WN == 1) return launch_one<4, 1, 16>(p, s);

@@ -53,6 +53,7 @@ struct ConvGeom {
     int IH, IW;          // staged input window per image
     int halo_floats;     // LDS floats for the activation window (multiple of 4)
     int w_floats;        // LDS floats of one weight slab buffer (two are allocated)
+    int ptab_off;        // LDS float offset of the output-pixel table (set by conv_launch)
     int TPS;             // taps (along kx) per weight slab: KW or 1
     int splits;          // K splits (blockIdx.y); > 1 writes partial sums
     int chunks_per_split;
