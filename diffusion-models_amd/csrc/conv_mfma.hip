@@ -149,7 +149,7 @@ static void fill_tile(ConvGeom& g, int B, int Ho, int Wo, int Cout, int KH, int 
 static int wgs_of(const ConvGeom& g) { return g.tiles_x * g.tiles_y * g.groups * g.n_tiles_n; }
 
 ConvGeom conv_plan(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, int C0, int C1, bool want_norm,
-                   bool allow_split) {
+                   bool allow_split, int grid_z) {
     static const int target_wgs = env_int("DM_CONV_TARGET_WGS", 512);
     static const int min_fused_wgs = env_int("DM_CONV_MIN_FUSED_WGS", 512);
     static const int force_tps = env_int("DM_CONV_TPS", 0);
@@ -166,7 +166,7 @@ ConvGeom conv_plan(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, 
         g.WN = Cout <= 64 ? 1 : (Cout <= 128 ? 2 : 4);
         g.WM = 4 / g.WN;
         fill_tile(g, B, Ho, Wo, Cout, KH, KW, stride);
-        if (wgs_of(g) >= min_fused_wgs) {
+        if (wgs_of(g) * grid_z >= min_fused_wgs) {
             chosen = true;
             g.fused_norm = 1;
         }
@@ -207,7 +207,7 @@ ConvGeom conv_plan(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, 
     // split-K over channel chunks when the grid would leave CUs idle
     g.splits = 1;
     if (!g.fused_norm && allow_split) {
-        int wgs = wgs_of(g);
+        int wgs = wgs_of(g) * grid_z;
         if (wgs < target_wgs && n_chunks >= 4) {
             int s = (target_wgs + wgs - 1) / wgs;
             s = std::min(s, std::min(max_splits, n_chunks / 2));
@@ -342,7 +342,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int tile_y = bid % g.tiles_y;
     const int group = bid / g.tiles_y;
     const int x0 = tile_x * g.TW, y0 = tile_y * g.TH, b0 = group * g.NB;
-    const int ix0 = x0 * p.stride - p.pad, iy0 = y0 * p.stride - p.pad;
+    // folded upsample conv: blockIdx.z picks the output parity, which fixes the (asymmetric) padding
+    const int par = p.fold ? blockIdx.z : 0;
+    const int par_y = par >> 1, par_x = par & 1;
+    const int pad_y = p.fold ? 1 - par_y : p.pad, pad_x = p.fold ? 1 - par_x : p.pad;
+    const int ix0 = x0 * p.stride - pad_x, iy0 = y0 * p.stride - pad_y;
     DM_STAMP_DECL
     DM_STAMP(0);
     __builtin_amdgcn_s_setprio(3);  // lowered to 0 only around the MFMA stream (see the slab loop)
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int spc = p.KH * kxg;           // slabs per chunk
     const int n_slabs = (ce - cb) * spc;
     const int CoutP = (p.Cout + 255) & ~255;  // packed rows are padded so every N tile reads in bounds
-    const float* __restrict__ wtile = p.w + (size_t)n_tile * NT * CK;
+    const float* __restrict__ wtile = p.w + (size_t)par * p.fold_w_stride + (size_t)n_tile * NT * CK;
 
     f32x4 wreg[WREGS];
     f32x4 hreg[HREGS];
@@ -442,7 +446,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         int ty = (tid >> g.lTW) & (g.TH - 1);
         int nb = tid >> (g.lTW + g.lTH);
         int b = b0 + nb, y = y0 + ty, x = x0 + tx;
-        ptab[tid] = (b < p.B && y < p.Ho && x < p.Wo) ? (b * p.Ho + y) * p.Wo + x : -1;
+        const bool ok = b < p.B && y < p.Ho && x < p.Wo;
+        ptab[tid] = !ok ? -1
+                        : (p.fold ? (b * 2 * p.Ho + 2 * y + par_y) * (2 * p.Wo) + 2 * x + par_x
+                                  : (b * p.Ho + y) * p.Wo + x);
     }
     // Input window of one channel chunk -> registers -> LDS.  CK == 16 (NHWC, C % 16 == 0): branch-free --
     // padding pixels load pixel 0 and are zeroed by a select; the LDS region is padded to whole passes.
@@ -626,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                 pixv[j] = ptab[wm * 64 + 4 * j + rsub];
             }
             if (p.partial) {
-                const size_t M = (size_t)p.B * p.Ho * p.Wo;
+                const size_t M = (size_t)p.B * p.Ho * p.Wo * (p.fold ? 4 : 1);
                 float* po = p.out + (size_t)split * M * p.Cout + cg;
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
@@ -674,7 +681,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                 for (int j = 0; j < 16; ++j) v[j] = v[j] * (fast_rsq(fmaxf(ssv[j], 1e-24f))) * g4;
             }
             if (epi & EPI_SCALE_SHIFT) {
-                const int HoWo = p.Ho * p.Wo;
+                const int HoWo = p.Ho * p.Wo * (p.fold ? 4 : 1);
                 const bool uni = g.NB == 1 || p.ss_stride == 0;
                 f32x4 sc = make_f32x4(1.f, 1.f, 1.f, 1.f), sh = zero4;
                 if (uni && cvalid) {
@@ -725,7 +732,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 
     if (p.partial) {
         // raw partial sums of this K split: out[split][pixel][cout]
-        const size_t M = (size_t)p.B * p.Ho * p.Wo;
+        const size_t M = (size_t)p.B * p.Ho * p.Wo * (p.fold ? 4 : 1);
         float* po = p.out + (size_t)split * M * p.Cout;
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -816,7 +823,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                 sh[q] = sp[p.Cout + co[q]];
             }
     }
-    const int HoWo = p.Ho * p.Wo;
+    const int HoWo = p.Ho * p.Wo * (p.fold ? 4 : 1);
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -866,15 +873,17 @@ static int launch_one(const ConvParams& p, hipStream_t s) {
     if (timed) {
         // algorithmic work of this launch: 2*k*k*Cin*Cout*pixels FLOP;
         // read input once + write output once + weights once
-        const double pix = (double)p.B * p.Ho * p.Wo;
+        // (a folded upsample conv is priced as the reference's op: 9 taps at the output resolution)
+        const double pix = (double)p.B * p.Ho * p.Wo * (p.fold ? 4 : 1);
         const double cin = p.C0 + p.C1;
         const double in_pix = (double)p.B * (p.up ? (p.Hin / 2) * (p.Win / 2) : p.Hin * p.Win);
-        const double flops = 2.0 * p.KH * p.KW * cin * p.Cout * pix;
-        const double bytes = 4.0 * (cin * in_pix + p.Cout * pix + (double)p.KH * p.KW * cin * p.Cout);
+        const double taps = p.fold ? 9.0 : (double)p.KH * p.KW;
+        const double flops = 2.0 * taps * cin * p.Cout * pix;
+        const double bytes = 4.0 * (cin * in_pix + p.Cout * pix + taps * cin * p.Cout);
         char name[64];
         if (prof::detail())
             snprintf(name, sizeof(name), "conv<%d,%d,%d> %dx%d s%d %d+%d->%d @%dx%d%s e%d k%d t%d", WM, WN, CK, p.KH,
-                     p.KW, p.stride, p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.up ? " up" : "", p.epi, g.splits, g.TPS);
+                     p.KW, p.stride, p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.fold ? " upfold" : (p.up ? " up" : ""), p.epi, g.splits, g.TPS);
         else
             snprintf(name, sizeof(name), "conv_mfma_kernel<%d,%d,%d>", WM, WN, CK);
         if (prof::begin(name, flops, bytes, s)) return 1;
@@ -888,7 +897,7 @@ static int launch_one(const ConvParams& p, hipStream_t s) {
         DM_CHECK_HIP(hipMemsetAsync(dbuf, 0, nblk * 8 * sizeof(unsigned long long), s));
         ConvParams ps = p;
         ps.stamps = dbuf;
-        hipLaunchKernelGGL(kern, dim3(blocks, g.splits), dim3(256), g.lds_bytes, s, ps);
+        hipLaunchKernelGGL(kern, dim3(blocks, g.splits, p.fold ? 4 : 1), dim3(256), g.lds_bytes, s, ps);
         DM_CHECK_HIP(hipStreamSynchronize(s));
         std::vector<unsigned long long> h(nblk * 8);
         DM_CHECK_HIP(hipMemcpy(h.data(), dbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -906,7 +915,7 @@ static int launch_one(const ConvParams& p, hipStream_t s) {
         return 0;
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3(blocks, g.splits), dim3(256), g.lds_bytes, s, p);
+    hipLaunchKernelGGL(kern, dim3(blocks, g.splits, p.fold ? 4 : 1), dim3(256), g.lds_bytes, s, p);
     DM_CHECK_HIP(hipGetLastError());
     if (timed && prof::end(s)) return 1;
     return 0;

@@ -6,6 +6,7 @@
 #include "dm_common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -103,7 +104,9 @@ struct Arena {
 
 struct ConvLayer {
     int C0 = 0, C1 = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0;
-    bool up = false;
+    bool up = false;    // nearest x2 in front of the conv (Upsample, DD/denoising_diffusion.py:48-52)
+    bool fold = false;  // ... executed as four 2x2 parity convs on the source grid (ConvParams::fold)
+    int fold_w_stride = 0;
     float* w = nullptr;
     float* bias = nullptr;
 };
@@ -226,8 +229,40 @@ static std::string idx(const std::string& a, int i) { return a + "." + std::to_s
 static int make_conv(DeviceOwner& own, ConvLayer& L, const float* oihw, const float* bias, int Cout, int C0, int C1, int KH,
                      int KW, int stride, int pad, bool up) {
     L.C0 = C0; L.C1 = C1; L.Cout = Cout; L.KH = KH; L.KW = KW; L.stride = stride; L.pad = pad; L.up = up;
-    std::vector<float> packed(conv_packed_floats(Cout, C0, C1, KH, KW));
-    conv_pack_weights(oihw, packed.data(), Cout, C0, C1, KH, KW);
+    static const bool no_fold = std::getenv("DM_NO_UPFOLD") != nullptr;
+    L.fold = up && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !no_fold;
+    std::vector<float> packed;
+    if (L.fold) {
+        // nearest x2 then conv3x3 == one 2x2 conv per output parity with summed taps:
+        //   parity 0 along an axis: source offsets {-1, 0} <- taps {0}, {1,2};  parity 1: {0, +1} <- taps {0,1}, {2}
+        const int Cin = C0 + C1;
+        const size_t per = conv_packed_floats(Cout, C0, C1, 2, 2);
+        packed.resize(4 * per);
+        std::vector<float> w2((size_t)Cout * Cin * 4);
+        auto taps = [](int parity, int a, int* lo, int* hi) {
+            if (parity == 0) { *lo = a == 0 ? 0 : 1; *hi = a == 0 ? 0 : 2; }
+            else             { *lo = a == 0 ? 0 : 2; *hi = a == 0 ? 1 : 2; }
+        };
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                for (size_t oc = 0; oc < (size_t)Cout * Cin; ++oc)
+                    for (int a = 0; a < 2; ++a)
+                        for (int b = 0; b < 2; ++b) {
+                            int y0, y1, x0, x1;
+                            taps(py, a, &y0, &y1);
+                            taps(px, b, &x0, &x1);
+                            float sacc = 0.f;
+                            for (int dy = y0; dy <= y1; ++dy)
+                                for (int dx = x0; dx <= x1; ++dx) sacc += oihw[oc * 9 + dy * 3 + dx];
+                            w2[oc * 4 + a * 2 + b] = sacc;
+                        }
+                conv_pack_weights(w2.data(), packed.data() + (size_t)(py * 2 + px) * per, Cout, C0, C1, 2, 2);
+            }
+        L.fold_w_stride = (int)per;
+    } else {
+        packed.resize(conv_packed_floats(Cout, C0, C1, KH, KW));
+        conv_pack_weights(oihw, packed.data(), Cout, C0, C1, KH, KW);
+    }
     if (own.upload(packed.data(), packed.size(), &L.w)) return 1;
     L.bias = nullptr;
     if (bias && own.upload(bias, Cout, &L.bias)) return 1;
@@ -315,16 +350,33 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
     const int CK = conv_ck_for(L.C0, L.C1);
     p.chunks0 = (L.C0 + CK - 1) / CK;
     p.n_chunks = p.chunks0 + (L.C1 ? (L.C1 + CK - 1) / CK : 0);
-    p.Hin = Hin; p.Win = Win; p.up = L.up ? 1 : 0; p.in_nchw = in_nchw ? 1 : 0;
+    p.in_nchw = in_nchw ? 1 : 0;
     p.w = L.w; p.bias = L.bias;
-    p.Cout = L.Cout; p.KH = L.KH; p.KW = L.KW; p.stride = L.stride; p.pad = L.pad;
+    p.Cout = L.Cout; p.stride = L.stride; p.pad = L.pad;
     p.B = c.B;
-    p.Ho = (Hin + 2 * L.pad - L.KH) / L.stride + 1;
-    p.Wo = (Win + 2 * L.pad - L.KW) / L.stride + 1;
     p.out_nchw = out_nchw ? 1 : 0;
     p.residual = residual; p.g = g; p.scale = scale; p.ss_stride = c.ss_stride;
     const bool want_norm = (epi & EPI_NORM) != 0;
-    p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, L.KH, L.KW, L.stride, L.C0, L.C1, want_norm && !out_nchw, !out_nchw);
+    int out_h, out_w;  // dims of the output tensor
+    if (L.fold) {
+        // (Hin, Win) is the upsampled size the caller sees; the four parity convs run on the source grid
+        DM_REQUIRE(!out_nchw && !in_nchw, "folded upsample conv is NHWC");
+        p.fold = 1; p.fold_w_stride = L.fold_w_stride; p.up = 0;
+        p.KH = 2; p.KW = 2;
+        p.Hin = Hin / 2; p.Win = Win / 2;
+        p.Ho = p.Hin; p.Wo = p.Win;
+        out_h = Hin; out_w = Win;
+        p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, 2, 2, 1, L.C0, L.C1, want_norm, true, 4);
+    } else {
+        p.fold = 0; p.fold_w_stride = 0; p.up = L.up ? 1 : 0;
+        p.KH = L.KH; p.KW = L.KW;
+        p.Hin = Hin; p.Win = Win;
+        p.Ho = (Hin + 2 * L.pad - L.KH) / L.stride + 1;
+        p.Wo = (Win + 2 * L.pad - L.KW) / L.stride + 1;
+        out_h = p.Ho; out_w = p.Wo;
+        p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, L.KH, L.KW, L.stride, L.C0, L.C1, want_norm && !out_nchw,
+                          !out_nchw);
+    }
     const int full_epi = epi | (L.bias ? EPI_BIAS : 0);
     const bool in_kernel = p.geo.splits == 1 && (!want_norm || p.geo.fused_norm);
     if (in_kernel) {
@@ -333,12 +385,12 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
         return conv_launch(p, c.s);
     }
     DM_REQUIRE(!out_nchw, "split / unfused epilogue writes NHWC");
-    const size_t M = (size_t)c.B * p.Ho * p.Wo;
+    const size_t M = (size_t)c.B * out_h * out_w;
     float* part = c.A->alloc((size_t)p.geo.splits * M * L.Cout);
     if (c.dry()) return 0;
     p.out = part; p.partial = 1; p.epi = 0;
     if (conv_launch(p, c.s)) return 1;
-    return launch_norm_act(part, p.geo.splits, (int64_t)(M * L.Cout), L.bias, g, scale, c.ss_stride, p.Ho * p.Wo,
+    return launch_norm_act(part, p.geo.splits, (int64_t)(M * L.Cout), L.bias, g, scale, c.ss_stride, out_h * out_w,
                            residual, out, (int64_t)M, L.Cout, full_epi, c.s);
 }
 

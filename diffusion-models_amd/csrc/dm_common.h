@@ -77,6 +77,12 @@ struct ConvParams {
     float* out;
     int out_nchw;
     int partial;         // out is [splits][pixel][Cout] raw partial sums, no epilogue
+    // Nearest-x2 + conv3x3 folded into four 2x2 convolutions on the SOURCE grid, one per output parity
+    // (blockIdx.z = py*2+px): out[2i+py][2j+px] = sum_{a,b<2} W'[py][px][a][b] * src[i+a-(1-py)][j+b-(1-px)],
+    // W' = sums of the 3x3 taps that hit the same source pixel.  4/9 of the multiply-adds.  Ho/Wo are the
+    // source-grid dims; the output tensor is (2Ho, 2Wo).
+    int fold;
+    int fold_w_stride;   // floats between the four packed weight sets
     unsigned long long* stamps;  // diagnostic build (-DDM_STAMPS) only: per-workgroup phase cycle sums
     int epi;
     const float* residual;   // NHWC [pixel][Cout]
@@ -89,7 +95,7 @@ struct ConvParams {
 // choose wave grid, tile, weight-slab size and K splits for an output of (B, Ho, Wo, Cout);
 // want_norm: the caller would like RMSNorm fused (granted when plan.fused_norm != 0)
 ConvGeom conv_plan(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, int C0, int C1, bool want_norm,
-                   bool allow_split);
+                   bool allow_split, int grid_z = 1);
 int conv_ck_for(int C0, int C1);
 // floats needed for packed weights
 size_t conv_packed_floats(int Cout, int C0, int C1, int KH, int KW);
