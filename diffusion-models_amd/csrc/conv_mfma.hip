@@ -311,7 +311,7 @@ __device__ __forceinline__ f32x4 load_window_px(const ConvParams& p, int pix, in
     return v;
 }
 
-template <int WM, int WN, int CK>
+template <int WM, int WN, int CK, int TPSC>  // TPSC: taps per weight slab at compile time (0 = run time)
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     constexpr int NT = WN * 64;
     constexpr int CKP = (CK == 4) ? 4 : CK + 4;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 
     const int halo_items = g.NB * g.IH * g.IW * QPP;
     const bool halo_in_regs = halo_items <= 256 * HREGS;
-    const int TPS = g.TPS;
+    const int TPS = TPSC ? TPSC : g.TPS;
     const int w_items = TPS * NT * QPP;
     const int kxg = p.KW / TPS;           // tap groups per kernel row
     const int spc = p.KH * kxg;           // slabs per chunk
@@ -515,6 +515,94 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 
     // slab counters (chunk, ky, tap group) advance incrementally: no integer division in the loop
     int chunk = cb, ky = 0, kgi = 0;
+    if constexpr (CK == 16 && TPSC > 0) {
+        // ---- main loop, taps per slab known at compile time: the staging work of the NEXT slab is issued from
+        // hooks BETWEEN the MFMAs of this slab (one small piece per MFMA, order pinned by sched_barrier), so it
+        // runs in the shadow of the 64-cycle matrix instructions instead of forming a phase of its own.  Stamps
+        // showed that phase at ~3.4k cycles per 6.1k-cycle slab before.
+        constexpr int E = 4, UPT = 2, NU = TPSC * UPT, NM = NU * E * 4;  // MFMAs per slab per wave
+        constexpr int NW = TPSC * WN;                                      // weight items per thread and slab
+        constexpr int H0 = NW + 2;                                         // first MFMA slot of the window loads
+        static_assert(H0 + HREGS <= NM - NW, "staging hooks do not fit into one slab");
+        for (int slab = 0; slab < n_slabs; ++slab) {
+            const bool has_next = slab + 1 < n_slabs;
+            int nchunk = chunk, nky = ky, nkgi = kgi + 1;
+            if (nkgi == kxg) {
+                nkgi = 0;
+                if (++nky == p.KH) {
+                    nky = 0;
+                    ++nchunk;
+                }
+            }
+            const bool chunk_ends = has_next && nchunk != chunk;
+            const bool ld_h = chunk_ends && halo_in_regs;
+            // uniform bases for the hooks (at the last slab the weight loads re-read a valid slab; never stored)
+            const int lchunk = has_next ? nchunk : chunk, lky = has_next ? nky : ky, lkg = has_next ? nkgi : kgi;
+            const float* __restrict__ wsrc =
+                wtile + ((((size_t)lchunk * p.KH + lky) * p.KW + lkg * TPSC) * (size_t)CoutP) * CK + tid * 4;
+            const bool hs1 = nchunk >= p.chunks0;
+            const float* __restrict__ hsrc =
+                (hs1 ? p.in1 : p.in0) + (hs1 ? nchunk - p.chunks0 : nchunk) * CK + (tid & 3) * 4;
+            const int hCs = hs1 ? p.C1 : p.C0;
+            float* wdst = ((slab & 1) ? wbuf0 : wbuf1) + (tid >> 2) * CKP + (tid & 3) * 4;
+            const float* wb = (slab & 1) ? wbuf1 : wbuf0;
+            const int a_row = (ky * g.IW + kgi * TPSC) * CKP;
+            DM_STAMP_ADD(1)
+            MicroFrag<E> fa[2][2], fb[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) fa[0][r].load(halo + a_base[r] + a_row);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) fb[0][q].load(wb + b_base[q]);
+            __builtin_amdgcn_s_setprio(0);  // the MFMA stream yields to the other wave's bookkeeping code
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if (u + 1 < NU) {
+                    const int t = (u + 1) / UPT, hh = (u + 1) % UPT;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) fa[(u + 1) & 1][r].load(halo + a_base[r] + a_row + t * CKP + hh * E);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) fb[(u + 1) & 1][q].load(wb + b_base[q] + t * NT * CKP + hh * E);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < E; ++s)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int m = ((u * E + s) * 2 + r) * 2 + q;  // index of this MFMA within the slab
+                            acc[r][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u & 1][r].v[s], fb[u & 1][q].v[s],
+                                                                             acc[r][q], 0, 0, 0);
+                            if (m < NW) {  // next slab's weights: one 16-byte load per hook
+                                wreg[m] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)(m / WN) * CoutP * CK +
+                                                                          (m % WN) * 1024);
+                            } else if (m >= H0 && m < H0 + HREGS) {  // next chunk's input window
+                                if (ld_h && m - H0 < n_h)
+                                    hreg[m - H0] = *reinterpret_cast<const f32x4*>(
+                                        hsrc + (size_t)max(hpix[m - H0], 0) * hCs);
+                            }
+                            if (m >= NM - NW) {  // weights -> the other LDS buffer (free since the last barrier)
+                                if (has_next) *reinterpret_cast<f32x4*>(wdst + (m - (NM - NW)) * 64 * CKP) = wreg[m - (NM - NW)];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+            }
+            __builtin_amdgcn_s_setprio(3);
+            DM_STAMP_ADD(2)
+            DM_STAMP_ADD(3)
+            __syncthreads();  // slab done everywhere: its weight buffer and (at a chunk end) the window are free
+            DM_STAMP_ADD(4)
+            if (chunk_ends) {
+                if (halo_in_regs) store_h();
+                else stage_h_direct(nchunk);
+                __syncthreads();
+            }
+            DM_STAMP_ADD(5)
+            chunk = nchunk;
+            ky = nky;
+            kgi = nkgi;
+        }
+    } else
     for (int slab = 0; slab < n_slabs; ++slab) {
         const bool has_next = slab + 1 < n_slabs;
         int nchunk = chunk, nky = ky, nkgi = kgi + 1;
@@ -857,10 +945,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     DM_STAMP_FLUSH
 }
 
-template <int WM, int WN, int CK>
+template <int WM, int WN, int CK, int TPSC>  // TPSC: taps per weight slab at compile time (0 = run time)
 static int launch_one(const ConvParams& p, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv_mfma_kernel<WM, WN, CK>;
+    auto kern = conv_mfma_kernel<WM, WN, CK, TPSC>;
     if (!attr_set) {
         DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -943,13 +1031,22 @@ int conv_launch(const ConvParams& pin, hipStream_t s) {
     g.lds_bytes = std::max(g.ptab_off + 64 * g.WM + 256, red_floats) * 4;
     DM_REQUIRE(g.lds_bytes <= 160 * 1024, "conv: tile does not fit LDS");
     if (CK == 16) {
-        if (g.WN == 1) return launch_one<4, 1, 16>(p, s);
-        if (g.WN == 2) return launch_one<2, 2, 16>(p, s);
-        return launch_one<1, 4, 16>(p, s);
+        // taps per slab is a template parameter on this path (hooked main loop)
+#define DM_CONV_DISPATCH(WM_, WN_)                                      \
+    switch (g.TPS) {                                                    \
+        case 1: return launch_one<WM_, WN_, 16, 1>(p, s);               \
+        case 2: return launch_one<WM_, WN_, 16, 2>(p, s);               \
+        case 3: return launch_one<WM_, WN_, 16, 3>(p, s);               \
+        default: return launch_one<WM_, WN_, 16, 0>(p, s);              \
+    }
+        if (g.WN == 1) { DM_CONV_DISPATCH(4, 1) }
+        if (g.WN == 2) { DM_CONV_DISPATCH(2, 2) }
+        DM_CONV_DISPATCH(1, 4)
+#undef DM_CONV_DISPATCH
     } else {
-        if (g.WN == 1) return launch_one<4, 1, 4>(p, s);
-        if (g.WN == 2) return launch_one<2, 2, 4>(p, s);
-        return launch_one<1, 4, 4>(p, s);
+        if (g.WN == 1) return launch_one<4, 1, 4, 0>(p, s);
+        if (g.WN == 2) return launch_one<2, 2, 4, 0>(p, s);
+        return launch_one<1, 4, 4, 0>(p, s);
     }
 }
 
