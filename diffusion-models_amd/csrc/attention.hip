@@ -8,6 +8,8 @@
 // qkv tensors are NHWC, i.e. one row of 3*heads*32 floats per token: [q(h,d) | k(h,d) | v(h,d)].
 #include "dm_common.h"
 
+#include <cstdlib>
+
 namespace dm {
 
 constexpr int DH = 32;
@@ -24,7 +26,104 @@ __device__ __forceinline__ float wave_sum64(float v) {
 }
 
 // ---------------------------------------------------------------------------------------
-// LinearAttention, part 1: ctx[b][h][d][e] = sum_n softmax_n(k)[d][n] * v[e][n]  (n includes 4 memory tokens)
+// LinearAttention, part 1 on the f32 MFMA: ctx[d][e] = sum_t softmax_t(k)[d][t] * v[e][t] is a (32 x n) x (n x 32)
+// product per (image, head), with the tokens as the reduction axis:
+//   A[i = d][k = token] = exp(k[token][d] - max_d),  B[k = token][j = e] = v[token][e]
+// so a lane loads ONE dword of k and ONE of v per step (lanes 0-31 / 32-63 read the 128 contiguous bytes of
+// two consecutive tokens) and the 32x32 context accumulates in 16 registers.  grid (heads, B), 4 waves; each
+// wave takes a quarter of the tokens, the partial contexts meet in LDS.  The 4 memory tokens are two extra steps.
+// ---------------------------------------------------------------------------------------
+using f32x16_t = __attribute__((ext_vector_type(16))) float;
+
+__global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(const float* __restrict__ qkv,
+                                                               const float* __restrict__ mem_kv,
+                                                               float* __restrict__ ctx, int n, int heads) {
+    constexpr int NMEM = 4;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, half = lane >> 5;
+    const int ld = 3 * heads * DH;
+    const float* kb = qkv + (size_t)b * n * ld + heads * DH + h * DH + c;
+    const float* vb = qkv + (size_t)b * n * ld + 2 * heads * DH + h * DH + c;
+    const float* mk = mem_kv + (size_t)h * DH * NMEM;            // [d][j]
+    const float* mv = mem_kv + (size_t)(heads + h) * DH * NMEM;  // [e][j]
+    __shared__ float red[4][DH];
+    __shared__ float kmax_s[DH], ksum_s[DH];
+    __shared__ __attribute__((aligned(16))) float part[4][DH * DH];
+
+    // tokens of this wave: [t0, t1), visited two at a time (one per lane half)
+    const int per = ((n + 7) / 8) * 2;  // even number of tokens per wave
+    const int t0 = wave * per, t1 = min(n, t0 + per);
+
+    // pass 1: max over all tokens (incl. memory) of k[.][d]
+    float m = -INFINITY;
+    for (int t = t0 + half; t < t1; t += 2) m = fmaxf(m, kb[(size_t)t * ld]);
+    if (wave == 0) {
+        m = fmaxf(m, mk[c * NMEM + half]);
+        m = fmaxf(m, mk[c * NMEM + 2 + half]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    if (half == 0) red[wave][c] = m;
+    __syncthreads();
+    if (tid < DH) kmax_s[tid] = fmaxf(fmaxf(red[0][tid], red[1][tid]), fmaxf(red[2][tid], red[3][tid]));
+    __syncthreads();
+    const float kmax = kmax_s[c];
+
+    // pass 2: exp, row sums, and the outer-product accumulation on the matrix core
+    f32x16_t acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float ksum = 0.f;
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < NMEM; j += 2) {
+            float a = __expf(mk[c * NMEM + j + half] - kmax);
+            float bv = mv[c * NMEM + j + half];
+            ksum += a;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+        }
+    }
+    int t = t0;
+    for (; t + 8 <= t1; t += 8) {  // 4 steps per iteration: 8 loads in flight per lane
+        float kv[4], vv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kv[s] = kb[(size_t)(t + 2 * s + half) * ld];
+            vv[s] = vb[(size_t)(t + 2 * s + half) * ld];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float a = __expf(kv[s] - kmax);
+            ksum += a;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, vv[s], acc, 0, 0, 0);
+        }
+    }
+    for (; t < t1; t += 2) {  // tail: a missing token contributes a = 0
+        const bool ok = t + half < t1;
+        float a = ok ? __expf(kb[(size_t)(t + half) * ld] - kmax) : 0.f;
+        float bv = ok ? vb[(size_t)(t + half) * ld] : 0.f;
+        ksum += a;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+    }
+    ksum += __shfl_xor(ksum, 32);
+    __syncthreads();  // red is reused
+    if (half == 0) red[wave][c] = ksum;
+    // accumulator element e of lane: row d = (e&3) + 8*(e>>2) + 4*half, column e-index = lane&31
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part[wave][((e & 3) + 8 * (e >> 2) + 4 * half) * DH + c] = acc[e];
+    __syncthreads();
+    if (tid < DH) ksum_s[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    __syncthreads();
+    float* cp = ctx + (size_t)(b * heads + h) * DH * DH;
+    for (int i = tid; i < DH * DH; i += 256) {
+        const int d = i >> 5;
+        cp[i] = (part[0][i] + part[1][i] + part[2][i] + part[3][i]) / ksum_s[d];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// LinearAttention, part 1 (VALU version, kept as the fallback for n_mem != 4):
+// ctx[b][h][d][e] = sum_n softmax_n(k)[d][n] * v[e][n]  (n includes the memory tokens)
 // grid (heads, B), 256 threads.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restrict__ qkv,
@@ -160,7 +259,11 @@ int launch_linear_attention_core(const float* qkv, const float* mem_kv, float* c
                                  int heads, int dh, hipStream_t s) {
     DM_REQUIRE(dh == DH, "LinearAttention kernel is specialised for dim_head == 32");
     DM_REQUIRE(heads >= 1 && heads <= 16, "LinearAttention kernel supports 1..16 heads");
-    hipLaunchKernelGGL(linattn_ctx_kernel, dim3(heads, B), dim3(256), 0, s, qkv, mem_kv, ctx_ws, n, heads, 4);
+    static const bool valu_ctx = std::getenv("DM_LINATTN_VALU") != nullptr;
+    if (valu_ctx)
+        hipLaunchKernelGGL(linattn_ctx_kernel, dim3(heads, B), dim3(256), 0, s, qkv, mem_kv, ctx_ws, n, heads, 4);
+    else
+        hipLaunchKernelGGL(linattn_ctx_mfma_kernel, dim3(heads, B), dim3(256), 0, s, qkv, mem_kv, ctx_ws, n, heads);
     DM_CHECK_HIP(hipGetLastError());
     size_t lds = (size_t)heads * DH * DH * sizeof(float);
     hipLaunchKernelGGL(linattn_out_kernel, dim3((n + 63) / 64, B), dim3(64 * heads), lds, s, qkv, ctx_ws, out, n,

@@ -110,9 +110,81 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const float* __restrict__
         for (int c = lane; c < C; c += 64) finish(c, value(c));
     }
 }
+// 16-byte version for C = 4*L*NV: a row occupies L lanes (NV float4 each), 64/L rows per wavefront, so a
+// 64-channel row no longer costs a whole wave one dword per lane.  Same arithmetic as norm_act_kernel.
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+template <int L, int NV>
+__global__ __launch_bounds__(256) void norm_act_vec_kernel(const float* __restrict__ x, int nsplit,
+                                                           int64_t split_stride, const float* __restrict__ bias,
+                                                           const float* __restrict__ g,
+                                                           const float* __restrict__ scale, int ss_stride,
+                                                           int pix_per_image, const float* __restrict__ residual,
+                                                           float* __restrict__ y, int64_t rows, int flags) {
+    constexpr int C = 4 * L * NV;
+    constexpr int RPW = 64 / L;  // rows per wavefront
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / L, li = lane % L;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + sub;
+    const bool ok = row < rows;
+    const int64_t rrow = ok ? row : rows - 1;  // keep every lane in the shuffles
+    f32x4v v[NV];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (li + L * i) * 4;
+        const float* xp = x + rrow * C + c;
+        v[i] = *reinterpret_cast<const f32x4v*>(xp);
+        for (int sp = 1; sp < nsplit; ++sp) v[i] += *reinterpret_cast<const f32x4v*>(xp + (size_t)sp * split_stride);
+        if (flags & EPI_BIAS) v[i] += *reinterpret_cast<const f32x4v*>(bias + c);
+        ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+    float rn = 1.0f;
+    if (flags & EPI_NORM) {
+#pragma unroll
+        for (int m = L / 2; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+        rn = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
+    }
+    if (!ok) return;
+    const float* sp = nullptr;
+    if (flags & EPI_SCALE_SHIFT) sp = scale + (row / pix_per_image) * (int64_t)ss_stride;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (li + L * i) * 4;
+        f32x4v t = v[i];
+        if (flags & EPI_NORM) t = t * rn * *reinterpret_cast<const f32x4v*>(g + c);
+        if (flags & EPI_SCALE_SHIFT)
+            t = t * (*reinterpret_cast<const f32x4v*>(sp + c) + 1.0f) + *reinterpret_cast<const f32x4v*>(sp + C + c);
+        if (flags & EPI_SILU) {
+            t.x = silu_f(t.x);
+            t.y = silu_f(t.y);
+            t.z = silu_f(t.z);
+            t.w = silu_f(t.w);
+        }
+        if (flags & EPI_RESIDUAL) t += *reinterpret_cast<const f32x4v*>(residual + row * C + c);
+        *reinterpret_cast<f32x4v*>(y + row * C + c) = t;
+    }
+}
+
 int launch_norm_act(const float* x, int nsplit, int64_t split_stride, const float* bias, const float* g,
                     const float* scale, int ss_stride, int pix_per_image, const float* residual, float* y,
                     int64_t rows, int C, int flags, hipStream_t s) {
+#define DM_NORM_VEC(L_, NV_)                                                                                       \
+    {                                                                                                              \
+        const int64_t rpb = 4 * (64 / L_);                                                                         \
+        hipLaunchKernelGGL((norm_act_vec_kernel<L_, NV_>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, s, x, nsplit, \
+                           split_stride, bias, g, scale, ss_stride, pix_per_image, residual, y, rows, flags);     \
+        DM_CHECK_HIP(hipGetLastError());                                                                           \
+        return 0;                                                                                                  \
+    }
+    const bool aligned = (split_stride % 4 == 0) && (ss_stride % 4 == 0);
+    if (aligned) {
+        if (C == 64) DM_NORM_VEC(16, 1)
+        if (C == 128) DM_NORM_VEC(32, 1)
+        if (C == 256) DM_NORM_VEC(64, 1)
+        if (C == 384) DM_NORM_VEC(32, 3)
+        if (C == 512) DM_NORM_VEC(64, 2)
+    }
+#undef DM_NORM_VEC
     dim3 grid((rows + 3) / 4), block(256);
     if (C <= 128)
         hipLaunchKernelGGL(norm_act_kernel<2>, grid, block, 0, s, x, nsplit, split_stride, bias, g, scale, ss_stride,
