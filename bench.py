@@ -175,8 +175,20 @@ def main():
             tf = r["total_flops"] / (r["total_ms"] * 1e-3) / 1e12
             kern.append({"kernel": r["kernel"], "launches_per_unet_fwd": r["launches"] // 4,
                          "avg_ms": avg_ms, "tflops": tf, "frac_f32_peak": tf / PEAK_F32_TFLOPS,
+                         "algorithmic_bytes_per_launch": r["total_bytes"] / r["launches"],
                          "algorithmic_GBps": r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e9})
         top = kern[0]
+        # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # separate runs, FETCH_SIZE doubled per the gfx950 correction); collected offline, see profiles/
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")) as f:
+                pmc = {k.replace(" ", ""): v for k, v in json.load(f).items()}
+            t = pmc.get(top["kernel"].replace(" ", ""))
+            if t:
+                traffic = t["fetch_bytes_per_launch_corrected"] + t["write_bytes_per_launch"]
+        except OSError:
+            pass
         result["roofline"] = {
             "bound": "mfma",
             "kernel": top["kernel"],
@@ -184,9 +196,12 @@ def main():
             "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s",
             "frac": top["tflops"] / PEAK_F32_TFLOPS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (PMC, offline pass)",
+            "algorithmic_bytes_per_launch": top["algorithmic_bytes_per_launch"],
             "avg_launch_ms": top["avg_ms"],
-            "note": "f32-input MFMA peak == f32 vector peak; algorithmic FLOPs 2*k*k*Cin*Cout*pixels per launch",
+            "note": "f32-input MFMA peak == f32 vector peak; algorithmic FLOPs 2*k*k*Cin*Cout*pixels per launch "
+                    "(an upsample conv is priced as the reference's 9-tap op although it executes 4/9 of it)",
         }
         result["kernels"] = kern
         conv_ms = sum(r["total_ms"] for r in rows) / 4

@@ -973,7 +973,7 @@ static int launch_one(const ConvParams& p, hipStream_t s) {
             snprintf(name, sizeof(name), "conv<%d,%d,%d> %dx%d s%d %d+%d->%d @%dx%d%s e%d k%d t%d", WM, WN, CK, p.KH,
                      p.KW, p.stride, p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.fold ? " upfold" : (p.up ? " up" : ""), p.epi, g.splits, g.TPS);
         else
-            snprintf(name, sizeof(name), "conv_mfma_kernel<%d,%d,%d>", WM, WN, CK);
+            snprintf(name, sizeof(name), "conv_mfma_kernel<%d,%d,%d,%d>", WM, WN, CK, TPSC);
         if (prof::begin(name, flops, bytes, s)) return 1;
     }
 #ifdef DM_STAMPS
