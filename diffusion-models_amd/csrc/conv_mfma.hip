@@ -524,26 +524,26 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         constexpr int NW = TPSC * WN;                                      // weight items per thread and slab
         constexpr int H0 = NW + 2;                                         // first MFMA slot of the window loads
         static_assert(H0 + HREGS <= NM - NW, "staging hooks do not fit into one slab");
+        // Consecutive slabs are consecutive in the packed weights ([chunk][ky][kx] order), so the source of the
+        // next slab is one pointer bump; the window source changes only when the chunk does.
+        const size_t slab_stride = (size_t)TPSC * CoutP * CK;
+        const float* __restrict__ wnext = wtile + ((size_t)cb * spc + 1) * slab_stride + tid * 4;
+        int sic = 0;  // slab index inside the chunk
+        const float* __restrict__ hsrc = nullptr;
+        int hCs = 0;
+        auto window_source = [&](int nc) {
+            const bool hs1 = nc >= p.chunks0;
+            hsrc = (hs1 ? p.in1 : p.in0) + (hs1 ? nc - p.chunks0 : nc) * CK + (tid & 3) * 4;
+            hCs = hs1 ? p.C1 : p.C0;
+        };
+        window_source(cb + 1 < ce ? cb + 1 : cb);
         for (int slab = 0; slab < n_slabs; ++slab) {
             const bool has_next = slab + 1 < n_slabs;
-            int nchunk = chunk, nky = ky, nkgi = kgi + 1;
-            if (nkgi == kxg) {
-                nkgi = 0;
-                if (++nky == p.KH) {
-                    nky = 0;
-                    ++nchunk;
-                }
-            }
-            const bool chunk_ends = has_next && nchunk != chunk;
+            const bool chunk_ends = has_next && sic == spc - 1;
+            const int nchunk = chunk_ends ? chunk + 1 : chunk;
             const bool ld_h = chunk_ends && halo_in_regs;
-            // uniform bases for the hooks (at the last slab the weight loads re-read a valid slab; never stored)
-            const int lchunk = has_next ? nchunk : chunk, lky = has_next ? nky : ky, lkg = has_next ? nkgi : kgi;
-            const float* __restrict__ wsrc =
-                wtile + ((((size_t)lchunk * p.KH + lky) * p.KW + lkg * TPSC) * (size_t)CoutP) * CK + tid * 4;
-            const bool hs1 = nchunk >= p.chunks0;
-            const float* __restrict__ hsrc =
-                (hs1 ? p.in1 : p.in0) + (hs1 ? nchunk - p.chunks0 : nchunk) * CK + (tid & 3) * 4;
-            const int hCs = hs1 ? p.C1 : p.C0;
+            // at the last slab the weight loads re-read the current slab (valid memory; never stored)
+            const float* __restrict__ wsrc = has_next ? wnext : wnext - slab_stride;
             float* wdst = ((slab & 1) ? wbuf0 : wbuf1) + (tid >> 2) * CKP + (tid & 3) * 4;
             const float* wb = (slab & 1) ? wbuf1 : wbuf0;
             const int a_row = (ky * g.IW + kgi * TPSC) * CKP;
@@ -598,9 +598,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                 __syncthreads();
             }
             DM_STAMP_ADD(5)
-            chunk = nchunk;
-            ky = nky;
-            kgi = nkgi;
+            wnext += slab_stride;
+            if (++kgi == kxg) {
+                kgi = 0;
+                ++ky;
+            }
+            if (++sic == spc) {
+                sic = 0;
+                ky = 0;
+                ++chunk;
+                window_source(chunk + 1 < ce ? chunk + 1 : chunk);
+            }
         }
     } else
     for (int slab = 0; slab < n_slabs; ++slab) {
