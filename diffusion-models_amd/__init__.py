@@ -16,6 +16,7 @@ from .unet import Unet  # noqa: F401
 from .diffusion import DenoisingDiffusion, LatentDiffusion, TextConditionalDenoisingDiffusion  # noqa: F401
 from .vae import VQDecoder  # noqa: F401
 from .dist import gather_shards, sample_sharded, shard_bounds  # noqa: F401
+from .checkpoint import load_trainer_checkpoint, load_vae_checkpoint  # noqa: F401
 
 __all__ = [
     "Unet",
