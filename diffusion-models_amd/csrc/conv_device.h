@@ -1,0 +1,138 @@
+// Device-side pieces shared by the convolution kernels (conv_mfma.hip, winograd_mfma.hip).
+#pragma once
+
+#include "dm_common.h"
+
+namespace dm {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+// 16-byte staging values are NATIVE vectors, not HIP's float4 struct: arrays of the struct are copied with
+// llvm.memcpy between address spaces, which keeps them in scratch memory (one synchronous round trip per
+// global load) instead of registers.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ f32x4 make_f32x4(float a, float b, float c, float d) { return f32x4{a, b, c, d}; }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ float half_wave_sum(float v) {
+    // sum over the 32 lanes that share lane>>5; every lane ends with the total.
+    // Four DPP steps inside each 16-lane row (they fuse into v_add_f32_dpp), one swizzle across the two rows.
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]  : lane ^ 1
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]  : lane ^ 2
+    v += dpp_f<0x141>(v);  // row_half_mirror      : pairs the two quads of each 8 lanes
+    v += dpp_f<0x140>(v);  // row_mirror           : pairs the two halves of the row
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // lane ^ 16
+    return v;
+}
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
+// Row-layout epilogue shared by the convolution kernels.  A wave holds 64 output pixels x 64 consecutive couts
+// as v[j] = the 4 couts [cg, cg+4) of pixel row 4*j + (lane>>4); the 16 lanes of a DPP row cover one pixel.
+// pixv[j] is the global output pixel of that row or -1.  Every global access is a 16-byte one, the RMSNorm
+// reduction stays inside a DPP row (plus one LDS exchange when the pixel's couts span WN waves: `red` is
+// [WN][rows_per_wg] floats and row_in_wg0 the index of this wave's first row in it -- all waves of the
+// workgroup must then call this function together).
+struct RowsEpilogue {
+    int split;        // K split index (partial sums go to out[split][pixel][cout])
+    size_t M;         // output pixels of the whole tensor
+    int b0;           // first image of the tile (scale/shift row when `uni`)
+    bool uni;         // one scale/shift row serves the whole tile
+    int HoWo;         // output pixels per image
+    float* red;
+    int rows_per_wg;
+    int row_in_wg0;
+    int wn;
+};
+
+template <int WN>
+__device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpilogue& e, f32x4 (&v)[16],
+                                              const int (&pixv)[16], int cg, bool cvalid) {
+    const int lane = threadIdx.x & 63;
+    const int rsub = lane >> 4;
+    if (p.partial) {
+        float* po = p.out + (size_t)e.split * e.M * p.Cout + cg;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (pixv[j] >= 0 && cvalid) *reinterpret_cast<f32x4*>(po + (size_t)pixv[j] * p.Cout) = v[j];
+        return;
+    }
+    const int epi = p.epi;
+    const f32x4 zero4 = make_f32x4(0.f, 0.f, 0.f, 0.f);
+    f32x4 b4 = zero4;
+    if ((epi & EPI_BIAS) && cvalid) b4 = *reinterpret_cast<const f32x4*>(p.bias + cg);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = cvalid ? v[j] + b4 : zero4;
+    if (epi & EPI_NORM) {
+        const float sqrtc = sqrtf((float)p.Cout);
+        f32x4 g4 = cvalid ? *reinterpret_cast<const f32x4*>(p.g + cg) * sqrtc : zero4;
+        float ssv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float ss = v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+            ss += dpp_f<0xB1>(ss);
+            ss += dpp_f<0x4E>(ss);
+            ss += dpp_f<0x141>(ss);
+            ss += dpp_f<0x140>(ss);  // all 16 lanes of the pixel hold the sum over this wave's 64 couts
+            ssv[j] = ss;
+        }
+        if constexpr (WN > 1) {
+            // the pixel's couts are spread over WN waves: exchange the partial sums through LDS
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) e.red[e.wn * e.rows_per_wg + e.row_in_wg0 + 4 * j + rsub] = ssv[j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) t += e.red[w * e.rows_per_wg + e.row_in_wg0 + 4 * j + rsub];
+                ssv[j] = t;
+            }
+        }
+        // 1 / max(||v||, 1e-12) as one v_rsq_f32 (1 ulp)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = v[j] * (fast_rsq(fmaxf(ssv[j], 1e-24f))) * g4;
+    }
+    if (epi & EPI_SCALE_SHIFT) {
+        f32x4 sc = make_f32x4(1.f, 1.f, 1.f, 1.f), sh = zero4;
+        if (e.uni && cvalid) {
+            const float* sp = p.scale + (size_t)min(e.b0, p.B - 1) * p.ss_stride;
+            sc = *reinterpret_cast<const f32x4*>(sp + cg) + 1.0f;
+            sh = *reinterpret_cast<const f32x4*>(sp + p.Cout + cg);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (!e.uni && cvalid && pixv[j] >= 0) {
+                const float* sp = p.scale + (size_t)(pixv[j] / e.HoWo) * p.ss_stride;
+                sc = *reinterpret_cast<const f32x4*>(sp + cg) + 1.0f;
+                sh = *reinterpret_cast<const f32x4*>(sp + p.Cout + cg);
+            }
+            v[j] = v[j] * sc + sh;
+        }
+    }
+    if (epi & EPI_SILU) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            v[j].x = v[j].x * fast_rcp(1.0f + __expf(-v[j].x));
+            v[j].y = v[j].y * fast_rcp(1.0f + __expf(-v[j].y));
+            v[j].z = v[j].z * fast_rcp(1.0f + __expf(-v[j].z));
+            v[j].w = v[j].w * fast_rcp(1.0f + __expf(-v[j].w));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (pixv[j] < 0 || !cvalid) continue;
+        const size_t o = (size_t)pixv[j] * p.Cout + cg;
+        f32x4 r4 = v[j];
+        if (epi & EPI_RESIDUAL) r4 += *reinterpret_cast<const f32x4*>(p.residual + o);
+        *reinterpret_cast<f32x4*>(p.out + o) = r4;
+    }
+}
+
+}  // namespace dm

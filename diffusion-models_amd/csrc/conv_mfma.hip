@@ -24,7 +24,7 @@
 // the matrix work of the same wave; one barrier per slab.
 // Split-K: blockIdx.y owns a contiguous range of channel chunks and writes raw partial sums; the
 // epilogue then runs in norm_act_kernel (elementwise.hip), which sums the partials.
-#include "dm_common.h"
+#include "conv_device.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -33,13 +33,6 @@
 #include <vector>
 
 namespace dm {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-// 16-byte staging values are NATIVE vectors, not HIP's float4 struct: arrays of the struct are copied with
-// llvm.memcpy between address spaces, which keeps them in scratch memory (one synchronous round trip per
-// global load) instead of registers.
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-__device__ __forceinline__ f32x4 make_f32x4(float a, float b, float c, float d) { return f32x4{a, b, c, d}; }
 
 // In-kernel cycle stamps: DIAGNOSTIC build only (make STAMPS=1 -> libdm_hip_stamps.so, tools/conv_stamps.py).
 // Wave 0 of every workgroup sums the s_memtime cycles it spends per phase into p.stamps[block][8]; nothing
@@ -239,25 +232,6 @@ struct MicroFrag {
         }
     }
 };
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-
-__device__ __forceinline__ float half_wave_sum(float v) {
-    // sum over the 32 lanes that share lane>>5; every lane ends with the total.
-    // Four DPP steps inside each 16-lane row (they fuse into v_add_f32_dpp), one swizzle across the two rows.
-    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]  : lane ^ 1
-    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]  : lane ^ 2
-    v += dpp_f<0x141>(v);  // row_half_mirror      : pairs the two quads of each 8 lanes
-    v += dpp_f<0x140>(v);  // row_mirror           : pairs the two halves of the row
-    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // lane ^ 16
-    return v;
-}
-
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
 // source pixel (b*Hs + sy)*Ws + sx behind window pixel hp of this tile, or -1 (padding / outside the batch).
 // Chunk independent, so a thread computes it once per kernel for the window items it stages.
@@ -728,90 +702,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                 v[j] = *reinterpret_cast<const f32x4*>(T + (4 * j + rsub) * TS + c4);
                 pixv[j] = ptab[wm * 64 + 4 * j + rsub];
             }
-            if (p.partial) {
-                const size_t M = (size_t)p.B * p.Ho * p.Wo * (p.fold ? 4 : 1);
-                float* po = p.out + (size_t)split * M * p.Cout + cg;
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    if (pixv[j] >= 0 && cvalid) *reinterpret_cast<f32x4*>(po + (size_t)pixv[j] * p.Cout) = v[j];
-                DM_STAMP_ADD(6)
-                DM_STAMP_FLUSH
-                return;
-            }
-            const int epi = p.epi;
-            const f32x4 zero4 = make_f32x4(0.f, 0.f, 0.f, 0.f);
-            f32x4 b4 = zero4;
-            if ((epi & EPI_BIAS) && cvalid) b4 = *reinterpret_cast<const f32x4*>(p.bias + cg);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = cvalid ? v[j] + b4 : zero4;
-            if (epi & EPI_NORM) {
-                const float sqrtc = sqrtf((float)p.Cout);
-                f32x4 g4 = cvalid ? *reinterpret_cast<const f32x4*>(p.g + cg) * sqrtc : zero4;
-                float ssv[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    float ss = v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
-                    ss += dpp_f<0xB1>(ss);
-                    ss += dpp_f<0x4E>(ss);
-                    ss += dpp_f<0x141>(ss);
-                    ss += dpp_f<0x140>(ss);  // all 16 lanes of the pixel hold the sum over this wave's 64 couts
-                    ssv[j] = ss;
-                }
-                if constexpr (WN > 1) {
-                    // the pixel's couts are spread over WN waves: exchange the partial sums through LDS
-                    float* red = smem + g.ptab_off + 64 * WM;  // [WN][64*WM]
-                    if ((lane & 15) == 0) {
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) red[wn * (64 * WM) + wm * 64 + 4 * j + rsub] = ssv[j];
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        float t = 0.f;
-#pragma unroll
-                        for (int w = 0; w < WN; ++w) t += red[w * (64 * WM) + wm * 64 + 4 * j + rsub];
-                        ssv[j] = t;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = v[j] * (fast_rsq(fmaxf(ssv[j], 1e-24f))) * g4;
-            }
-            if (epi & EPI_SCALE_SHIFT) {
-                const int HoWo = p.Ho * p.Wo * (p.fold ? 4 : 1);
-                const bool uni = g.NB == 1 || p.ss_stride == 0;
-                f32x4 sc = make_f32x4(1.f, 1.f, 1.f, 1.f), sh = zero4;
-                if (uni && cvalid) {
-                    const float* sp = p.scale + (size_t)min(b0, p.B - 1) * p.ss_stride;
-                    sc = *reinterpret_cast<const f32x4*>(sp + cg) + 1.0f;
-                    sh = *reinterpret_cast<const f32x4*>(sp + p.Cout + cg);
-                }
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    if (!uni && cvalid && pixv[j] >= 0) {
-                        const float* sp = p.scale + (size_t)(pixv[j] / HoWo) * p.ss_stride;
-                        sc = *reinterpret_cast<const f32x4*>(sp + cg) + 1.0f;
-                        sh = *reinterpret_cast<const f32x4*>(sp + p.Cout + cg);
-                    }
-                    v[j] = v[j] * sc + sh;
-                }
-            }
-            if (epi & EPI_SILU) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    v[j].x = v[j].x * fast_rcp(1.0f + __expf(-v[j].x));
-                    v[j].y = v[j].y * fast_rcp(1.0f + __expf(-v[j].y));
-                    v[j].z = v[j].z * fast_rcp(1.0f + __expf(-v[j].z));
-                    v[j].w = v[j].w * fast_rcp(1.0f + __expf(-v[j].w));
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (pixv[j] < 0 || !cvalid) continue;
-                const size_t o = (size_t)pixv[j] * p.Cout + cg;
-                f32x4 r4 = v[j];
-                if (epi & EPI_RESIDUAL) r4 += *reinterpret_cast<const f32x4*>(p.residual + o);
-                *reinterpret_cast<f32x4*>(p.out + o) = r4;
-            }
+            RowsEpilogue re;
+            re.split = split;
+            re.M = (size_t)p.B * p.Ho * p.Wo * (p.fold ? 4 : 1);
+            re.b0 = b0;
+            re.uni = g.NB == 1 || p.ss_stride == 0;
+            re.HoWo = p.Ho * p.Wo * (p.fold ? 4 : 1);
+            re.red = smem + g.ptab_off + 64 * WM;  // [WN][64*WM]
+            re.rows_per_wg = 64 * WM;
+            re.row_in_wg0 = wm * 64;
+            re.wn = wn;
+            rows_epilogue<WN>(p, re, v, pixv, cg, cvalid);
             DM_STAMP_ADD(6)
             DM_STAMP_FLUSH
             return;

@@ -108,6 +108,7 @@ struct ConvLayer {
     bool fold = false;  // ... executed as four 2x2 parity convs on the source grid (ConvParams::fold)
     int fold_w_stride = 0;
     float* w = nullptr;
+    float* ww = nullptr;  // Winograd-transformed weights (winograd_mfma.hip) when the layer is eligible
     float* bias = nullptr;
 };
 
@@ -264,6 +265,12 @@ static int make_conv(DeviceOwner& own, ConvLayer& L, const float* oihw, const fl
         conv_pack_weights(oihw, packed.data(), Cout, C0, C1, KH, KW);
     }
     if (own.upload(packed.data(), packed.size(), &L.w)) return 1;
+    L.ww = nullptr;
+    if (wino_eligible(Cout, C0, C1, KH, KW, stride, pad, up)) {
+        std::vector<float> wp(wino_packed_floats(Cout, C0, C1));
+        wino_pack_weights(oihw, wp.data(), Cout, C0, C1);
+        if (own.upload(wp.data(), wp.size(), &L.ww)) return 1;
+    }
     L.bias = nullptr;
     if (bias && own.upload(bias, Cout, &L.bias)) return 1;
     return 0;
@@ -339,6 +346,13 @@ struct Ctx {
     bool dry() const { return A->dry; }
 };
 
+// policy: which eligible layers take the Winograd kernel (DM_WINO=0 none, 1 all)
+static bool wino_use(int B, int Ho, int Wo, int Cout, int C0, int C1) {
+    static const int mode = std::getenv("DM_WINO") ? std::atoi(std::getenv("DM_WINO")) : 1;
+    (void)B; (void)Ho; (void)Wo; (void)Cout; (void)C0; (void)C1;
+    return mode != 0;
+}
+
 static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* in1, int Hin, int Win, float* out,
                     int epi, const float* g, const float* scale, const float* residual, bool in_nchw = false,
                     bool out_nchw = false) {
@@ -377,19 +391,28 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
         p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, L.KH, L.KW, L.stride, L.C0, L.C1, want_norm && !out_nchw,
                           !out_nchw);
     }
+    // 3x3 / stride 1 convolutions run as Winograd F(2x2,3x3) when the layer has transformed weights
+    const bool wino = L.ww && !L.fold && !in_nchw && !out_nchw && (p.Ho % 2 == 0) && (p.Wo % 2 == 0) &&
+                      wino_use(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
+    if (wino) {
+        p.w = L.ww;
+        p.chunks0 = L.C0 / 8;
+        p.n_chunks = (L.C0 + L.C1) / 8;
+        p.geo = wino_plan(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1, true);
+    }
     const int full_epi = epi | (L.bias ? EPI_BIAS : 0);
     const bool in_kernel = p.geo.splits == 1 && (!want_norm || p.geo.fused_norm);
     if (in_kernel) {
         if (c.dry()) return 0;
         p.out = out; p.partial = 0; p.epi = full_epi;
-        return conv_launch(p, c.s);
+        return wino ? wino_launch(p, c.s) : conv_launch(p, c.s);
     }
     DM_REQUIRE(!out_nchw, "split / unfused epilogue writes NHWC");
     const size_t M = (size_t)c.B * out_h * out_w;
     float* part = c.A->alloc((size_t)p.geo.splits * M * L.Cout);
     if (c.dry()) return 0;
     p.out = part; p.partial = 1; p.epi = 0;
-    if (conv_launch(p, c.s)) return 1;
+    if (wino ? wino_launch(p, c.s) : conv_launch(p, c.s)) return 1;
     return launch_norm_act(part, p.geo.splits, (int64_t)(M * L.Cout), L.bias, g, scale, c.ss_stride, out_h * out_w,
                            residual, out, (int64_t)M, L.Cout, full_epi, c.s);
 }

@@ -58,6 +58,7 @@ struct ConvGeom {
     int splits;          // K splits (blockIdx.y); > 1 writes partial sums
     int chunks_per_split;
     int fused_norm;      // the plan keeps all couts of a pixel in one workgroup (EPI_NORM allowed)
+    int row_stride;      // winograd: LDS floats per window row
     int lds_bytes;
 };
 
@@ -102,6 +103,18 @@ size_t conv_packed_floats(int Cout, int C0, int C1, int KH, int KW);
 // pack OIHW (Cout, C0+C1, KH, KW) -> kernel layout (host side)
 void conv_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1, int KH, int KW);
 int conv_launch(const ConvParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) convolution on the f32 MFMA (winograd_mfma.hip): 3x3 / stride 1 / pad 1, NHWC,
+// C0 % 8 == 0, C1 % 8 == 0, Cout % 64 == 0, even output size.  Same ConvParams / epilogue contract as
+// conv_launch; ConvGeom is reused with TW/TH/NB counted in 2x2-pixel Winograd tiles (64 per workgroup).
+// ---------------------------------------------------------------------------------------
+bool wino_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up);
+size_t wino_packed_floats(int Cout, int C0, int C1);
+// OIHW (Cout, C0+C1, 3, 3) -> U = G g G^T in kernel layout [chunk of 8 cin][16 xi][Cout][8]
+void wino_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1);
+ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_split);
+int wino_launch(const ConvParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).

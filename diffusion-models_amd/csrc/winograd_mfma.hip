@@ -1,0 +1,423 @@
+// Winograd F(2x2, 3x3) convolution for gfx950 on the f32-input MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Runs the 3x3 / stride-1 / pad-1 convolutions of Block (DD/denoising_diffusion.py:108, inside ResnetBlock
+// :136-148) and the plain 3x3 convs of the last Downsample / Upsample stages (:291, :303) with 16 instead of
+// 36 multiplies per 2x2 output pixels and (cin, cout) pair:
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A          d = 4x4 input patch, g = 3x3 filter, Y = 2x2 outputs
+//     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+// For each of the 16 positions xi = (i, j) of the transformed patch the reduction over cin is an independent GEMM
+//     M[xi][tile][cout] = sum_c V[xi][tile][c] * U[xi][cout][c],   V = B^T d B,   U = G g G^T (host, once)
+//
+// Mapping (one workgroup = 4 waves = 64 Winograd tiles (128..256 output pixels) x 64 couts; one workgroup per CU):
+//   wave i owns row i of the transformed patch: xi = (i, 0..3).  Its accumulators are 4 xi x (64 tiles x 64
+//   couts = 2x2 MFMA tiles) = 256 registers.  Nothing but the raw input window is shared between waves:
+//   * B operand: U[xi][cout][c] is packed on the host as [chunk of 8 cin][xi][cout][8], so lane (cout = lane&31,
+//     half = lane>>5) loads its 4 channels of a chunk as ONE 16-byte global load straight into the MFMA operand
+//     registers (a wave reads 1 KiB contiguous).  Weights never touch LDS.
+//   * A operand: the raw input window of the tile (NB images x (2TH+2) x (2TW+2) pixels x 8 channels) is staged in
+//     LDS (double buffered, one barrier per chunk).  Lane (tile = lane&31 [+32], half) reads the two patch rows
+//     that row i of B^T combines (8 ds_read_b128 per tile), forms T = d[ra] +- d[rb] and V[i][0..3] from it -- and
+//     those 4 values ARE its MFMA A operands for the chunk.  The transformed input never touches LDS either.
+//   * All of that (global loads of the next weights / next-but-one window, LDS reads and the ~64 VALU ops of the
+//     next chunk's transform) is issued from hooks between the 64 MFMAs of the current chunk.
+//   Epilogue: each wave reduces its 4 columns with A (R_i[b], 2 values), the four R_i go through LDS in the
+//   row layout of conv_mfma.hip, Y[a][b] = sum_i A^T[a][i] R_i[b], then the shared Block epilogue
+//   (bias / RMSNorm / scale-shift / SiLU / residual, or raw K-split partial sums).
+//
+// The summation order differs from the direct kernel's (and from PyTorch's), like any fp32 convolution
+// algorithm; tests/test_hip_ops.py holds the tolerance.
+#include "conv_device.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace dm {
+
+static constexpr int WCK = 8;     // input channels per K chunk
+static constexpr int WHREGS = 5;  // window staging registers (16 B each) per thread
+static constexpr int WTS = 68;    // padded row stride of the transposed epilogue tiles (floats)
+
+static inline int w_pow2ceil(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+static inline int w_ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+static inline int w_env_int(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
+}
+
+bool wino_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up) {
+    static const bool off = std::getenv("DM_NO_WINOGRAD") != nullptr;
+    return !off && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !up && C0 > 0 && C0 % WCK == 0 &&
+           C1 % WCK == 0 && Cout % 64 == 0;
+}
+
+size_t wino_packed_floats(int Cout, int C0, int C1) { return (size_t)(C0 + C1) * 16 * Cout; }
+
+void wino_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1) {
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int Cin = C0 + C1;
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* gk = oihw + ((size_t)co * Cin + ci) * 9;
+            double Gg[4][3];
+            for (int i = 0; i < 4; ++i)
+                for (int b = 0; b < 3; ++b) Gg[i][b] = G[i][0] * gk[b] + G[i][1] * gk[3 + b] + G[i][2] * gk[6 + b];
+            const int chunk = ci / WCK, cc = ci % WCK;
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    double u = Gg[i][0] * G[j][0] + Gg[i][1] * G[j][1] + Gg[i][2] * G[j][2];
+                    packed[(((size_t)chunk * 16 + i * 4 + j) * Cout + co) * WCK + cc] = (float)u;
+                }
+        }
+}
+
+ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_split) {
+    ConvGeom g{};
+    g.WM = 4;
+    g.WN = 1;
+    g.CK = WCK;
+    const int twi = (Wo + 1) / 2, thi = (Ho + 1) / 2;  // tiles per image
+    g.TW = std::min(w_pow2ceil(twi), 8);
+    g.TH = std::min(w_pow2ceil(thi), 64 / g.TW);
+    g.NB = 64 / (g.TW * g.TH);
+    g.lTW = w_ilog2(g.TW);
+    g.lTH = w_ilog2(g.TH);
+    g.tiles_x = (twi + g.TW - 1) / g.TW;
+    g.tiles_y = (thi + g.TH - 1) / g.TH;
+    g.groups = (B + g.NB - 1) / g.NB;
+    g.n_tiles_n = Cout / 64;
+    g.IH = 2 * g.TH + 2;
+    g.IW = 2 * g.TW + 2;
+    g.row_stride = g.IW * WCK + 4;  // +4: rows of consecutive tile rows start 8 banks apart mod 16
+    g.halo_floats = g.NB * g.IH * g.row_stride;
+    g.w_floats = 0;
+    g.TPS = 3;
+    const int n_chunks = (C0 + C1) / WCK;
+    const int wgs = g.tiles_x * g.tiles_y * g.groups * g.n_tiles_n;
+    int splits = 1;
+    if (allow_split) {
+        static const int target = w_env_int("DM_WINO_TARGET_WGS", 256);
+        static const int min_chunks = w_env_int("DM_WINO_MIN_CHUNKS", 8);
+        while (wgs * splits < target && splits < 8 && n_chunks / (splits * 2) >= min_chunks) splits *= 2;
+    }
+    g.chunks_per_split = (n_chunks + splits - 1) / splits;
+    g.splits = (n_chunks + g.chunks_per_split - 1) / g.chunks_per_split;
+    g.fused_norm = g.n_tiles_n == 1 && g.splits == 1;
+    g.ptab_off = 0;
+    g.lds_bytes = std::max(2 * g.halo_floats, 4 * 2 * 64 * WTS) * 4;
+    return g;
+}
+
+__global__ __launch_bounds__(256, 1) void wino_mfma_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const ConvGeom& g = p.geo;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int n_tile = bid % g.n_tiles_n;
+    bid /= g.n_tiles_n;
+    const int tile_x = bid % g.tiles_x;
+    bid /= g.tiles_x;
+    const int tile_y = bid % g.tiles_y;
+    const int group = bid / g.tiles_y;
+    const int tx0 = tile_x * g.TW, ty0 = tile_y * g.TH, b0 = group * g.NB;  // in Winograd tiles
+    const int ix0 = 2 * tx0 - 1, iy0 = 2 * ty0 - 1;                         // window origin in pixels
+    const int split = blockIdx.y;
+    const int cb = split * g.chunks_per_split;
+    const int ce = min(cb + g.chunks_per_split, p.n_chunks);
+    const int RS = g.row_stride;
+    float* raw0 = smem;
+    float* raw1 = smem + g.halo_floats;
+
+    // ---- window staging: item = (window pixel, channel quad); the quad is tid & 1 for every item of a thread
+    const int win_items = g.NB * g.IH * g.IW * 2;
+    int hpix[WHREGS], hoff[WHREGS];
+#pragma unroll
+    for (int i = 0; i < WHREGS; ++i) {
+        const int it = tid + 256 * i;
+        hpix[i] = -1;
+        hoff[i] = -1;
+        if (it < win_items) {
+            const int hp = it >> 1;
+            const int nb = hp / (g.IH * g.IW);
+            const int rem = hp - nb * (g.IH * g.IW);
+            const int hy = rem / g.IW;
+            const int hx = rem - hy * g.IW;
+            const int b = b0 + nb, iy = iy0 + hy, ix = ix0 + hx;
+            hoff[i] = (nb * g.IH + hy) * RS + hx * WCK + 4 * (tid & 1);
+            if (b < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) hpix[i] = (b * p.Hin + iy) * p.Win + ix;
+        }
+    }
+    f32x4 hreg[WHREGS];
+    const float* __restrict__ hsrc = nullptr;
+    int hCs = 0;
+    auto window_source = [&](int chunk) {
+        const bool s1 = chunk >= p.chunks0;
+        hsrc = (s1 ? p.in1 : p.in0) + (s1 ? chunk - p.chunks0 : chunk) * WCK + 4 * (tid & 1);
+        hCs = s1 ? p.C1 : p.C0;
+    };
+    auto load_window = [&](int i) { hreg[i] = *reinterpret_cast<const f32x4*>(hsrc + (size_t)max(hpix[i], 0) * hCs); };
+    auto store_window = [&](float* raw, int i) {
+        if (hoff[i] >= 0)
+            *reinterpret_cast<f32x4*>(raw + hoff[i]) = hpix[i] >= 0 ? hreg[i] : make_f32x4(0.f, 0.f, 0.f, 0.f);
+    };
+
+    // ---- input transform of this lane: tiles l31 and 32 + l31, channel quad lh, row `wave` of B^T d
+    int rbase[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int t = 32 * r + l31;
+        const int tx = t & (g.TW - 1);
+        const int ty = (t >> g.lTW) & (g.TH - 1);
+        const int nb = t >> (g.lTW + g.lTH);
+        rbase[r] = (nb * g.IH + 2 * ty) * RS + 2 * tx * WCK + 4 * lh;
+    }
+    // B^T row i = d[ra] + sgn * d[rb]:  i=0: d0 - d2;  i=1: d1 + d2;  i=2: d2 - d1;  i=3: d1 - d3
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sgn = wave == 1 ? 1.0f : -1.0f;
+    const int offa = ra * RS, offb = rb * RS;
+
+    f32x4 A[4][2];  // V[wave][j] of tile r: channels 4*lh .. 4*lh+3 of the chunk
+    f32x4 U[4][2];  // U[wave*4 + j][cout 32*q + l31][channels 4*lh ..]
+    const size_t u_chunk = (size_t)16 * p.Cout * WCK;
+    const float* __restrict__ ucur =
+        p.w + (size_t)cb * u_chunk + ((size_t)(4 * wave) * p.Cout + n_tile * 64 + l31) * WCK + 4 * lh;
+    auto load_u = [&](const float* __restrict__ ub, int j, int q) {
+        U[j][q] = *reinterpret_cast<const f32x4*>(ub + ((size_t)j * p.Cout + 32 * q) * WCK);
+    };
+
+    f32x16 acc[4][2][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][r][q][e] = 0.f;
+
+    // ---- prologue: chunk cb (and cb + 1) -> LDS, operands of chunk cb -> registers
+    __builtin_amdgcn_s_setprio(1);
+    window_source(cb);
+#pragma unroll
+    for (int i = 0; i < WHREGS; ++i) load_window(i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) load_u(ucur, j, q);
+#pragma unroll
+    for (int i = 0; i < WHREGS; ++i) store_window(raw0, i);
+    if (cb + 1 < ce) {
+        window_source(cb + 1);
+#pragma unroll
+        for (int i = 0; i < WHREGS; ++i) load_window(i);
+#pragma unroll
+        for (int i = 0; i < WHREGS; ++i) store_window(raw1, i);
+    }
+    __syncthreads();
+    {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            f32x4 T[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const f32x4 da = *reinterpret_cast<const f32x4*>(raw0 + rbase[r] + offa + b * WCK);
+                const f32x4 db = *reinterpret_cast<const f32x4*>(raw0 + rbase[r] + offb + b * WCK);
+                T[b] = da + sgn * db;
+            }
+            A[0][r] = T[0] - T[2];
+            A[1][r] = T[1] + T[2];
+            A[2][r] = T[2] - T[1];
+            A[3][r] = T[1] - T[3];
+        }
+    }
+    __syncthreads();  // raw0 is overwritten with chunk cb + 2 by the first iteration
+
+    // ---- main loop: 64 MFMAs per chunk and wave; everything else is issued from the hooks between them
+    for (int c = cb; c < ce; ++c) {
+        const bool has1 = c + 1 < ce, has2 = c + 2 < ce;
+        const int par = (c - cb) & 1;
+        const float* rawn = par ? raw0 : raw1;  // chunk c + 1 (stored during iteration c - 1 / the prologue)
+        float* rawst = par ? raw1 : raw0;       // chunk c was read from here during iteration c - 1: free
+        window_source(has2 ? c + 2 : c);
+        const float* __restrict__ unext = has1 ? ucur + u_chunk : ucur;  // never reads past the packed weights
+        f32x4 d[8];
+        f32x4 T[2][4];
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int m = ((j * 4 + s) * 2 + r) * 2 + q;  // 0..63
+                        acc[j][r][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[j][r][s], U[j][q][s], acc[j][r][q], 0, 0, 0);
+                        if (m < WHREGS) {
+                            if (has2) load_window(m);
+                        }
+                        if (m >= 6 && m < 14) {  // patch rows of tile r = 0
+                            const int k = m - 6;
+                            d[k] = *reinterpret_cast<const f32x4*>(rawn + rbase[0] + (k < 4 ? offa : offb) + (k & 3) * WCK);
+                        }
+                        if (m >= 14 && m < 18) {
+                            const int b = m - 14;
+                            T[0][b] = d[b] + sgn * d[4 + b];
+                        }
+                        if (m == 16) {  // the MFMAs of j = 0 were issued by m = 15: its operands are free
+                            load_u(unext, 0, 0);
+                            load_u(unext, 0, 1);
+                        }
+                        if (m >= 18 && m < 26) {  // tile r = 1
+                            const int k = m - 18;
+                            d[k] = *reinterpret_cast<const f32x4*>(rawn + rbase[1] + (k < 4 ? offa : offb) + (k & 3) * WCK);
+                        }
+                        if (m >= 26 && m < 30) {
+                            const int b = m - 26;
+                            T[1][b] = d[b] + sgn * d[4 + b];
+                        }
+                        if (m == 30) {
+                            A[0][0] = T[0][0] - T[0][2];
+                            A[0][1] = T[1][0] - T[1][2];
+                        }
+                        if (m == 32) {  // j = 1 done at m = 31
+                            A[1][0] = T[0][1] + T[0][2];
+                            A[1][1] = T[1][1] + T[1][2];
+                        }
+                        if (m == 33) {
+                            load_u(unext, 1, 0);
+                            load_u(unext, 1, 1);
+                        }
+                        if (m == 48) {  // j = 2 done at m = 47
+                            A[2][0] = T[0][2] - T[0][1];
+                            A[2][1] = T[1][2] - T[1][1];
+                        }
+                        if (m == 49) {
+                            load_u(unext, 2, 0);
+                            load_u(unext, 2, 1);
+                        }
+                        if (m >= 56 && m < 56 + WHREGS) {
+                            if (has2) store_window(rawst, m - 56);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+        A[3][0] = T[0][1] - T[0][3];
+        A[3][1] = T[1][1] - T[1][3];
+        load_u(unext, 3, 0);
+        load_u(unext, 3, 1);
+        __builtin_amdgcn_s_setprio(1);
+        ucur = unext;
+        __syncthreads();
+    }
+
+    // ---- epilogue: R_i[b] = sum_j M[i][j] A[j][b] per wave, then Y[a][b] = sum_i A^T[a][i] R_i[b] through LDS
+    float* Tb = smem + wave * (2 * 64 * WTS);  // [b][tile][WTS]
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x16 r0 = acc[0][r][q] + acc[1][r][q] + acc[2][r][q];
+            const f32x16 r1 = acc[1][r][q] - acc[2][r][q] - acc[3][r][q];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = r * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                Tb[row * WTS + q * 32 + l31] = r0[e];
+                Tb[(64 + row) * WTS + q * 32 + l31] = r1[e];
+            }
+        }
+    __syncthreads();
+    const int rsub = lane >> 4;  // = 2a + b: position of this lane's pixels inside their 2x2 tile
+    const int oa = rsub >> 1, ob = rsub & 1;
+    const int c4 = (lane & 15) * 4;
+    const int cg = n_tile * 64 + c4;
+    const bool cvalid = cg < p.Cout;
+    const float ysgn = oa ? -1.0f : 1.0f;  // Y[0] = R0 + R1 + R2,  Y[1] = R1 - R2 - R3
+    const float* Y0 = smem + (oa * 2 + ob) * (64 * WTS) + c4;
+    f32x4 v[16];
+    int pixv[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int t = 16 * wave + jj;
+        const float* yp = Y0 + t * WTS;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(yp);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(yp + 2 * 64 * WTS);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(yp + 4 * 64 * WTS);
+        v[jj] = a0 + ysgn * a1 + ysgn * a2;
+        const int tx = t & (g.TW - 1);
+        const int ty = (t >> g.lTW) & (g.TH - 1);
+        const int nb = t >> (g.lTW + g.lTH);
+        const int b = b0 + nb, y = 2 * (ty0 + ty) + oa, x = 2 * (tx0 + tx) + ob;
+        pixv[jj] = (b < p.B && y < p.Ho && x < p.Wo) ? (b * p.Ho + y) * p.Wo + x : -1;
+    }
+    RowsEpilogue re;
+    re.split = split;
+    re.M = (size_t)p.B * p.Ho * p.Wo;
+    re.b0 = b0;
+    re.uni = g.NB == 1 || p.ss_stride == 0;
+    re.HoWo = p.Ho * p.Wo;
+    re.red = nullptr;
+    re.rows_per_wg = 256;
+    re.row_in_wg0 = wave * 64;
+    re.wn = 0;
+    rows_epilogue<1>(p, re, v, pixv, cg, cvalid);
+}
+
+int wino_launch(const ConvParams& pin, hipStream_t s) {
+    ConvParams p = pin;
+    p.stamps = nullptr;
+    const ConvGeom& g = p.geo;
+    DM_REQUIRE(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && !p.up && !p.fold, "winograd: 3x3 s1 p1 only");
+    DM_REQUIRE(!p.in_nchw && !p.out_nchw, "winograd: NHWC only");
+    DM_REQUIRE(p.C0 % WCK == 0 && p.C1 % WCK == 0 && p.Cout % 64 == 0, "winograd: channel counts");
+    DM_REQUIRE(p.Hin == p.Ho && p.Win == p.Wo, "winograd: same-size convolution");
+    DM_REQUIRE(g.TW * g.TH * g.NB == 64, "winograd: 64 tiles per workgroup");
+    DM_REQUIRE(g.NB * g.IH * g.IW * 2 <= 256 * WHREGS, "winograd: window exceeds staging registers");
+    DM_REQUIRE(!(p.epi & EPI_NORM) || (g.n_tiles_n == 1 && g.splits == 1), "winograd: fused RMSNorm needs one N tile");
+    DM_REQUIRE(g.splits == 1 || p.partial, "winograd: split-K writes partial sums");
+    DM_REQUIRE(g.lds_bytes <= 160 * 1024, "winograd: tile does not fit LDS");
+    DM_REQUIRE(p.chunks0 == p.C0 / WCK && p.n_chunks == (p.C0 + p.C1) / WCK, "winograd: chunk counts");
+    static bool attr_set = false;
+    if (!attr_set) {
+        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_mfma_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int blocks = g.n_tiles_n * g.tiles_x * g.tiles_y * g.groups;
+    const bool timed = prof::enabled();
+    if (timed) {
+        // priced as the reference's op: 2*9*Cin*Cout*pixels FLOP; the kernel executes 16/36 of
+        // the multiply-adds of that count
+        const double pix = (double)p.B * p.Ho * p.Wo;
+        const double cin = p.C0 + p.C1;
+        const double flops = 2.0 * 9.0 * cin * p.Cout * pix;
+        const double bytes = 4.0 * (cin * pix + p.Cout * pix + 9.0 * cin * p.Cout);
+        char name[64];
+        if (prof::detail())
+            snprintf(name, sizeof(name), "wino 3x3 s1 %d+%d->%d @%dx%d e%d k%d", p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.epi,
+                     g.splits);
+        else
+            snprintf(name, sizeof(name), "wino_mfma_kernel");
+        if (prof::begin(name, flops, bytes, s)) return 1;
+    }
+    hipLaunchKernelGGL(wino_mfma_kernel, dim3(blocks, g.splits, 1), dim3(256), g.lds_bytes, s, p);
+    DM_CHECK_HIP(hipGetLastError());
+    if (timed && prof::end(s)) return 1;
+    return 0;
+}
+
+}  // namespace dm
