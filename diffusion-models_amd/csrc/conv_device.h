@@ -32,7 +32,8 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
 // Row-layout epilogue shared by the convolution kernels.  A wave holds 64 output pixels x 64 consecutive couts
-// as v[j] = the 4 couts [cg, cg+4) of pixel row 4*j + (lane>>4); the 16 lanes of a DPP row cover one pixel.
+// (NR = 16; 32 pixels for NR = 8) as v[j] = the 4 couts [cg, cg+4) of pixel row 4*j + (lane>>4); the 16 lanes
+// of a DPP row cover one pixel.
 // pixv[j] is the global output pixel of that row or -1.  Every global access is a 16-byte one, the RMSNorm
 // reduction stays inside a DPP row (plus one LDS exchange when the pixel's couts span WN waves: `red` is
 // [WN][rows_per_wg] floats and row_in_wg0 the index of this wave's first row in it -- all waves of the
@@ -49,15 +50,15 @@ struct RowsEpilogue {
     int wn;
 };
 
-template <int WN>
-__device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpilogue& e, f32x4 (&v)[16],
-                                              const int (&pixv)[16], int cg, bool cvalid) {
+template <int WN, int NR = 16>
+__device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpilogue& e, f32x4 (&v)[NR],
+                                              const int (&pixv)[NR], int cg, bool cvalid) {
     const int lane = threadIdx.x & 63;
     const int rsub = lane >> 4;
     if (p.partial) {
         float* po = p.out + (size_t)e.split * e.M * p.Cout + cg;
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
+        for (int j = 0; j < NR; ++j)
             if (pixv[j] >= 0 && cvalid) *reinterpret_cast<f32x4*>(po + (size_t)pixv[j] * p.Cout) = v[j];
         return;
     }
@@ -66,13 +67,13 @@ __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpi
     f32x4 b4 = zero4;
     if ((epi & EPI_BIAS) && cvalid) b4 = *reinterpret_cast<const f32x4*>(p.bias + cg);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = cvalid ? v[j] + b4 : zero4;
+    for (int j = 0; j < NR; ++j) v[j] = cvalid ? v[j] + b4 : zero4;
     if (epi & EPI_NORM) {
         const float sqrtc = sqrtf((float)p.Cout);
         f32x4 g4 = cvalid ? *reinterpret_cast<const f32x4*>(p.g + cg) * sqrtc : zero4;
-        float ssv[16];
+        float ssv[NR];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < NR; ++j) {
             float ss = v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
             ss += dpp_f<0xB1>(ss);
             ss += dpp_f<0x4E>(ss);
@@ -84,11 +85,11 @@ __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpi
             // the pixel's couts are spread over WN waves: exchange the partial sums through LDS
             if ((lane & 15) == 0) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) e.red[e.wn * e.rows_per_wg + e.row_in_wg0 + 4 * j + rsub] = ssv[j];
+                for (int j = 0; j < NR; ++j) e.red[e.wn * e.rows_per_wg + e.row_in_wg0 + 4 * j + rsub] = ssv[j];
             }
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < NR; ++j) {
                 float t = 0.f;
 #pragma unroll
                 for (int w = 0; w < WN; ++w) t += e.red[w * e.rows_per_wg + e.row_in_wg0 + 4 * j + rsub];
@@ -97,7 +98,7 @@ __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpi
         }
         // 1 / max(||v||, 1e-12) as one v_rsq_f32 (1 ulp)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = v[j] * (fast_rsq(fmaxf(ssv[j], 1e-24f))) * g4;
+        for (int j = 0; j < NR; ++j) v[j] = v[j] * (fast_rsq(fmaxf(ssv[j], 1e-24f))) * g4;
     }
     if (epi & EPI_SCALE_SHIFT) {
         f32x4 sc = make_f32x4(1.f, 1.f, 1.f, 1.f), sh = zero4;
@@ -107,7 +108,7 @@ __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpi
             sh = *reinterpret_cast<const f32x4*>(sp + p.Cout + cg);
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < NR; ++j) {
             if (!e.uni && cvalid && pixv[j] >= 0) {
                 const float* sp = p.scale + (size_t)(pixv[j] / e.HoWo) * p.ss_stride;
                 sc = *reinterpret_cast<const f32x4*>(sp + cg) + 1.0f;
@@ -118,7 +119,7 @@ __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpi
     }
     if (epi & EPI_SILU) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < NR; ++j) {
             v[j].x = v[j].x * fast_rcp(1.0f + __expf(-v[j].x));
             v[j].y = v[j].y * fast_rcp(1.0f + __expf(-v[j].y));
             v[j].z = v[j].z * fast_rcp(1.0f + __expf(-v[j].z));
@@ -126,7 +127,7 @@ __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpi
         }
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < NR; ++j) {
         if (pixv[j] < 0 || !cvalid) continue;
         const size_t o = (size_t)pixv[j] * p.Cout + cg;
         f32x4 r4 = v[j];

@@ -36,7 +36,6 @@
 namespace dm {
 
 static constexpr int WCK = 8;     // input channels per K chunk
-static constexpr int WHREGS = 5;  // window staging registers (16 B each) per thread
 static constexpr int WTS = 68;    // padded row stride of the transposed epilogue tiles (floats)
 
 static inline int w_pow2ceil(int v) {
@@ -81,14 +80,18 @@ void wino_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C
 }
 
 ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_split) {
+    // R = Winograd tiles per lane: 2 -> 64 tiles per workgroup, 256 accumulator registers, one workgroup per CU;
+    //                              1 -> 32 tiles per workgroup, 128 accumulator registers, two workgroups per CU
+    static const int R = w_env_int("DM_WINO_R", 1) == 2 ? 2 : 1;
+    const int tiles = 32 * R;
     ConvGeom g{};
-    g.WM = 4;
+    g.WM = R;
     g.WN = 1;
     g.CK = WCK;
     const int twi = (Wo + 1) / 2, thi = (Ho + 1) / 2;  // tiles per image
     g.TW = std::min(w_pow2ceil(twi), 8);
-    g.TH = std::min(w_pow2ceil(thi), 64 / g.TW);
-    g.NB = 64 / (g.TW * g.TH);
+    g.TH = std::min(w_pow2ceil(thi), tiles / g.TW);
+    g.NB = tiles / (g.TW * g.TH);
     g.lTW = w_ilog2(g.TW);
     g.lTH = w_ilog2(g.TH);
     g.tiles_x = (twi + g.TW - 1) / g.TW;
@@ -107,17 +110,22 @@ ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_s
     if (allow_split) {
         static const int target = w_env_int("DM_WINO_TARGET_WGS", 256);
         static const int min_chunks = w_env_int("DM_WINO_MIN_CHUNKS", 8);
-        while (wgs * splits < target && splits < 8 && n_chunks / (splits * 2) >= min_chunks) splits *= 2;
+        while (wgs * splits < target * (3 - R) && splits < 8 && n_chunks / (splits * 2) >= min_chunks) splits *= 2;
     }
     g.chunks_per_split = (n_chunks + splits - 1) / splits;
     g.splits = (n_chunks + g.chunks_per_split - 1) / g.chunks_per_split;
     g.fused_norm = g.n_tiles_n == 1 && g.splits == 1;
     g.ptab_off = 0;
-    g.lds_bytes = std::max(2 * g.halo_floats, 4 * 2 * 64 * WTS) * 4;
+    // two windows + a scratch slot reachable from both; the epilogue reuses the space for 4 x 2 transposed tiles
+    g.lds_bytes = std::max(3 * g.halo_floats + 4, 4 * 2 * tiles * WTS) * 4;
     return g;
 }
 
-__global__ __launch_bounds__(256, 1) void wino_mfma_kernel(const ConvParams p) {
+template <int R>
+__global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams p) {
+    constexpr int TILES = 32 * R;         // Winograd tiles per workgroup
+    constexpr int HR = R == 2 ? 5 : 3;    // window staging registers (16 B each) per thread
+    constexpr int NM = 32 * R;            // MFMAs per chunk and wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ConvGeom& g = p.geo;
     const int tid = threadIdx.x;
@@ -144,12 +152,12 @@ __global__ __launch_bounds__(256, 1) void wino_mfma_kernel(const ConvParams p) {
 
     // ---- window staging: item = (window pixel, channel quad); the quad is tid & 1 for every item of a thread
     const int win_items = g.NB * g.IH * g.IW * 2;
-    int hpix[WHREGS], hoff[WHREGS];
+    int hpix[HR], hoff[HR];
 #pragma unroll
-    for (int i = 0; i < WHREGS; ++i) {
+    for (int i = 0; i < HR; ++i) {
         const int it = tid + 256 * i;
         hpix[i] = -1;
-        hoff[i] = -1;
+        hoff[i] = 2 * g.halo_floats;  // items past the window go to a scratch slot: the main loop has no branches
         if (it < win_items) {
             const int hp = it >> 1;
             const int nb = hp / (g.IH * g.IW);
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void wino_mfma_kernel(const ConvParams p) {
             if (b < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) hpix[i] = (b * p.Hin + iy) * p.Win + ix;
         }
     }
-    f32x4 hreg[WHREGS];
+    f32x4 hreg[HR];
     const float* __restrict__ hsrc = nullptr;
     int hCs = 0;
     auto window_source = [&](int chunk) {
@@ -169,16 +177,18 @@ __global__ __launch_bounds__(256, 1) void wino_mfma_kernel(const ConvParams p) {
         hsrc = (s1 ? p.in1 : p.in0) + (s1 ? chunk - p.chunks0 : chunk) * WCK + 4 * (tid & 1);
         hCs = s1 ? p.C1 : p.C0;
     };
-    auto load_window = [&](int i) { hreg[i] = *reinterpret_cast<const f32x4*>(hsrc + (size_t)max(hpix[i], 0) * hCs); };
+    // pixel index and channel count are < 2^24 (wino_launch checks): one full-rate v_mul_u32_u24 per address
+    auto load_window = [&](int i) {
+        hreg[i] = *reinterpret_cast<const f32x4*>(hsrc + __umul24((unsigned)max(hpix[i], 0), (unsigned)hCs));
+    };
     auto store_window = [&](float* raw, int i) {
-        if (hoff[i] >= 0)
-            *reinterpret_cast<f32x4*>(raw + hoff[i]) = hpix[i] >= 0 ? hreg[i] : make_f32x4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<f32x4*>(raw + hoff[i]) = hpix[i] >= 0 ? hreg[i] : make_f32x4(0.f, 0.f, 0.f, 0.f);
     };
 
-    // ---- input transform of this lane: tiles l31 and 32 + l31, channel quad lh, row `wave` of B^T d
-    int rbase[2];
+    // ---- input transform of this lane: tiles l31 (and 32 + l31), channel quad lh, row `wave` of B^T d
+    int rbase[R];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < R; ++r) {
         const int t = 32 * r + l31;
         const int tx = t & (g.TW - 1);
         const int ty = (t >> g.lTW) & (g.TH - 1);
@@ -190,64 +200,67 @@ __global__ __launch_bounds__(256, 1) void wino_mfma_kernel(const ConvParams p) {
     const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sgn = wave == 1 ? 1.0f : -1.0f;
     const int offa = ra * RS, offb = rb * RS;
+    auto rd = [&](const float* raw, int r, int ab, int b) {  // patch row ra (ab = 0) or rb (1), column b, of tile r
+        return *reinterpret_cast<const f32x4*>(raw + rbase[r] + (ab ? offb : offa) + b * WCK);
+    };
 
-    f32x4 A[4][2];  // V[wave][j] of tile r: channels 4*lh .. 4*lh+3 of the chunk
+    f32x4 A[4][R];  // V[wave][j] of tile r: channels 4*lh .. 4*lh+3 of the chunk
     f32x4 U[4][2];  // U[wave*4 + j][cout 32*q + l31][channels 4*lh ..]
     const size_t u_chunk = (size_t)16 * p.Cout * WCK;
     const float* __restrict__ ucur =
         p.w + (size_t)cb * u_chunk + ((size_t)(4 * wave) * p.Cout + n_tile * 64 + l31) * WCK + 4 * lh;
-    auto load_u = [&](const float* __restrict__ ub, int j, int q) {
-        U[j][q] = *reinterpret_cast<const f32x4*>(ub + ((size_t)j * p.Cout + 32 * q) * WCK);
+    auto load_u = [&](const float* __restrict__ ub, int j) {
+        U[j][0] = *reinterpret_cast<const f32x4*>(ub + (size_t)j * p.Cout * WCK);
+        U[j][1] = *reinterpret_cast<const f32x4*>(ub + ((size_t)j * p.Cout + 32) * WCK);
     };
 
-    f32x16 acc[4][2][2];
+    f32x16 acc[4][R][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[j][r][q][e] = 0.f;
 
-    // ---- prologue: chunk cb (and cb + 1) -> LDS, operands of chunk cb -> registers
+    // ---- prologue: chunks cb and cb + 1 -> LDS (both loads in flight together), operands of chunk cb -> registers
     __builtin_amdgcn_s_setprio(1);
-    window_source(cb);
+    {
+        const bool two = cb + 1 < ce;
+        f32x4 h2[HR];
+        window_source(cb);
 #pragma unroll
-    for (int i = 0; i < WHREGS; ++i) load_window(i);
+        for (int i = 0; i < HR; ++i) load_window(i);
+        window_source(two ? cb + 1 : cb);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < HR; ++i)
+            h2[i] = *reinterpret_cast<const f32x4*>(hsrc + __umul24((unsigned)max(hpix[i], 0), (unsigned)hCs));
 #pragma unroll
-        for (int q = 0; q < 2; ++q) load_u(ucur, j, q);
+        for (int j = 0; j < 4; ++j) load_u(ucur, j);
 #pragma unroll
-    for (int i = 0; i < WHREGS; ++i) store_window(raw0, i);
-    if (cb + 1 < ce) {
-        window_source(cb + 1);
+        for (int i = 0; i < HR; ++i) store_window(raw0, i);
 #pragma unroll
-        for (int i = 0; i < WHREGS; ++i) load_window(i);
+        for (int i = 0; i < HR; ++i) hreg[i] = h2[i];
 #pragma unroll
-        for (int i = 0; i < WHREGS; ++i) store_window(raw1, i);
+        for (int i = 0; i < HR; ++i) store_window(raw1, i);
     }
     __syncthreads();
-    {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            f32x4 T[4];
+    for (int r = 0; r < R; ++r) {
+        f32x4 T[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const f32x4 da = *reinterpret_cast<const f32x4*>(raw0 + rbase[r] + offa + b * WCK);
-                const f32x4 db = *reinterpret_cast<const f32x4*>(raw0 + rbase[r] + offb + b * WCK);
-                T[b] = da + sgn * db;
-            }
-            A[0][r] = T[0] - T[2];
-            A[1][r] = T[1] + T[2];
-            A[2][r] = T[2] - T[1];
-            A[3][r] = T[1] - T[3];
-        }
+        for (int b = 0; b < 4; ++b) T[b] = rd(raw0, r, 0, b) + sgn * rd(raw0, r, 1, b);
+        A[0][r] = T[0] - T[2];
+        A[1][r] = T[1] + T[2];
+        A[2][r] = T[2] - T[1];
+        A[3][r] = T[1] - T[3];
     }
     __syncthreads();  // raw0 is overwritten with chunk cb + 2 by the first iteration
 
-    // ---- main loop: 64 MFMAs per chunk and wave; everything else is issued from the hooks between them
+    // ---- main loop: NM MFMAs per chunk and wave; everything else is issued from the hooks between them.
+    // The body is ONE basic block (no branch: loads past the end re-read valid memory and are never used), so
+    // sched_barrier pins every hook to its slot.
     for (int c = cb; c < ce; ++c) {
         const bool has1 = c + 1 < ce, has2 = c + 2 < ce;
         const int par = (c - cb) & 1;
@@ -255,80 +268,86 @@ __global__ __launch_bounds__(256, 1) void wino_mfma_kernel(const ConvParams p) {
         float* rawst = par ? raw1 : raw0;       // chunk c was read from here during iteration c - 1: free
         window_source(has2 ? c + 2 : c);
         const float* __restrict__ unext = has1 ? ucur + u_chunk : ucur;  // never reads past the packed weights
-        f32x4 d[8];
-        f32x4 T[2][4];
+        f32x4 T[R][4];
         __builtin_amdgcn_s_setprio(0);
+        if constexpr (R == 2) {
+            f32x4 d[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int m = ((j * 4 + s) * 2 + r) * 2 + q;  // 0..63
+                            acc[j][r][q] =
+                                __builtin_amdgcn_mfma_f32_32x32x2f32(A[j][r][s], U[j][q][s], acc[j][r][q], 0, 0, 0);
+                            if (m < HR) load_window(m);  // chunk c + 2 (or c again at the end: never read)
+                            if (m >= 6 && m < 14) d[m - 6] = rd(rawn, 0, (m - 6) >> 2, (m - 6) & 3);
+                            if (m >= 14 && m < 18) T[0][m - 14] = d[m - 14] + sgn * d[4 + m - 14];
+                            if (m == 16) load_u(unext, 0);  // the MFMAs of j = 0 were issued by m = 15
+                            if (m >= 18 && m < 26) d[m - 18] = rd(rawn, 1, (m - 18) >> 2, (m - 18) & 3);
+                            if (m >= 26 && m < 30) T[1][m - 26] = d[m - 26] + sgn * d[4 + m - 26];
+                            if (m == 30) {
+                                A[0][0] = T[0][0] - T[0][2];
+                                A[0][1] = T[1][0] - T[1][2];
+                            }
+                            if (m == 32) {  // j = 1 done at m = 31
+                                A[1][0] = T[0][1] + T[0][2];
+                                A[1][1] = T[1][1] + T[1][2];
+                            }
+                            if (m == 33) load_u(unext, 1);
+                            if (m == 48) {  // j = 2 done at m = 47
+                                A[2][0] = T[0][2] - T[0][1];
+                                A[2][1] = T[1][2] - T[1][1];
+                            }
+                            if (m == 49) load_u(unext, 2);
+                            if (m >= 56 && m < 56 + HR) store_window(rawst, m - 56);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+            A[3][0] = T[0][1] - T[0][3];
+            A[3][1] = T[1][1] - T[1][3];
+        } else {
+            f32x4 d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        const int m = ((j * 4 + s) * 2 + r) * 2 + q;  // 0..63
-                        acc[j][r][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[j][r][s], U[j][q][s], acc[j][r][q], 0, 0, 0);
-                        if (m < WHREGS) {
-                            if (has2) load_window(m);
-                        }
-                        if (m >= 6 && m < 14) {  // patch rows of tile r = 0
-                            const int k = m - 6;
-                            d[k] = *reinterpret_cast<const f32x4*>(rawn + rbase[0] + (k < 4 ? offa : offb) + (k & 3) * WCK);
-                        }
-                        if (m >= 14 && m < 18) {
-                            const int b = m - 14;
-                            T[0][b] = d[b] + sgn * d[4 + b];
-                        }
-                        if (m == 16) {  // the MFMAs of j = 0 were issued by m = 15: its operands are free
-                            load_u(unext, 0, 0);
-                            load_u(unext, 0, 1);
-                        }
-                        if (m >= 18 && m < 26) {  // tile r = 1
-                            const int k = m - 18;
-                            d[k] = *reinterpret_cast<const f32x4*>(rawn + rbase[1] + (k < 4 ? offa : offb) + (k & 3) * WCK);
-                        }
-                        if (m >= 26 && m < 30) {
-                            const int b = m - 26;
-                            T[1][b] = d[b] + sgn * d[4 + b];
-                        }
-                        if (m == 30) {
+                        const int m = (j * 4 + s) * 2 + q;  // 0..31
+                        acc[j][0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[j][0][s], U[j][q][s], acc[j][0][q], 0, 0, 0);
+                        if (m < HR) load_window(m);
+                        if (m >= 3 && m < 7) d[m - 3] = rd(rawn, 0, (m - 3) & 1, (m - 3) >> 1);  // columns 0, 1
+                        if (m == 8) load_u(unext, 0);  // j = 0 done at m = 7
+                        if (m == 11) T[0][0] = d[0] + sgn * d[1];
+                        if (m == 12) T[0][1] = d[2] + sgn * d[3];
+                        if (m >= 13 && m < 17) d[m - 13] = rd(rawn, 0, (m - 13) & 1, 2 + ((m - 13) >> 1));  // columns 2, 3
+                        if (m == 17) load_u(unext, 1);  // j = 1 done at m = 15
+                        if (m == 21) T[0][2] = d[0] + sgn * d[1];
+                        if (m == 22) {
+                            T[0][3] = d[2] + sgn * d[3];
                             A[0][0] = T[0][0] - T[0][2];
-                            A[0][1] = T[1][0] - T[1][2];
                         }
-                        if (m == 32) {  // j = 1 done at m = 31
-                            A[1][0] = T[0][1] + T[0][2];
-                            A[1][1] = T[1][1] + T[1][2];
-                        }
-                        if (m == 33) {
-                            load_u(unext, 1, 0);
-                            load_u(unext, 1, 1);
-                        }
-                        if (m == 48) {  // j = 2 done at m = 47
-                            A[2][0] = T[0][2] - T[0][1];
-                            A[2][1] = T[1][2] - T[1][1];
-                        }
-                        if (m == 49) {
-                            load_u(unext, 2, 0);
-                            load_u(unext, 2, 1);
-                        }
-                        if (m >= 56 && m < 56 + WHREGS) {
-                            if (has2) store_window(rawst, m - 56);
-                        }
+                        if (m == 23) A[1][0] = T[0][1] + T[0][2];
+                        if (m == 24) load_u(unext, 2);  // j = 2 done at m = 23
+                        if (m == 25) A[2][0] = T[0][2] - T[0][1];
+                        if (m >= 27 && m < 27 + HR) store_window(rawst, m - 27);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-        A[3][0] = T[0][1] - T[0][3];
-        A[3][1] = T[1][1] - T[1][3];
-        load_u(unext, 3, 0);
-        load_u(unext, 3, 1);
+            A[3][0] = T[0][1] - T[0][3];
+        }
+        load_u(unext, 3);
         __builtin_amdgcn_s_setprio(1);
         ucur = unext;
         __syncthreads();
     }
 
     // ---- epilogue: R_i[b] = sum_j M[i][j] A[j][b] per wave, then Y[a][b] = sum_i A^T[a][i] R_i[b] through LDS
-    float* Tb = smem + wave * (2 * 64 * WTS);  // [b][tile][WTS]
+    float* Tb = smem + wave * (2 * TILES * WTS);  // [b][tile][WTS]
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const f32x16 r0 = acc[0][r][q] + acc[1][r][q] + acc[2][r][q];
@@ -337,26 +356,27 @@ __global__ __launch_bounds__(256, 1) void wino_mfma_kernel(const ConvParams p) {
             for (int e = 0; e < 16; ++e) {
                 const int row = r * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 Tb[row * WTS + q * 32 + l31] = r0[e];
-                Tb[(64 + row) * WTS + q * 32 + l31] = r1[e];
+                Tb[(TILES + row) * WTS + q * 32 + l31] = r1[e];
             }
         }
     __syncthreads();
+    constexpr int NR = 8 * R;    // rows (pixels) per lane: wave w finishes tiles [NR*w, NR*w + NR)
     const int rsub = lane >> 4;  // = 2a + b: position of this lane's pixels inside their 2x2 tile
     const int oa = rsub >> 1, ob = rsub & 1;
     const int c4 = (lane & 15) * 4;
     const int cg = n_tile * 64 + c4;
     const bool cvalid = cg < p.Cout;
     const float ysgn = oa ? -1.0f : 1.0f;  // Y[0] = R0 + R1 + R2,  Y[1] = R1 - R2 - R3
-    const float* Y0 = smem + (oa * 2 + ob) * (64 * WTS) + c4;
-    f32x4 v[16];
-    int pixv[16];
+    const float* Y0 = smem + (oa * 2 + ob) * (TILES * WTS) + c4;
+    f32x4 v[NR];
+    int pixv[NR];
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-        const int t = 16 * wave + jj;
+    for (int jj = 0; jj < NR; ++jj) {
+        const int t = NR * wave + jj;
         const float* yp = Y0 + t * WTS;
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(yp);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(yp + 2 * 64 * WTS);
-        const f32x4 a2 = *reinterpret_cast<const f32x4*>(yp + 4 * 64 * WTS);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(yp + 2 * TILES * WTS);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(yp + 4 * TILES * WTS);
         v[jj] = a0 + ysgn * a1 + ysgn * a2;
         const int tx = t & (g.TW - 1);
         const int ty = (t >> g.lTW) & (g.TH - 1);
@@ -371,10 +391,23 @@ __global__ __launch_bounds__(256, 1) void wino_mfma_kernel(const ConvParams p) {
     re.uni = g.NB == 1 || p.ss_stride == 0;
     re.HoWo = p.Ho * p.Wo;
     re.red = nullptr;
-    re.rows_per_wg = 256;
-    re.row_in_wg0 = wave * 64;
+    re.rows_per_wg = 4 * TILES;
+    re.row_in_wg0 = wave * 4 * NR;
     re.wn = 0;
-    rows_epilogue<1>(p, re, v, pixv, cg, cvalid);
+    rows_epilogue<1, NR>(p, re, v, pixv, cg, cvalid);
+}
+
+template <int R>
+static int wino_launch_r(const ConvParams& p, int blocks, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_mfma_kernel<R>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wino_mfma_kernel<R>, dim3(blocks, p.geo.splits, 1), dim3(256), p.geo.lds_bytes, s, p);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int wino_launch(const ConvParams& pin, hipStream_t s) {
@@ -385,18 +418,17 @@ int wino_launch(const ConvParams& pin, hipStream_t s) {
     DM_REQUIRE(!p.in_nchw && !p.out_nchw, "winograd: NHWC only");
     DM_REQUIRE(p.C0 % WCK == 0 && p.C1 % WCK == 0 && p.Cout % 64 == 0, "winograd: channel counts");
     DM_REQUIRE(p.Hin == p.Ho && p.Win == p.Wo, "winograd: same-size convolution");
-    DM_REQUIRE(g.TW * g.TH * g.NB == 64, "winograd: 64 tiles per workgroup");
-    DM_REQUIRE(g.NB * g.IH * g.IW * 2 <= 256 * WHREGS, "winograd: window exceeds staging registers");
+    const int R = g.WM;
+    DM_REQUIRE(R == 1 || R == 2, "winograd: tiles per lane");
+    DM_REQUIRE(g.TW * g.TH * g.NB == 32 * R, "winograd: 32 R tiles per workgroup");
+    DM_REQUIRE(g.NB * g.IH * g.IW * 2 <= 256 * (R == 2 ? 5 : 3), "winograd: window exceeds staging registers");
+    DM_REQUIRE((size_t)p.B * p.Ho * p.Wo < (1u << 24) && p.C0 < (1 << 24) && p.C1 < (1 << 24) &&
+                   (size_t)p.B * p.Ho * p.Wo * std::max(p.C0, p.C1) < (1ull << 31),
+               "winograd: tensor too large for 24-bit pixel indices");
     DM_REQUIRE(!(p.epi & EPI_NORM) || (g.n_tiles_n == 1 && g.splits == 1), "winograd: fused RMSNorm needs one N tile");
     DM_REQUIRE(g.splits == 1 || p.partial, "winograd: split-K writes partial sums");
     DM_REQUIRE(g.lds_bytes <= 160 * 1024, "winograd: tile does not fit LDS");
     DM_REQUIRE(p.chunks0 == p.C0 / WCK && p.n_chunks == (p.C0 + p.C1) / WCK, "winograd: chunk counts");
-    static bool attr_set = false;
-    if (!attr_set) {
-        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_mfma_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     const int blocks = g.n_tiles_n * g.tiles_x * g.tiles_y * g.groups;
     const bool timed = prof::enabled();
     if (timed) {
@@ -408,14 +440,13 @@ int wino_launch(const ConvParams& pin, hipStream_t s) {
         const double bytes = 4.0 * (cin * pix + p.Cout * pix + 9.0 * cin * p.Cout);
         char name[64];
         if (prof::detail())
-            snprintf(name, sizeof(name), "wino 3x3 s1 %d+%d->%d @%dx%d e%d k%d", p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.epi,
-                     g.splits);
+            snprintf(name, sizeof(name), "wino<%d> 3x3 s1 %d+%d->%d @%dx%d e%d k%d", R, p.C0, p.C1, p.Cout, p.Ho, p.Wo,
+                     p.epi, g.splits);
         else
-            snprintf(name, sizeof(name), "wino_mfma_kernel");
+            snprintf(name, sizeof(name), "wino_mfma_kernel<%d>", R);
         if (prof::begin(name, flops, bytes, s)) return 1;
     }
-    hipLaunchKernelGGL(wino_mfma_kernel, dim3(blocks, g.splits, 1), dim3(256), g.lds_bytes, s, p);
-    DM_CHECK_HIP(hipGetLastError());
+    if (R == 2 ? wino_launch_r<2>(p, blocks, s) : wino_launch_r<1>(p, blocks, s)) return 1;
     if (timed && prof::end(s)) return 1;
     return 0;
 }
