@@ -38,6 +38,21 @@ namespace dm {
 static constexpr int WCK = 8;     // input channels per K chunk
 static constexpr int WTS = 68;    // padded row stride of the transposed epilogue tiles (floats)
 
+// tell the compiler a pointer is wave-uniform (keeps it in SGPRs so that loads use the saddr + voffset form)
+using gfloat_ptr = const float __attribute__((address_space(1)))*;   // global address space
+using gf32x4_ptr = const f32x4 __attribute__((address_space(1)))*;
+__device__ __forceinline__ gfloat_ptr uniform_ptr(const float* ptr) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (gfloat_ptr)(((unsigned long long)hi << 32) | lo);
+}
+// base in SGPRs + 32-bit BYTE offset in a VGPR: global_load_dwordx4 v, voff, s[base:base+1]
+__device__ __forceinline__ f32x4 gload4(gfloat_ptr base, unsigned off_floats) {
+    using gchar_ptr = const char __attribute__((address_space(1)))*;
+    return *(gf32x4_ptr)((gchar_ptr)base + (off_floats << 2));
+}
+
 static inline int w_pow2ceil(int v) {
     int p = 1;
     while (p < v) p <<= 1;
@@ -125,7 +140,6 @@ template <int R>
 __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams p) {
     constexpr int TILES = 32 * R;         // Winograd tiles per workgroup
     constexpr int HR = R == 2 ? 5 : 3;    // window staging registers (16 B each) per thread
-    constexpr int NM = 32 * R;            // MFMAs per chunk and wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ConvGeom& g = p.geo;
     const int tid = threadIdx.x;
@@ -165,25 +179,35 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
             const int hy = rem / g.IW;
             const int hx = rem - hy * g.IW;
             const int b = b0 + nb, iy = iy0 + hy, ix = ix0 + hx;
-            hoff[i] = (nb * g.IH + hy) * RS + hx * WCK + 4 * (tid & 1);
-            if (b < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) hpix[i] = (b * p.Hin + iy) * p.Win + ix;
+            const int off = (nb * g.IH + hy) * RS + hx * WCK + 4 * (tid & 1);
+            if (b < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) {
+                hpix[i] = (b * p.Hin + iy) * p.Win + ix;
+                hoff[i] = off;
+            } else {
+                // padding / out-of-batch pixel: zero in both buffers, once; its loads (pixel 0) land in the scratch slot
+                *reinterpret_cast<f32x4*>(raw0 + off) = make_f32x4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<f32x4*>(raw1 + off) = make_f32x4(0.f, 0.f, 0.f, 0.f);
+            }
         }
+        hpix[i] = max(hpix[i], 0);
     }
     f32x4 hreg[HR];
-    const float* __restrict__ hsrc = nullptr;
-    int hCs = 0;
+    // Addresses are (wave-uniform base) + (32-bit lane offset): the loads take the base from SGPRs and need no
+    // 64-bit vector arithmetic.  Pixel index and channel count are < 2^24 (wino_launch checks): one full-rate
+    // v_mul_u32_u24 per address.
+    gfloat_ptr hsrc = nullptr;  // uniform
+    unsigned hCs = 0;
+    const unsigned hq = 4 * (tid & 1);
     auto window_source = [&](int chunk) {
         const bool s1 = chunk >= p.chunks0;
-        hsrc = (s1 ? p.in1 : p.in0) + (s1 ? chunk - p.chunks0 : chunk) * WCK + 4 * (tid & 1);
+        hsrc = uniform_ptr((s1 ? p.in1 : p.in0) + (s1 ? chunk - p.chunks0 : chunk) * WCK);
         hCs = s1 ? p.C1 : p.C0;
     };
-    // pixel index and channel count are < 2^24 (wino_launch checks): one full-rate v_mul_u32_u24 per address
-    auto load_window = [&](int i) {
-        hreg[i] = *reinterpret_cast<const f32x4*>(hsrc + __umul24((unsigned)max(hpix[i], 0), (unsigned)hCs));
+    auto window_value = [&](int i) {
+        return gload4(hsrc, __umul24((unsigned)hpix[i], hCs) + hq);
     };
-    auto store_window = [&](float* raw, int i) {
-        *reinterpret_cast<f32x4*>(raw + hoff[i]) = hpix[i] >= 0 ? hreg[i] : make_f32x4(0.f, 0.f, 0.f, 0.f);
-    };
+    auto load_window = [&](int i) { hreg[i] = window_value(i); };
+    auto store_window = [&](float* raw, int i) { *reinterpret_cast<f32x4*>(raw + hoff[i]) = hreg[i]; };
 
     // ---- input transform of this lane: tiles l31 (and 32 + l31), channel quad lh, row `wave` of B^T d
     int rbase[R];
@@ -207,11 +231,12 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
     f32x4 A[4][R];  // V[wave][j] of tile r: channels 4*lh .. 4*lh+3 of the chunk
     f32x4 U[4][2];  // U[wave*4 + j][cout 32*q + l31][channels 4*lh ..]
     const size_t u_chunk = (size_t)16 * p.Cout * WCK;
-    const float* __restrict__ ucur =
-        p.w + (size_t)cb * u_chunk + ((size_t)(4 * wave) * p.Cout + n_tile * 64 + l31) * WCK + 4 * lh;
-    auto load_u = [&](const float* __restrict__ ub, int j) {
-        U[j][0] = *reinterpret_cast<const f32x4*>(ub + (size_t)j * p.Cout * WCK);
-        U[j][1] = *reinterpret_cast<const f32x4*>(ub + ((size_t)j * p.Cout + 32) * WCK);
+    const float* __restrict__ ucur =  // uniform
+        p.w + (size_t)cb * u_chunk + ((size_t)(4 * wave) * p.Cout + n_tile * 64) * WCK;
+    const unsigned ulane = l31 * WCK + 4 * lh;
+    auto load_u = [&](gfloat_ptr ub, int j) {
+        U[j][0] = gload4(ub + (size_t)j * p.Cout * WCK, ulane);
+        U[j][1] = gload4(ub + ((size_t)j * p.Cout + 32) * WCK, ulane);
     };
 
     f32x16 acc[4][R][2];
@@ -235,9 +260,9 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
         window_source(two ? cb + 1 : cb);
 #pragma unroll
         for (int i = 0; i < HR; ++i)
-            h2[i] = *reinterpret_cast<const f32x4*>(hsrc + __umul24((unsigned)max(hpix[i], 0), (unsigned)hCs));
+            h2[i] = window_value(i);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) load_u(ucur, j);
+        for (int j = 0; j < 4; ++j) load_u(uniform_ptr(ucur), j);
 #pragma unroll
         for (int i = 0; i < HR; ++i) store_window(raw0, i);
 #pragma unroll
@@ -267,7 +292,8 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
         const float* rawn = par ? raw0 : raw1;  // chunk c + 1 (stored during iteration c - 1 / the prologue)
         float* rawst = par ? raw1 : raw0;       // chunk c was read from here during iteration c - 1: free
         window_source(has2 ? c + 2 : c);
-        const float* __restrict__ unext = has1 ? ucur + u_chunk : ucur;  // never reads past the packed weights
+        const float* unext_g = has1 ? ucur + u_chunk : ucur;  // never reads past the packed weights
+        gfloat_ptr unext = uniform_ptr(unext_g);
         f32x4 T[R][4];
         __builtin_amdgcn_s_setprio(0);
         if constexpr (R == 2) {
@@ -340,7 +366,7 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
         }
         load_u(unext, 3);
         __builtin_amdgcn_s_setprio(1);
-        ucur = unext;
+        ucur = unext_g;
         __syncthreads();
     }
 
@@ -423,7 +449,7 @@ int wino_launch(const ConvParams& pin, hipStream_t s) {
     DM_REQUIRE(g.TW * g.TH * g.NB == 32 * R, "winograd: 32 R tiles per workgroup");
     DM_REQUIRE(g.NB * g.IH * g.IW * 2 <= 256 * (R == 2 ? 5 : 3), "winograd: window exceeds staging registers");
     DM_REQUIRE((size_t)p.B * p.Ho * p.Wo < (1u << 24) && p.C0 < (1 << 24) && p.C1 < (1 << 24) &&
-                   (size_t)p.B * p.Ho * p.Wo * std::max(p.C0, p.C1) < (1ull << 31),
+                   (size_t)p.B * p.Ho * p.Wo * std::max(p.C0, p.C1) < (1ull << 30),
                "winograd: tensor too large for 24-bit pixel indices");
     DM_REQUIRE(!(p.epi & EPI_NORM) || (g.n_tiles_n == 1 && g.splits == 1), "winograd: fused RMSNorm needs one N tile");
     DM_REQUIRE(g.splits == 1 || p.partial, "winograd: split-K writes partial sums");
