@@ -31,6 +31,37 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
+// In-kernel cycle stamps: DIAGNOSTIC build only (make STAMPS=1 -> libdm_hip_stamps.so, tools/conv_stamps.py).
+// Wave 0 of every workgroup sums the s_memtime cycles it spends per phase into p.stamps[block][8]; nothing
+// the kernel outputs depends on them.  In the shipped library every macro below is empty.
+#ifdef DM_STAMPS
+__device__ __forceinline__ unsigned long long dm_stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define DM_STAMP_DECL unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DM_STAMP(k) st_prev = dm_stamp_now();
+#define DM_STAMP_ADD(k)                              \
+    {                                                \
+        unsigned long long st_now = dm_stamp_now();  \
+        st_acc[k] += st_now - st_prev;               \
+        st_prev = st_now;                            \
+    }
+#define DM_STAMP_FLUSH                                                                              \
+    if (threadIdx.x == 0 && p.stamps) {                                                             \
+        unsigned long long* sp_ = p.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;     \
+        for (int k_ = 0; k_ < 8; ++k_) sp_[k_] = st_acc[k_];                                        \
+    }
+#else
+#define DM_STAMP_DECL
+#define DM_STAMP(k)
+#define DM_STAMP_ADD(k)
+#define DM_STAMP_FLUSH
+#endif
+
 // Row-layout epilogue shared by the convolution kernels.  A wave holds 64 output pixels x 64 consecutive couts
 // (NR = 16; 32 pixels for NR = 8) as v[j] = the 4 couts [cg, cg+4) of pixel row 4*j + (lane>>4); the 16 lanes
 // of a DPP row cover one pixel.
@@ -50,9 +81,51 @@ struct RowsEpilogue {
     int wn;
 };
 
-template <int WN, int NR = 16>
+// Everything the epilogue reads from global memory, fetched BEFORE the accumulators go through LDS so that the
+// HBM/L2 latency (bias, g, scale/shift, the residual rows) overlaps the transposition instead of following it.
+// RES = false leaves the residual rows to the point of use (for callers without the registers to hold them).
+template <int NR, bool RES = true>
+struct RowsPrefetch {
+    f32x4 b4, g4, sc, sh;
+    f32x4 res[RES ? NR : 1];
+};
+
+template <int NR, bool RES>
+__device__ __forceinline__ void rows_prefetch(const ConvParams& p, const RowsEpilogue& e, const int (&pixv)[NR], int cg,
+                                              bool cvalid, RowsPrefetch<NR, RES>& f) {
+    const f32x4 zero4 = make_f32x4(0.f, 0.f, 0.f, 0.f);
+    f.b4 = zero4;
+    f.g4 = zero4;
+    f.sc = zero4;
+    f.sh = zero4;
+    if constexpr (RES) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) f.res[j] = zero4;
+    }
+    if (p.partial) return;
+    const int epi = p.epi;
+    if ((epi & EPI_BIAS) && cvalid) f.b4 = *reinterpret_cast<const f32x4*>(p.bias + cg);
+    if ((epi & EPI_NORM) && cvalid) f.g4 = *reinterpret_cast<const f32x4*>(p.g + cg);
+    if ((epi & EPI_SCALE_SHIFT) && e.uni && cvalid) {
+        const float* sp = p.scale + (size_t)min(e.b0, p.B - 1) * p.ss_stride;
+        f.sc = *reinterpret_cast<const f32x4*>(sp + cg);  // raw scale: nothing here may USE a loaded value
+        f.sh = *reinterpret_cast<const f32x4*>(sp + p.Cout + cg);
+    }
+    if constexpr (RES) {
+        if (epi & EPI_RESIDUAL) {
+            // unconditional loads (rows outside the tensor read row 0 and are never stored): no per-row branches
+            const int cgc = cvalid ? cg : 0;
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+                f.res[j] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)max(pixv[j], 0) * p.Cout + cgc);
+        }
+    }
+}
+
+template <int WN, int NR, bool RES>
 __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpilogue& e, f32x4 (&v)[NR],
-                                              const int (&pixv)[NR], int cg, bool cvalid) {
+                                              const int (&pixv)[NR], int cg, bool cvalid,
+                                              const RowsPrefetch<NR, RES>& f) {
     const int lane = threadIdx.x & 63;
     const int rsub = lane >> 4;
     if (p.partial) {
@@ -64,13 +137,11 @@ __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpi
     }
     const int epi = p.epi;
     const f32x4 zero4 = make_f32x4(0.f, 0.f, 0.f, 0.f);
-    f32x4 b4 = zero4;
-    if ((epi & EPI_BIAS) && cvalid) b4 = *reinterpret_cast<const f32x4*>(p.bias + cg);
 #pragma unroll
-    for (int j = 0; j < NR; ++j) v[j] = cvalid ? v[j] + b4 : zero4;
+    for (int j = 0; j < NR; ++j) v[j] = cvalid ? v[j] + f.b4 : zero4;
     if (epi & EPI_NORM) {
         const float sqrtc = sqrtf((float)p.Cout);
-        f32x4 g4 = cvalid ? *reinterpret_cast<const f32x4*>(p.g + cg) * sqrtc : zero4;
+        const f32x4 g4 = f.g4 * sqrtc;
         float ssv[NR];
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
@@ -101,12 +172,7 @@ __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpi
         for (int j = 0; j < NR; ++j) v[j] = v[j] * (fast_rsq(fmaxf(ssv[j], 1e-24f))) * g4;
     }
     if (epi & EPI_SCALE_SHIFT) {
-        f32x4 sc = make_f32x4(1.f, 1.f, 1.f, 1.f), sh = zero4;
-        if (e.uni && cvalid) {
-            const float* sp = p.scale + (size_t)min(e.b0, p.B - 1) * p.ss_stride;
-            sc = *reinterpret_cast<const f32x4*>(sp + cg) + 1.0f;
-            sh = *reinterpret_cast<const f32x4*>(sp + p.Cout + cg);
-        }
+        f32x4 sc = f.sc + 1.0f, sh = f.sh;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             if (!e.uni && cvalid && pixv[j] >= 0) {
@@ -130,9 +196,13 @@ __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpi
     for (int j = 0; j < NR; ++j) {
         if (pixv[j] < 0 || !cvalid) continue;
         const size_t o = (size_t)pixv[j] * p.Cout + cg;
-        f32x4 r4 = v[j];
-        if (epi & EPI_RESIDUAL) r4 += *reinterpret_cast<const f32x4*>(p.residual + o);
-        *reinterpret_cast<f32x4*>(p.out + o) = r4;
+        if constexpr (RES) {
+            *reinterpret_cast<f32x4*>(p.out + o) = v[j] + f.res[j];
+        } else {
+            f32x4 r4 = v[j];
+            if (epi & EPI_RESIDUAL) r4 += *reinterpret_cast<const f32x4*>(p.residual + o);
+            *reinterpret_cast<f32x4*>(p.out + o) = r4;
+        }
     }
 }
 

@@ -34,37 +34,6 @@
 
 namespace dm {
 
-// In-kernel cycle stamps: DIAGNOSTIC build only (make STAMPS=1 -> libdm_hip_stamps.so, tools/conv_stamps.py).
-// Wave 0 of every workgroup sums the s_memtime cycles it spends per phase into p.stamps[block][8]; nothing
-// the kernel outputs depends on them.  In the shipped library every macro below is empty.
-#ifdef DM_STAMPS
-__device__ __forceinline__ unsigned long long dm_stamp_now() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#define DM_STAMP_DECL unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define DM_STAMP(k) st_prev = dm_stamp_now();
-#define DM_STAMP_ADD(k)                              \
-    {                                                \
-        unsigned long long st_now = dm_stamp_now();  \
-        st_acc[k] += st_now - st_prev;               \
-        st_prev = st_now;                            \
-    }
-#define DM_STAMP_FLUSH                                                                              \
-    if (threadIdx.x == 0 && p.stamps) {                                                             \
-        unsigned long long* sp_ = p.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;     \
-        for (int k_ = 0; k_ < 8; ++k_) sp_[k_] = st_acc[k_];                                        \
-    }
-#else
-#define DM_STAMP_DECL
-#define DM_STAMP(k)
-#define DM_STAMP_ADD(k)
-#define DM_STAMP_FLUSH
-#endif
-
 static inline int pow2ceil(int v) {
     int p = 1;
     while (p < v) p <<= 1;
@@ -682,26 +651,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         // per-cout vectors (bias, g, scale, shift) are one float4 per lane.
         if (!p.out_nchw && (p.Cout & 3) == 0) {
             constexpr int TS = 68;  // padded row stride (floats): conflict-free b32 writes and b128 reads
-            float* T = smem + wave * (64 * TS);
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        T[(r * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * TS + q * 32 + l31] = acc[r][q][e];
-            __builtin_amdgcn_wave_barrier();
             const int rsub = lane >> 4;          // row within a group of 4
             const int c4 = (lane & 15) * 4;      // first of this lane's 4 couts inside the tile
             const int cg = n_tile * NT + wn * 64 + c4;  // global cout
             const bool cvalid = cg < p.Cout;
-            f32x4 v[16];
             int pixv[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                v[j] = *reinterpret_cast<const f32x4*>(T + (4 * j + rsub) * TS + c4);
-                pixv[j] = ptab[wm * 64 + 4 * j + rsub];
-            }
+            for (int j = 0; j < 16; ++j) pixv[j] = ptab[wm * 64 + 4 * j + rsub];
             RowsEpilogue re;
             re.split = split;
             re.M = (size_t)p.B * p.Ho * p.Wo * (p.fold ? 4 : 1);
@@ -712,7 +668,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
             re.rows_per_wg = 64 * WM;
             re.row_in_wg0 = wm * 64;
             re.wn = wn;
-            rows_epilogue<WN>(p, re, v, pixv, cg, cvalid);
+            float* T = smem + wave * (64 * TS);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        T[(r * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * TS + q * 32 + l31] = acc[r][q][e];
+            __builtin_amdgcn_wave_barrier();
+            f32x4 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const f32x4*>(T + (4 * j + rsub) * TS + c4);
+            // the per-cout operands of the epilogue are requested together, ahead of their use
+            RowsPrefetch<16, false> pf;
+            rows_prefetch<16, false>(p, re, pixv, cg, cvalid, pf);
+            rows_epilogue<WN, 16, false>(p, re, v, pixv, cg, cvalid, pf);
             DM_STAMP_ADD(6)
             DM_STAMP_FLUSH
             return;

@@ -349,8 +349,7 @@ struct Ctx {
 // policy: which eligible layers take the Winograd kernel (DM_WINO=0 none, 1 all)
 static bool wino_use(int B, int Ho, int Wo, int Cout, int C0, int C1) {
     static const int mode = std::getenv("DM_WINO") ? std::atoi(std::getenv("DM_WINO")) : 1;
-    (void)B; (void)Ho; (void)Wo; (void)Cout; (void)C0; (void)C1;
-    return mode != 0;
+    return mode != 0 && wino_shape_ok(B, Ho, Wo, Cout, C0, C1);
 }
 
 static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* in1, int Hin, int Win, float* out,
@@ -392,8 +391,7 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
                           !out_nchw);
     }
     // 3x3 / stride 1 convolutions run as Winograd F(2x2,3x3) when the layer has transformed weights
-    const bool wino = L.ww && !L.fold && !in_nchw && !out_nchw && (p.Ho % 2 == 0) && (p.Wo % 2 == 0) &&
-                      wino_use(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
+    const bool wino = L.ww && !L.fold && !in_nchw && !out_nchw && wino_use(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
     if (wino) {
         p.w = L.ww;
         p.chunks0 = L.C0 / 8;

@@ -117,7 +117,6 @@ ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_s
     g.IW = 2 * g.TW + 2;
     g.row_stride = g.IW * WCK + 4;  // +4: rows of consecutive tile rows start 8 banks apart mod 16
     g.halo_floats = g.NB * g.IH * g.row_stride;
-    g.w_floats = 0;
     g.TPS = 3;
     const int n_chunks = (C0 + C1) / WCK;
     const int wgs = g.tiles_x * g.tiles_y * g.groups * g.n_tiles_n;
@@ -131,9 +130,18 @@ ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_s
     g.splits = (n_chunks + g.chunks_per_split - 1) / g.chunks_per_split;
     g.fused_norm = g.n_tiles_n == 1 && g.splits == 1;
     g.ptab_off = 0;
+    g.w_floats = 0;
     // two windows + a scratch slot reachable from both; the epilogue reuses the space for 4 x 2 transposed tiles
     g.lds_bytes = std::max(3 * g.halo_floats + 4, 4 * 2 * tiles * WTS) * 4;
     return g;
+}
+
+bool wino_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1) {
+    if ((Ho | Wo) & 1) return false;
+    const ConvGeom g = wino_plan(B, Ho, Wo, Cout, C0, C1, true);
+    // the window of one tile block must fit the staging registers (very small images pack too many per block)
+    return g.NB * g.IH * g.IW * 2 <= 256 * (g.WM == 2 ? 5 : 3) && g.lds_bytes <= 160 * 1024 &&
+           (size_t)B * Ho * Wo < (1u << 24) && (size_t)B * Ho * Wo * std::max(C0, C1) < (1ull << 30);
 }
 
 template <int R>
@@ -160,6 +168,8 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
     const int split = blockIdx.y;
     const int cb = split * g.chunks_per_split;
     const int ce = min(cb + g.chunks_per_split, p.n_chunks);
+    DM_STAMP_DECL
+    DM_STAMP(0);
     const int RS = g.row_stride;
     float* raw0 = smem;
     float* raw1 = smem + g.halo_floats;
@@ -282,6 +292,7 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
         A[3][r] = T[1] - T[3];
     }
     __syncthreads();  // raw0 is overwritten with chunk cb + 2 by the first iteration
+    DM_STAMP_ADD(0)
 
     // ---- main loop: NM MFMAs per chunk and wave; everything else is issued from the hooks between them.
     // The body is ONE basic block (no branch: loads past the end re-read valid memory and are never used), so
@@ -370,40 +381,20 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
         __syncthreads();
     }
 
-    // ---- epilogue: R_i[b] = sum_j M[i][j] A[j][b] per wave, then Y[a][b] = sum_i A^T[a][i] R_i[b] through LDS
-    float* Tb = smem + wave * (2 * TILES * WTS);  // [b][tile][WTS]
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const f32x16 r0 = acc[0][r][q] + acc[1][r][q] + acc[2][r][q];
-            const f32x16 r1 = acc[1][r][q] - acc[2][r][q] - acc[3][r][q];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = r * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                Tb[row * WTS + q * 32 + l31] = r0[e];
-                Tb[(TILES + row) * WTS + q * 32 + l31] = r1[e];
-            }
-        }
-    __syncthreads();
-    constexpr int NR = 8 * R;    // rows (pixels) per lane: wave w finishes tiles [NR*w, NR*w + NR)
-    const int rsub = lane >> 4;  // = 2a + b: position of this lane's pixels inside their 2x2 tile
+    DM_STAMP_ADD(1)
+    // ---- epilogue: R_i[b] = sum_j M[i][j] A[j][b] per wave, then Y[a][b] = sum_i A^T[a][i] R_i[b] through LDS.
+    // Wave w finishes tiles [NR*w, NR*w + NR): lane group rsub = 2a + b owns pixel (a, b) of each tile.  What
+    // the epilogue needs from global memory is requested first.
+    constexpr int NR = 8 * R;
+    const int rsub = lane >> 4;
     const int oa = rsub >> 1, ob = rsub & 1;
     const int c4 = (lane & 15) * 4;
     const int cg = n_tile * 64 + c4;
     const bool cvalid = cg < p.Cout;
-    const float ysgn = oa ? -1.0f : 1.0f;  // Y[0] = R0 + R1 + R2,  Y[1] = R1 - R2 - R3
-    const float* Y0 = smem + (oa * 2 + ob) * (TILES * WTS) + c4;
-    f32x4 v[NR];
     int pixv[NR];
 #pragma unroll
     for (int jj = 0; jj < NR; ++jj) {
         const int t = NR * wave + jj;
-        const float* yp = Y0 + t * WTS;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(yp);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(yp + 2 * TILES * WTS);
-        const f32x4 a2 = *reinterpret_cast<const f32x4*>(yp + 4 * TILES * WTS);
-        v[jj] = a0 + ysgn * a1 + ysgn * a2;
         const int tx = t & (g.TW - 1);
         const int ty = (t >> g.lTW) & (g.TH - 1);
         const int nb = t >> (g.lTW + g.lTH);
@@ -420,7 +411,39 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
     re.rows_per_wg = 4 * TILES;
     re.row_in_wg0 = wave * 4 * NR;
     re.wn = 0;
-    rows_epilogue<1, NR>(p, re, v, pixv, cg, cvalid);
+    RowsPrefetch<NR, true> pf;
+    rows_prefetch<NR, true>(p, re, pixv, cg, cvalid, pf);
+
+    float* Tb = smem + wave * (2 * TILES * WTS);  // [b][tile][WTS]
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x16 r0 = acc[0][r][q] + acc[1][r][q] + acc[2][r][q];
+            const f32x16 r1 = acc[1][r][q] - acc[2][r][q] - acc[3][r][q];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = r * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                Tb[row * WTS + q * 32 + l31] = r0[e];
+                Tb[(TILES + row) * WTS + q * 32 + l31] = r1[e];
+            }
+        }
+    __syncthreads();
+    DM_STAMP_ADD(2)
+    const float ysgn = oa ? -1.0f : 1.0f;  // Y[0] = R0 + R1 + R2,  Y[1] = R1 - R2 - R3
+    const float* Y0 = smem + (oa * 2 + ob) * (TILES * WTS) + c4;
+    f32x4 v[NR];
+#pragma unroll
+    for (int jj = 0; jj < NR; ++jj) {
+        const float* yp = Y0 + (NR * wave + jj) * WTS;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(yp);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(yp + 2 * TILES * WTS);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(yp + 4 * TILES * WTS);
+        v[jj] = a0 + ysgn * a1 + ysgn * a2;
+    }
+    rows_epilogue<1, NR, true>(p, re, v, pixv, cg, cvalid, pf);
+    DM_STAMP_ADD(3)
+    DM_STAMP_FLUSH
 }
 
 template <int R>
@@ -431,6 +454,30 @@ static int wino_launch_r(const ConvParams& p, int blocks, hipStream_t s) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+#ifdef DM_STAMPS
+    // diagnostic build: run the launch synchronously with a stamp buffer and print the phase averages
+    {
+        const size_t nblk = (size_t)blocks * p.geo.splits;
+        unsigned long long* dbuf = nullptr;
+        DM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), nblk * 8 * sizeof(unsigned long long)));
+        DM_CHECK_HIP(hipMemsetAsync(dbuf, 0, nblk * 8 * sizeof(unsigned long long), s));
+        ConvParams ps = p;
+        ps.stamps = dbuf;
+        hipLaunchKernelGGL(wino_mfma_kernel<R>, dim3(blocks, p.geo.splits, 1), dim3(256), p.geo.lds_bytes, s, ps);
+        DM_CHECK_HIP(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h(nblk * 8);
+        DM_CHECK_HIP(hipMemcpy(h.data(), dbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        (void)hipFree(dbuf);
+        double avg[8] = {0};
+        for (size_t b = 0; b < nblk; ++b)
+            for (int k = 0; k < 8; ++k) avg[k] += (double)h[b * 8 + k] / nblk;
+        fprintf(stderr, "STAMPS wino<%d> %d+%d->%d @%dx%d e%d k%d chunks %d: wgs=%zu | prologue %.0f loop %.0f (%.0f/chunk) "
+                        "reduce %.0f epilogue %.0f\n",
+                R, p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.epi, p.geo.splits, p.geo.chunks_per_split, nblk, avg[0], avg[1],
+                avg[1] / p.geo.chunks_per_split, avg[2], avg[3]);
+        return 0;
+    }
+#endif
     hipLaunchKernelGGL(wino_mfma_kernel<R>, dim3(blocks, p.geo.splits, 1), dim3(256), p.geo.lds_bytes, s, p);
     DM_CHECK_HIP(hipGetLastError());
     return 0;

@@ -61,6 +61,16 @@ CONV_CASES = [
     (2, 16, 0, 24, 24, 16, 3, 1, False, True, False),     # non power-of-two image (masked tile)
     (2, 48, 16, 12, 12, 48, 3, 1, False, True, False),    # odd sizes, concat
     (1, 6, 0, 8, 8, 8, 3, 1, False, True, False),         # channels not a multiple of 4
+    # Winograd F(2x2,3x3) path (3x3, C % 8 == 0, Cout % 64 == 0, even size); the cases above with those
+    # properties take it too
+    (3, 72, 8, 12, 20, 64, 3, 1, False, True, True),      # non power-of-two even image, masked tiles, concat 72+8
+    (37, 64, 0, 4, 4, 128, 3, 1, False, False, False),    # 8 images per workgroup, ragged batch, no bias
+    (2, 8, 0, 6, 2, 64, 3, 1, False, True, False),        # single K chunk, image narrower than a tile row
+    (2, 1024, 0, 4, 4, 64, 3, 1, False, True, False),     # Winograd with K split 8 ways (partial sums + finalize)
+    (1, 1024, 0, 2, 2, 64, 3, 1, False, True, False),     # 2x2 image: window too large for Winograd -> direct kernel
+    # the direct 3x3 kernel behind it (odd sizes are not Winograd-eligible)
+    (2, 64, 64, 7, 9, 64, 3, 1, False, True, True),
+    (3, 256, 0, 5, 5, 256, 3, 1, False, True, False),
 ]
 
 
@@ -122,6 +132,11 @@ BLOCK_CASES = [
     (5, 256, 256, 4, 4, True),     # NB=4 images per tile, per-image scale/shift, ragged
     (2, 768, 512, 4, 4, True),     # Cout > 256: conv + separate norm kernel
     (2, 32, 48, 8, 8, True),       # Cout not a multiple of 32
+    (5, 64, 64, 4, 4, True),       # Winograd, 8 images per workgroup: per-image scale/shift rows inside one tile
+    (3, 64, 64, 12, 10, True),     # Winograd fused epilogue on masked tiles
+    (2, 64, 64, 7, 9, True),       # direct kernel, fused epilogue (odd size)
+    (2, 128, 128, 5, 5, False),    # direct kernel, 2x2 wave grid
+    (2, 192, 256, 3, 3, True),     # direct kernel, 1x4 wave grid
 ]
 
 
