@@ -124,6 +124,8 @@ struct AttnLayer {
     int dim = 0;
     float *norm_g = nullptr, *mem_kv = nullptr, *out_g = nullptr;
     ConvLayer qkv, out;
+    bool has_fused = false;  // LinearAttention as two fused kernels (linattn_fused.hip)
+    LinAttnFused fused{};
 };
 
 struct CrossLayer {
@@ -320,6 +322,23 @@ static int build_attn(dm_unet* u, AttnLayer& A, const std::string& p, int dim, b
         if (make_conv(u->own, A.out, P(u, p + ".to_out.0.weight").data.data(), P(u, p + ".to_out.0.bias").data.data(),
                       dim, hidden, 0, 1, 1, 1, 0, false)) return 1;
         if (up1(u, p + ".to_out.1.g", &A.out_g)) return 1;
+        if (linattn_fused_eligible(dim, u->heads, u->dh)) {
+            std::vector<float> wq, wk, wv, wo, kb;
+            const HostTensor& og = P(u, p + ".to_out.1.g");
+            if (linattn_fused_pack(P(u, p + ".to_qkv.weight").data.data(), P(u, p + ".norm.g").data.data(),
+                                   P(u, p + ".to_out.0.weight").data.data(), P(u, p + ".mem_kv").data.data(), dim, wq,
+                                   wk, wv, wo, kb)) {
+                std::vector<float> ogs(og.data);
+                for (float& v : ogs) v *= std::sqrt((float)dim);
+                float *dq, *dk, *dv, *dwo, *dkb, *dog;
+                if (u->own.upload(wq.data(), wq.size(), &dq) || u->own.upload(wk.data(), wk.size(), &dk) ||
+                    u->own.upload(wv.data(), wv.size(), &dv) || u->own.upload(wo.data(), wo.size(), &dwo) ||
+                    u->own.upload(kb.data(), kb.size(), &dkb) || u->own.upload(ogs.data(), ogs.size(), &dog))
+                    return 1;
+                A.fused = LinAttnFused{dim, dq, dk, dv, dwo, A.out.bias, dog, dkb, A.mem_kv};
+                A.has_fused = true;
+            }
+        }
     }
     return 0;
 }
@@ -448,6 +467,13 @@ static int run_attn(Ctx& c, const AttnLayer& At, const float* x, int H, int W, f
     dm_unet* u = c.u;
     const int n = H * W, hidden = u->heads * u->dh;
     const size_t rows = (size_t)c.B * n;
+    if (!At.full && At.has_fused) {
+        float* ws = c.A->alloc(linattn_fused_ws_floats(c.B, n));
+        float* yf = c.A->alloc(rows * At.dim);
+        if (!c.dry() && launch_linattn_fused(At.fused, x, ws, yf, c.B, n, add_x, c.s)) return 1;
+        *out = yf;
+        return 0;
+    }
     float* xn = c.A->alloc(rows * At.dim);
     float* qkv = c.A->alloc(rows * 3 * hidden);
     float* o = c.A->alloc(rows * hidden);

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 namespace dm {
 
@@ -171,5 +172,26 @@ int launch_linear_attention_core(const float* qkv, const float* mem_kv, float* c
 int launch_attention_core(const float* q, int ldq, const float* k, const float* v, int ldk, const float* mem_k,
                           const float* mem_v, int n_mem, float* out, int ldo, int B, int nq, int nk, int heads,
                           int dh, float scale, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// Fused LinearAttention (linattn_fused.hip): RMSNorm + to_qkv + both softmaxes + context + to_out + RMSNorm (+ x)
+// in two kernels; heads == 4, dim_head == 32, C in {64, 128}
+// ---------------------------------------------------------------------------------------
+struct LinAttnFused {
+    int C;
+    const float *wq, *wk, *wv;  // packed projections with the RMSNorm gain folded in
+    const float* wo;            // packed to_out weight
+    const float* bias;          // to_out bias [C]
+    const float* og;            // to_out RMSNorm gain * sqrt(C) [C]
+    const float* kbound;        // softmax shift per (head, d) [128]
+    const float* mem_kv;        // (2, heads, 32, 4)
+};
+bool linattn_fused_eligible(int C, int heads, int dh);
+bool linattn_fused_pack(const float* w_qkv, const float* norm_g, const float* w_out, const float* mem_kv, int C,
+                        std::vector<float>& wq, std::vector<float>& wk, std::vector<float>& wv, std::vector<float>& wo,
+                        std::vector<float>& kbound);
+size_t linattn_fused_ws_floats(int B, int n);
+int launch_linattn_fused(const LinAttnFused& w, const float* x, float* ws, float* y, int B, int n, bool add_x,
+                         hipStream_t s);
 
 }  // namespace dm

@@ -176,7 +176,9 @@ def _attn_sd(Cc, full, heads=4, dh=32, seed=10):
     return sd
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 32, 32), (2, 64, 16, 16), (3, 128, 8, 8), (1, 256, 8, 8), (2, 32, 6, 10)])
+# C in {64, 128} take the two fused kernels (linattn_fused.hip), the others the unfused chain of kernels
+@pytest.mark.parametrize("shape", [(2, 64, 32, 32), (2, 64, 16, 16), (3, 128, 8, 8), (1, 256, 8, 8), (2, 32, 6, 10),
+                                   (2, 64, 6, 10), (3, 128, 16, 16), (1, 64, 2, 2), (2, 128, 18, 14)])
 def test_linear_attention(shape):
     B, Cc, H, W = shape
     x = seeded(shape, 1)
