@@ -11,6 +11,7 @@
 //      invariant to the shift, so the bound replaces the running maximum: no max pass over the tokens, and partial
 //      sums of different token blocks simply add.  (Layers whose bound exceeds 40 -- exp(-2*bound) must stay a
 //      normal float -- keep the unfused path.)
+//   (a tiny kernel sums the block partials, divides by the denominators and packs the context in lane order)
 //   2. linattn_out_fused_kernel   (token block, image): q = W_q x^, softmax over dim_head, out = ctx^T q,
 //      z = W_out out + b, RMSNorm(z) * g, + x, one store.
 //
@@ -92,7 +93,8 @@ bool linattn_fused_pack(const float* w_qkv, const float* norm_g, const float* w_
 
 size_t linattn_fused_ws_floats(int B, int n) {
     const int nblk = (n + LA_TOK1 - 1) / LA_TOK1;
-    return (size_t)B * nblk * LA_HEADS * LA_CTX;
+    // per-block partial contexts, then the normalised context packed as the A operand of kernel 2
+    return (size_t)B * nblk * LA_HEADS * LA_CTX + (size_t)B * LA_HEADS * LA_DH * LA_DH;
 }
 
 // x rows [t0, t0 + TOK) of image b -> LDS (zero rows past the image), rn[t] = 1 / max(||x_t||, 1e-12)
@@ -199,10 +201,32 @@ __global__ __launch_bounds__(256) void linattn_ctx_fused_kernel(const float* __r
     if (lh == 0) cp[LA_DH * LA_DH + l31] = ksum;
 }
 
+// Sum the per-block partial contexts in block order, divide by the softmax denominator (k.softmax(dim=-1), :186) and
+// store the result in the lane order kernel 2 consumes: [image][head][e>>2][lane][e&3] = ctx[row_of(e, half)][l].
+__global__ __launch_bounds__(256) void linattn_ctx_reduce_kernel(const float* __restrict__ ws, float* __restrict__ ctxn,
+                                                                 int nblk) {
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, e4 = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int d = la_row_of(4 * e4 + i, lh);
+        float cs = 0.f, ks = 0.f;
+        for (int k = 0; k < nblk; ++k) {
+            const float* cp = ws + (((size_t)b * nblk + k) * LA_HEADS + h) * LA_CTX;
+            cs += cp[d * LA_DH + l31];
+            ks += cp[LA_DH * LA_DH + d];
+        }
+        o[i] = cs / ks;
+    }
+    *reinterpret_cast<f32x4*>(ctxn + ((((size_t)b * LA_HEADS + h) * 4 + e4) * 64 + lane) * 4) = o;
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void linattn_out_fused_kernel(const float* __restrict__ x, const LinAttnFused w,
-                                                                const float* __restrict__ ws, float* __restrict__ y,
-                                                                int n, int nblk, int add_x, float scale) {
+                                                                const float* __restrict__ ctxn, float* __restrict__ y,
+                                                                int n, int add_x, float scale) {
     constexpr int G = C / 8, XS = C + 4, TOK = LA_TOK2, MT = C / 32, Q = C / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                  // [TOK][XS]
@@ -219,24 +243,11 @@ __global__ __launch_bounds__(256) void linattn_out_fused_kernel(const float* __r
     for (int g = 0; g < G; ++g) wq[g] = *reinterpret_cast<const f32x4*>(w.wq + (((size_t)h * G + g) * 64 + lane) * 4);
     // normalised context as the A operand of out = ctx^T q: step e reduces over d = row_of(e, half)
     float actx[16];
-    {
-        float cs[16], ks[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            cs[e] = 0.f;
-            ks[e] = 0.f;
-        }
-        for (int k = 0; k < nblk; ++k) {
-            const float* cp = ws + (((size_t)b * nblk + k) * LA_HEADS + h) * LA_CTX;
+    for (int e4 = 0; e4 < 4; ++e4) {
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(ctxn + ((((size_t)b * LA_HEADS + h) * 4 + e4) * 64 + lane) * 4);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int d = la_row_of(e, lh);
-                cs[e] += cp[d * LA_DH + l31];
-                ks[e] += cp[LA_DH * LA_DH + d];
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) actx[e] = cs[e] / ks[e];
+        for (int i = 0; i < 4; ++i) actx[4 * e4 + i] = c4[i];
     }
     la_stage_rows<C, TOK>(x + ((size_t)b * n + t0) * C, nt, xs, rn);
     __syncthreads();
@@ -340,11 +351,14 @@ static int launch_c(const LinAttnFused& w, const float* x, float* ws, float* y, 
     hipLaunchKernelGGL(linattn_ctx_fused_kernel<C>, dim3(nblk, B), dim3(256), lds1, s, x, w, ws, n, nblk);
     DM_CHECK_HIP(hipGetLastError());
     if (timed && prof::end(s)) return 1;
+    float* ctxn = ws + (size_t)B * nblk * LA_HEADS * LA_CTX;
+    hipLaunchKernelGGL(linattn_ctx_reduce_kernel, dim3(LA_HEADS, B), dim3(256), 0, s, ws, ctxn, nblk);
+    DM_CHECK_HIP(hipGetLastError());
     if (timed && prof::begin("linattn_out_fused_kernel", 2.0 * tokens * (2.0 * LA_HID * C + LA_HID * LA_DH),
                              8.0 * tokens * C, s))
         return 1;
-    hipLaunchKernelGGL(linattn_out_fused_kernel<C>, dim3((n + LA_TOK2 - 1) / LA_TOK2, B), dim3(256), lds2, s, x, w, ws,
-                       y, n, nblk, add_x ? 1 : 0, 1.0f / sqrtf((float)LA_DH));
+    hipLaunchKernelGGL(linattn_out_fused_kernel<C>, dim3((n + LA_TOK2 - 1) / LA_TOK2, B), dim3(256), lds2, s, x, w,
+                       ctxn, y, n, add_x ? 1 : 0, 1.0f / sqrtf((float)LA_DH));
     DM_CHECK_HIP(hipGetLastError());
     if (timed && prof::end(s)) return 1;
     return 0;
