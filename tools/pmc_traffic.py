@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""HBM-side traffic per kernel launch from two rocprofv3 PMC passes (MI355X_MICROARCH.md, HBM / rocprofv3 section).
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -o f -- python3 bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -o w -- python3 bench.py ...
+    python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w > profiles/<round>_pmc_hbm_traffic.json
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch; on gfx950 FETCH_SIZE counts half of the bytes of wide
+coalesced reads, so it is doubled (the guide's correction); WRITE_SIZE is exact for 16-byte-per-lane stores."""
+import csv
+import glob
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def per_kernel(directory, counter):
+    files = glob.glob(f"{directory}/**/*counter_collection.csv", recursive=True)
+    if not files:
+        sys.exit(f"no counter_collection.csv under {directory}")
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            name = re.sub(r"^void\s+", "", r["Kernel_Name"])
+            name = re.sub(r"\(.*$", "", name).replace("dm::", "")
+            tot[name] += float(r["Counter_Value"])
+            cnt[name] += 1
+    return tot, cnt
+
+
+def main():
+    fdir, wdir = sys.argv[1], sys.argv[2]
+    ft, fc = per_kernel(fdir, "FETCH_SIZE")
+    wt, wc = per_kernel(wdir, "WRITE_SIZE")
+    out = {}
+    for k in sorted(ft):
+        raw_kb = ft[k] / fc[k]
+        out[k] = {
+            "launches": fc[k],
+            "fetch_KB_per_launch_raw": raw_kb,
+            "fetch_bytes_per_launch_corrected": raw_kb * 1024.0 * 2.0,
+            "write_bytes_per_launch": (wt.get(k, 0.0) / max(wc.get(k, 1), 1)) * 1024.0,
+        }
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
