@@ -12,6 +12,39 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 __device__ __forceinline__ f32x4 make_f32x4(float a, float b, float c, float d) { return f32x4{a, b, c, d}; }
 
+// Packed fp32 VALU ops (two floats per lane and instruction).  On gfx950 the f32-input MFMA runs on the same
+// vector ALUs as ordinary VALU code -- measured: a kernel's time is the SUM of 64 cycles per 32x32x2 MFMA and
+// 4 cycles per VALU instruction, nothing overlaps -- so every VALU instruction next to an MFMA stream costs 1/16
+// of an MFMA and the packed forms halve that.  The compiler emits v_pk_add/v_pk_fma only for some patterns
+// (never for subtraction), hence the explicit forms.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {  // a * b + c
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x4 join4(f32x2 lo, f32x2 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3); }
+__device__ __forceinline__ f32x4 add4(f32x4 a, f32x4 b) { return join4(pk_add(a.xy, b.xy), pk_add(a.zw, b.zw)); }
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) { return join4(pk_sub(a.xy, b.xy), pk_sub(a.zw, b.zw)); }
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x2 s, f32x4 c) {  // a * s + c, s = one scalar in both halves
+    return join4(pk_fma(a.xy, s, c.xy), pk_fma(a.zw, s, c.zw));
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));

@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace dm {
@@ -249,16 +250,9 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
         U[j][1] = gload4(ub + ((size_t)j * p.Cout + 32) * WCK, ulane);
     };
 
-    f32x16 acc[4][R][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[j][r][q][e] = 0.f;
+    f32x16 acc[4][R][2];  // first written by the first chunk's MFMAs (C = 0)
 
+    DM_STAMP_ADD(4)
     // ---- prologue: chunks cb and cb + 1 -> LDS (both loads in flight together), operands of chunk cb -> registers
     __builtin_amdgcn_s_setprio(1);
     {
@@ -280,16 +274,17 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
 #pragma unroll
         for (int i = 0; i < HR; ++i) store_window(raw1, i);
     }
+    DM_STAMP_ADD(5)
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         f32x4 T[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) T[b] = rd(raw0, r, 0, b) + sgn * rd(raw0, r, 1, b);
-        A[0][r] = T[0] - T[2];
-        A[1][r] = T[1] + T[2];
-        A[2][r] = T[2] - T[1];
-        A[3][r] = T[1] - T[3];
+        A[0][r] = sub4(T[0], T[2]);
+        A[1][r] = add4(T[1], T[2]);
+        A[2][r] = sub4(T[2], T[1]);
+        A[3][r] = sub4(T[1], T[3]);
     }
     __syncthreads();  // raw0 is overwritten with chunk cb + 2 by the first iteration
     DM_STAMP_ADD(0)
@@ -297,7 +292,14 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
     // ---- main loop: NM MFMAs per chunk and wave; everything else is issued from the hooks between them.
     // The body is ONE basic block (no branch: loads past the end re-read valid memory and are never used), so
     // sched_barrier pins every hook to its slot.
-    for (int c = cb; c < ce; ++c) {
+    // The first chunk runs as its own copy of the body whose first MFMA per accumulator takes C = 0 (an inline
+    // constant): no accumulator initialisation.
+    const f32x2 sgn2 = {sgn, sgn};
+    f32x16 zero16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
+    auto chunk_body = [&](int c, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const bool has1 = c + 1 < ce, has2 = c + 2 < ce;
         const int par = (c - cb) & 1;
         const float* rawn = par ? raw0 : raw1;  // chunk c + 1 (stored during iteration c - 1 / the prologue)
@@ -318,33 +320,33 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const int m = ((j * 4 + s) * 2 + r) * 2 + q;  // 0..63
-                            acc[j][r][q] =
-                                __builtin_amdgcn_mfma_f32_32x32x2f32(A[j][r][s], U[j][q][s], acc[j][r][q], 0, 0, 0);
+                            acc[j][r][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                A[j][r][s], U[j][q][s], (FIRST && s == 0) ? zero16 : acc[j][r][q], 0, 0, 0);
                             if (m < HR) load_window(m);  // chunk c + 2 (or c again at the end: never read)
                             if (m >= 6 && m < 14) d[m - 6] = rd(rawn, 0, (m - 6) >> 2, (m - 6) & 3);
-                            if (m >= 14 && m < 18) T[0][m - 14] = d[m - 14] + sgn * d[4 + m - 14];
+                            if (m >= 14 && m < 18) T[0][m - 14] = fma4(d[4 + m - 14], sgn2, d[m - 14]);
                             if (m == 16) load_u(unext, 0);  // the MFMAs of j = 0 were issued by m = 15
                             if (m >= 18 && m < 26) d[m - 18] = rd(rawn, 1, (m - 18) >> 2, (m - 18) & 3);
-                            if (m >= 26 && m < 30) T[1][m - 26] = d[m - 26] + sgn * d[4 + m - 26];
+                            if (m >= 26 && m < 30) T[1][m - 26] = fma4(d[4 + m - 26], sgn2, d[m - 26]);
                             if (m == 30) {
-                                A[0][0] = T[0][0] - T[0][2];
-                                A[0][1] = T[1][0] - T[1][2];
+                                A[0][0] = sub4(T[0][0], T[0][2]);
+                                A[0][1] = sub4(T[1][0], T[1][2]);
                             }
                             if (m == 32) {  // j = 1 done at m = 31
-                                A[1][0] = T[0][1] + T[0][2];
-                                A[1][1] = T[1][1] + T[1][2];
+                                A[1][0] = add4(T[0][1], T[0][2]);
+                                A[1][1] = add4(T[1][1], T[1][2]);
                             }
                             if (m == 33) load_u(unext, 1);
                             if (m == 48) {  // j = 2 done at m = 47
-                                A[2][0] = T[0][2] - T[0][1];
-                                A[2][1] = T[1][2] - T[1][1];
+                                A[2][0] = sub4(T[0][2], T[0][1]);
+                                A[2][1] = sub4(T[1][2], T[1][1]);
                             }
                             if (m == 49) load_u(unext, 2);
                             if (m >= 56 && m < 56 + HR) store_window(rawst, m - 56);
                             __builtin_amdgcn_sched_barrier(0);
                         }
-            A[3][0] = T[0][1] - T[0][3];
-            A[3][1] = T[1][1] - T[1][3];
+            A[3][0] = sub4(T[0][1], T[0][3]);
+            A[3][1] = sub4(T[1][1], T[1][3]);
         } else {
             f32x4 d[4];
 #pragma unroll
@@ -354,32 +356,35 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int m = (j * 4 + s) * 2 + q;  // 0..31
-                        acc[j][0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[j][0][s], U[j][q][s], acc[j][0][q], 0, 0, 0);
+                        acc[j][0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            A[j][0][s], U[j][q][s], (FIRST && s == 0) ? zero16 : acc[j][0][q], 0, 0, 0);
                         if (m < HR) load_window(m);
                         if (m >= 3 && m < 7) d[m - 3] = rd(rawn, 0, (m - 3) & 1, (m - 3) >> 1);  // columns 0, 1
                         if (m == 8) load_u(unext, 0);  // j = 0 done at m = 7
-                        if (m == 11) T[0][0] = d[0] + sgn * d[1];
-                        if (m == 12) T[0][1] = d[2] + sgn * d[3];
+                        if (m == 11) T[0][0] = fma4(d[1], sgn2, d[0]);
+                        if (m == 12) T[0][1] = fma4(d[3], sgn2, d[2]);
                         if (m >= 13 && m < 17) d[m - 13] = rd(rawn, 0, (m - 13) & 1, 2 + ((m - 13) >> 1));  // columns 2, 3
                         if (m == 17) load_u(unext, 1);  // j = 1 done at m = 15
-                        if (m == 21) T[0][2] = d[0] + sgn * d[1];
+                        if (m == 21) T[0][2] = fma4(d[1], sgn2, d[0]);
                         if (m == 22) {
-                            T[0][3] = d[2] + sgn * d[3];
-                            A[0][0] = T[0][0] - T[0][2];
+                            T[0][3] = fma4(d[3], sgn2, d[2]);
+                            A[0][0] = sub4(T[0][0], T[0][2]);
                         }
-                        if (m == 23) A[1][0] = T[0][1] + T[0][2];
+                        if (m == 23) A[1][0] = add4(T[0][1], T[0][2]);
                         if (m == 24) load_u(unext, 2);  // j = 2 done at m = 23
-                        if (m == 25) A[2][0] = T[0][2] - T[0][1];
+                        if (m == 25) A[2][0] = sub4(T[0][2], T[0][1]);
                         if (m >= 27 && m < 27 + HR) store_window(rawst, m - 27);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-            A[3][0] = T[0][1] - T[0][3];
+            A[3][0] = sub4(T[0][1], T[0][3]);
         }
         load_u(unext, 3);
         __builtin_amdgcn_s_setprio(1);
         ucur = unext_g;
         __syncthreads();
-    }
+    };
+    chunk_body(cb, std::true_type{});
+    for (int c = cb + 1; c < ce; ++c) chunk_body(c, std::false_type{});
 
     DM_STAMP_ADD(1)
     // ---- epilogue: R_i[b] = sum_j M[i][j] A[j][b] per wave, then Y[a][b] = sum_i A^T[a][i] R_i[b] through LDS.
@@ -471,10 +476,10 @@ static int wino_launch_r(const ConvParams& p, int blocks, hipStream_t s) {
         double avg[8] = {0};
         for (size_t b = 0; b < nblk; ++b)
             for (int k = 0; k < 8; ++k) avg[k] += (double)h[b * 8 + k] / nblk;
-        fprintf(stderr, "STAMPS wino<%d> %d+%d->%d @%dx%d e%d k%d chunks %d: wgs=%zu | prologue %.0f loop %.0f (%.0f/chunk) "
-                        "reduce %.0f epilogue %.0f\n",
-                R, p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.epi, p.geo.splits, p.geo.chunks_per_split, nblk, avg[0], avg[1],
-                avg[1] / p.geo.chunks_per_split, avg[2], avg[3]);
+        fprintf(stderr, "STAMPS wino<%d> %d+%d->%d @%dx%d e%d k%d chunks %d: wgs=%zu | setup %.0f load+store %.0f "
+                        "transform %.0f loop %.0f (%.0f/chunk) reduce %.0f epilogue %.0f\n",
+                R, p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.epi, p.geo.splits, p.geo.chunks_per_split, nblk, avg[4], avg[5],
+                avg[0], avg[1], avg[1] / p.geo.chunks_per_split, avg[2], avg[3]);
         return 0;
     }
 #endif
