@@ -112,7 +112,21 @@ struct RowsEpilogue {
     int rows_per_wg;
     int row_in_wg0;
     int wn;
+    bool all_valid;   // every lane of the tile maps to a real cout (no masking needed)
 };
+
+// global-memory access as (wave-uniform base in SGPRs) + (32-bit element offset in a VGPR): no 64-bit vector
+// arithmetic per access.  Tensors on this path hold < 2^30 elements (checked by the launchers).
+using gfloat_ptr = const float __attribute__((address_space(1)))*;
+using gfloat_mptr = float __attribute__((address_space(1)))*;
+__device__ __forceinline__ f32x4 gload4(gfloat_ptr base, unsigned off_floats) {
+    using gchar_ptr = const char __attribute__((address_space(1)))*;
+    return *(const f32x4 __attribute__((address_space(1)))*)((gchar_ptr)base + (off_floats << 2));
+}
+__device__ __forceinline__ void gstore4(gfloat_mptr base, unsigned off_floats, f32x4 v) {
+    using gchar_ptr = char __attribute__((address_space(1)))*;
+    *(f32x4 __attribute__((address_space(1)))*)((gchar_ptr)base + (off_floats << 2)) = v;
+}
 
 // Everything the epilogue reads from global memory, fetched BEFORE the accumulators go through LDS so that the
 // HBM/L2 latency (bias, g, scale/shift, the residual rows) overlaps the transposition instead of following it.
@@ -121,40 +135,36 @@ template <int NR, bool RES = true>
 struct RowsPrefetch {
     f32x4 b4, g4, sc, sh;
     f32x4 res[RES ? NR : 1];
+    unsigned off[NR];  // element offset of (pixel row j, cout cg) in the output / residual tensor
 };
 
 template <int NR, bool RES>
 __device__ __forceinline__ void rows_prefetch(const ConvParams& p, const RowsEpilogue& e, const int (&pixv)[NR], int cg,
                                               bool cvalid, RowsPrefetch<NR, RES>& f) {
-    const f32x4 zero4 = make_f32x4(0.f, 0.f, 0.f, 0.f);
-    f.b4 = zero4;
-    f.g4 = zero4;
-    f.sc = zero4;
-    f.sh = zero4;
-    if constexpr (RES) {
+    // fields are only read by rows_epilogue under the same epilogue flags they are loaded under: no defaults
+    const int cgc = cvalid ? cg : 0;
 #pragma unroll
-        for (int j = 0; j < NR; ++j) f.res[j] = zero4;
-    }
+    for (int j = 0; j < NR; ++j) f.off[j] = __umul24((unsigned)max(pixv[j], 0), (unsigned)p.Cout) + cgc;
     if (p.partial) return;
     const int epi = p.epi;
-    if ((epi & EPI_BIAS) && cvalid) f.b4 = *reinterpret_cast<const f32x4*>(p.bias + cg);
-    if ((epi & EPI_NORM) && cvalid) f.g4 = *reinterpret_cast<const f32x4*>(p.g + cg);
-    if ((epi & EPI_SCALE_SHIFT) && e.uni && cvalid) {
+    if (epi & EPI_BIAS) f.b4 = *reinterpret_cast<const f32x4*>(p.bias + cgc);
+    if (epi & EPI_NORM) f.g4 = *reinterpret_cast<const f32x4*>(p.g + cgc);
+    if ((epi & EPI_SCALE_SHIFT) && e.uni) {
         const float* sp = p.scale + (size_t)min(e.b0, p.B - 1) * p.ss_stride;
-        f.sc = *reinterpret_cast<const f32x4*>(sp + cg);  // raw scale: nothing here may USE a loaded value
-        f.sh = *reinterpret_cast<const f32x4*>(sp + p.Cout + cg);
+        f.sc = *reinterpret_cast<const f32x4*>(sp + cgc);  // raw scale: nothing here may USE a loaded value
+        f.sh = *reinterpret_cast<const f32x4*>(sp + p.Cout + cgc);
     }
     if constexpr (RES) {
         if (epi & EPI_RESIDUAL) {
             // unconditional loads (rows outside the tensor read row 0 and are never stored): no per-row branches
-            const int cgc = cvalid ? cg : 0;
+            const gfloat_ptr rp = (gfloat_ptr)p.residual;
 #pragma unroll
-            for (int j = 0; j < NR; ++j)
-                f.res[j] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)max(pixv[j], 0) * p.Cout + cgc);
+            for (int j = 0; j < NR; ++j) f.res[j] = gload4(rp, f.off[j]);
         }
     }
 }
 
+// The arithmetic is written with the packed forms: next to an MFMA stream every VALU instruction counts (see above).
 template <int WN, int NR, bool RES>
 __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpilogue& e, f32x4 (&v)[NR],
                                               const int (&pixv)[NR], int cg, bool cvalid,
@@ -162,23 +172,30 @@ __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpi
     const int lane = threadIdx.x & 63;
     const int rsub = lane >> 4;
     if (p.partial) {
-        float* po = p.out + (size_t)e.split * e.M * p.Cout + cg;
+        const gfloat_mptr po = (gfloat_mptr)(p.out + (size_t)e.split * e.M * p.Cout);
 #pragma unroll
         for (int j = 0; j < NR; ++j)
-            if (pixv[j] >= 0 && cvalid) *reinterpret_cast<f32x4*>(po + (size_t)pixv[j] * p.Cout) = v[j];
+            if (pixv[j] >= 0 && cvalid) gstore4(po, f.off[j], v[j]);
         return;
     }
     const int epi = p.epi;
     const f32x4 zero4 = make_f32x4(0.f, 0.f, 0.f, 0.f);
+    if (epi & EPI_BIAS) {
 #pragma unroll
-    for (int j = 0; j < NR; ++j) v[j] = cvalid ? v[j] + f.b4 : zero4;
+        for (int j = 0; j < NR; ++j) v[j] = add4(v[j], f.b4);
+    }
+    if (!e.all_valid) {  // lanes past the last cout must not feed the norm
+#pragma unroll
+        for (int j = 0; j < NR; ++j) v[j] = cvalid ? v[j] : zero4;
+    }
     if (epi & EPI_NORM) {
         const float sqrtc = sqrtf((float)p.Cout);
-        const f32x4 g4 = f.g4 * sqrtc;
+        const f32x4 g4 = cvalid ? f.g4 * sqrtc : zero4;
         float ssv[NR];
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            float ss = v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+            const f32x2 sq = pk_fma(v[j].zw, v[j].zw, pk_mul(v[j].xy, v[j].xy));
+            float ss = sq.x + sq.y;
             ss += dpp_f<0xB1>(ss);
             ss += dpp_f<0x4E>(ss);
             ss += dpp_f<0x141>(ss);
@@ -202,10 +219,18 @@ __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpi
         }
         // 1 / max(||v||, 1e-12) as one v_rsq_f32 (1 ulp)
 #pragma unroll
-        for (int j = 0; j < NR; ++j) v[j] = v[j] * (fast_rsq(fmaxf(ssv[j], 1e-24f))) * g4;
+        for (int j = 0; j < NR; ++j) {
+            const float rn = fast_rsq(fmaxf(ssv[j], 1e-24f));
+            const f32x2 rn2 = {rn, rn};
+            v[j] = join4(pk_mul(pk_mul(v[j].xy, rn2), g4.xy), pk_mul(pk_mul(v[j].zw, rn2), g4.zw));
+        }
     }
     if (epi & EPI_SCALE_SHIFT) {
-        f32x4 sc = f.sc + 1.0f, sh = f.sh;
+        f32x4 sc = make_f32x4(1.f, 1.f, 1.f, 1.f), sh = zero4;
+        if (e.uni) {
+            sc = f.sc + 1.0f;
+            sh = f.sh;
+        }
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             if (!e.uni && cvalid && pixv[j] >= 0) {
@@ -213,28 +238,34 @@ __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpi
                 sc = *reinterpret_cast<const f32x4*>(sp + cg) + 1.0f;
                 sh = *reinterpret_cast<const f32x4*>(sp + p.Cout + cg);
             }
-            v[j] = v[j] * sc + sh;
+            v[j] = join4(pk_fma(v[j].xy, sc.xy, sh.xy), pk_fma(v[j].zw, sc.zw, sh.zw));
         }
     }
     if (epi & EPI_SILU) {
+        // x * 1 / (1 + 2^(-x log2 e)): the same instructions __expf / the reciprocal lower to, packed where possible
+        const f32x2 nl2e = {-1.4426950408889634f, -1.4426950408889634f}, one2 = {1.0f, 1.0f};
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            v[j].x = v[j].x * fast_rcp(1.0f + __expf(-v[j].x));
-            v[j].y = v[j].y * fast_rcp(1.0f + __expf(-v[j].y));
-            v[j].z = v[j].z * fast_rcp(1.0f + __expf(-v[j].z));
-            v[j].w = v[j].w * fast_rcp(1.0f + __expf(-v[j].w));
+            f32x2 t0 = pk_mul(v[j].xy, nl2e), t1 = pk_mul(v[j].zw, nl2e);
+            t0 = f32x2{__builtin_amdgcn_exp2f(t0.x), __builtin_amdgcn_exp2f(t0.y)};
+            t1 = f32x2{__builtin_amdgcn_exp2f(t1.x), __builtin_amdgcn_exp2f(t1.y)};
+            t0 = pk_add(t0, one2);
+            t1 = pk_add(t1, one2);
+            t0 = f32x2{fast_rcp(t0.x), fast_rcp(t0.y)};
+            t1 = f32x2{fast_rcp(t1.x), fast_rcp(t1.y)};
+            v[j] = join4(pk_mul(v[j].xy, t0), pk_mul(v[j].zw, t1));
         }
     }
+    const gfloat_mptr op = (gfloat_mptr)p.out;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         if (pixv[j] < 0 || !cvalid) continue;
-        const size_t o = (size_t)pixv[j] * p.Cout + cg;
         if constexpr (RES) {
-            *reinterpret_cast<f32x4*>(p.out + o) = v[j] + f.res[j];
+            gstore4(op, f.off[j], (epi & EPI_RESIDUAL) ? add4(v[j], f.res[j]) : v[j]);
         } else {
             f32x4 r4 = v[j];
-            if (epi & EPI_RESIDUAL) r4 += *reinterpret_cast<const f32x4*>(p.residual + o);
-            *reinterpret_cast<f32x4*>(p.out + o) = r4;
+            if (epi & EPI_RESIDUAL) r4 = add4(r4, gload4((gfloat_ptr)p.residual, f.off[j]));
+            gstore4(op, f.off[j], r4);
         }
     }
 }

@@ -668,6 +668,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
             re.rows_per_wg = 64 * WM;
             re.row_in_wg0 = wm * 64;
             re.wn = wn;
+            re.all_valid = (p.Cout % NT) == 0;
             float* T = smem + wave * (64 * TS);
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -902,6 +903,11 @@ int conv_launch(const ConvParams& pin, hipStream_t s) {
     DM_REQUIRE(!p.in_nchw || p.C1 == 0, "conv: NCHW input supports one source");
     DM_REQUIRE(!p.up || ((p.Hin % 2 == 0) && (p.Win % 2 == 0)), "conv: upsampled input must be even");
     DM_REQUIRE(p.KW % g.TPS == 0, "conv: taps per slab must divide KW");
+    {
+        // the row epilogue addresses the output with 24-bit pixel indices and 32-bit byte offsets
+        const size_t M = (size_t)p.B * p.Ho * p.Wo * (p.fold ? 4 : 1);
+        DM_REQUIRE(M < (1u << 24) && M * (size_t)p.Cout < (1ull << 30), "conv: output tensor too large (2^30 elements)");
+    }
     if (CK == 16) DM_REQUIRE(p.C0 % 4 == 0 && p.C1 % 4 == 0, "conv: CK16 needs C % 4 == 0");
     int red_floats = (p.epi & EPI_NORM) && g.WN > 1 ? g.WN * g.WM * 64 : 0;
     // the pixel table sits behind the staging buffers and behind the 4 x [64][68] transposed tiles of the

@@ -60,6 +60,7 @@ struct ConvGeom {
     int chunks_per_split;
     int fused_norm;      // the plan keeps all couts of a pixel in one workgroup (EPI_NORM allowed)
     int row_stride;      // winograd: LDS floats per window row
+    int magic_win, magic_row;  // winograd: ceil(2^24 / (IH*IW)), ceil(2^24 / IW): divisions of the window setup
     int lds_bytes;
 };
 

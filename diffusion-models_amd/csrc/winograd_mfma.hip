@@ -40,20 +40,12 @@ static constexpr int WCK = 8;     // input channels per K chunk
 static constexpr int WTS = 68;    // padded row stride of the transposed epilogue tiles (floats)
 
 // tell the compiler a pointer is wave-uniform (keeps it in SGPRs so that loads use the saddr + voffset form)
-using gfloat_ptr = const float __attribute__((address_space(1)))*;   // global address space
-using gf32x4_ptr = const f32x4 __attribute__((address_space(1)))*;
 __device__ __forceinline__ gfloat_ptr uniform_ptr(const float* ptr) {
     const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (gfloat_ptr)(((unsigned long long)hi << 32) | lo);
 }
-// base in SGPRs + 32-bit BYTE offset in a VGPR: global_load_dwordx4 v, voff, s[base:base+1]
-__device__ __forceinline__ f32x4 gload4(gfloat_ptr base, unsigned off_floats) {
-    using gchar_ptr = const char __attribute__((address_space(1)))*;
-    return *(gf32x4_ptr)((gchar_ptr)base + (off_floats << 2));
-}
-
 static inline int w_pow2ceil(int v) {
     int p = 1;
     while (p < v) p <<= 1;
@@ -118,6 +110,8 @@ ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_s
     g.IW = 2 * g.TW + 2;
     g.row_stride = g.IW * WCK + 4;  // +4: rows of consecutive tile rows start 8 banks apart mod 16
     g.halo_floats = g.NB * g.IH * g.row_stride;
+    g.magic_win = ((1 << 24) + g.IH * g.IW - 1) / (g.IH * g.IW);  // exact for the < 2^10 window pixels
+    g.magic_row = ((1 << 24) + g.IW - 1) / g.IW;
     g.TPS = 3;
     const int n_chunks = (C0 + C1) / WCK;
     const int wgs = g.tiles_x * g.tiles_y * g.groups * g.n_tiles_n;
@@ -130,10 +124,11 @@ ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_s
     g.chunks_per_split = (n_chunks + splits - 1) / splits;
     g.splits = (n_chunks + g.chunks_per_split - 1) / g.chunks_per_split;
     g.fused_norm = g.n_tiles_n == 1 && g.splits == 1;
-    g.ptab_off = 0;
     g.w_floats = 0;
-    // two windows + a scratch slot reachable from both; the epilogue reuses the space for 4 x 2 transposed tiles
-    g.lds_bytes = std::max(3 * g.halo_floats + 4, 4 * 2 * tiles * WTS) * 4;
+    // two windows + a scratch slot reachable from both; the epilogue reuses the space for 4 x 2 transposed tiles;
+    // behind both: the output-pixel table [wave][2a+b][tile of the wave] (built once, read by the epilogue)
+    g.ptab_off = std::max(3 * g.halo_floats + 4, 4 * 2 * tiles * WTS);
+    g.lds_bytes = (g.ptab_off + 4 * tiles) * 4;
     return g;
 }
 
@@ -185,9 +180,9 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
         hoff[i] = 2 * g.halo_floats;  // items past the window go to a scratch slot: the main loop has no branches
         if (it < win_items) {
             const int hp = it >> 1;
-            const int nb = hp / (g.IH * g.IW);
+            const int nb = (int)(((unsigned)hp * (unsigned)g.magic_win) >> 24);  // hp / (IH * IW)
             const int rem = hp - nb * (g.IH * g.IW);
-            const int hy = rem / g.IW;
+            const int hy = (int)(((unsigned)rem * (unsigned)g.magic_row) >> 24);  // rem / IW
             const int hx = rem - hy * g.IW;
             const int b = b0 + nb, iy = iy0 + hy, ix = ix0 + hx;
             const int off = (nb * g.IH + hy) * RS + hx * WCK + 4 * (tid & 1);
@@ -201,6 +196,20 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
             }
         }
         hpix[i] = max(hpix[i], 0);
+    }
+    {
+        // output pixel of (tile, a, b), or -1: thread = tile * 4 + (2a + b)
+        constexpr int NRT = 8 * R;
+        int* ptab = reinterpret_cast<int*>(smem + g.ptab_off);
+        if (tid < 4 * TILES) {
+            const int t = tid >> 2, ab = tid & 3;
+            const int tx = t & (g.TW - 1);
+            const int ty = (t >> g.lTW) & (g.TH - 1);
+            const int nb = t >> (g.lTW + g.lTH);
+            const int b = b0 + nb, y = 2 * (ty0 + ty) + (ab >> 1), x = 2 * (tx0 + tx) + (ab & 1);
+            ptab[(t / NRT) * (4 * NRT) + ab * NRT + (t % NRT)] =
+                (b < p.B && y < p.Ho && x < p.Wo) ? (b * p.Ho + y) * p.Wo + x : -1;
+        }
     }
     f32x4 hreg[HR];
     // Addresses are (wave-uniform base) + (32-bit lane offset): the loads take the base from SGPRs and need no
@@ -397,14 +406,16 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
     const int cg = n_tile * 64 + c4;
     const bool cvalid = cg < p.Cout;
     int pixv[NR];
+    {
+        const int* pt = reinterpret_cast<const int*>(smem + g.ptab_off) + wave * (4 * NR) + rsub * NR;
 #pragma unroll
-    for (int jj = 0; jj < NR; ++jj) {
-        const int t = NR * wave + jj;
-        const int tx = t & (g.TW - 1);
-        const int ty = (t >> g.lTW) & (g.TH - 1);
-        const int nb = t >> (g.lTW + g.lTH);
-        const int b = b0 + nb, y = 2 * (ty0 + ty) + oa, x = 2 * (tx0 + tx) + ob;
-        pixv[jj] = (b < p.B && y < p.Ho && x < p.Wo) ? (b * p.Ho + y) * p.Wo + x : -1;
+        for (int jj = 0; jj < NR; jj += 4) {
+            const int4 t4 = *reinterpret_cast<const int4*>(pt + jj);
+            pixv[jj] = t4.x;
+            pixv[jj + 1] = t4.y;
+            pixv[jj + 2] = t4.z;
+            pixv[jj + 3] = t4.w;
+        }
     }
     RowsEpilogue re;
     re.split = split;
@@ -416,6 +427,7 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
     re.rows_per_wg = 4 * TILES;
     re.row_in_wg0 = wave * 4 * NR;
     re.wn = 0;
+    re.all_valid = true;
     RowsPrefetch<NR, true> pf;
     rows_prefetch<NR, true>(p, re, pixv, cg, cvalid, pf);
 
@@ -424,13 +436,17 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const f32x16 r0 = acc[0][r][q] + acc[1][r][q] + acc[2][r][q];
-            const f32x16 r1 = acc[1][r][q] - acc[2][r][q] - acc[3][r][q];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
+            for (int e = 0; e < 16; e += 2) {  // two accumulator registers per packed instruction
+                const f32x2 a0 = {acc[0][r][q][e], acc[0][r][q][e + 1]}, a1 = {acc[1][r][q][e], acc[1][r][q][e + 1]};
+                const f32x2 a2 = {acc[2][r][q][e], acc[2][r][q][e + 1]}, a3 = {acc[3][r][q][e], acc[3][r][q][e + 1]};
+                const f32x2 r0 = pk_add(pk_add(a0, a1), a2);
+                const f32x2 r1 = pk_sub(pk_sub(a1, a2), a3);
                 const int row = r * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                Tb[row * WTS + q * 32 + l31] = r0[e];
-                Tb[(TILES + row) * WTS + q * 32 + l31] = r1[e];
+                Tb[row * WTS + q * 32 + l31] = r0.x;
+                Tb[(row + 1) * WTS + q * 32 + l31] = r0.y;
+                Tb[(TILES + row) * WTS + q * 32 + l31] = r1.x;
+                Tb[(TILES + row + 1) * WTS + q * 32 + l31] = r1.y;
             }
         }
     __syncthreads();
