@@ -109,6 +109,7 @@ struct ConvLayer {
     int fold_w_stride = 0;
     float* w = nullptr;
     float* ww = nullptr;  // Winograd-transformed weights (winograd_mfma.hip) when the layer is eligible
+    float* wraw = nullptr;  // (Cout, Cin) weights of a 1x1 conv with Cout <= 4 (pointwise_small_kernel)
     float* bias = nullptr;
 };
 
@@ -273,6 +274,10 @@ static int make_conv(DeviceOwner& own, ConvLayer& L, const float* oihw, const fl
         wino_pack_weights(oihw, wp.data(), Cout, C0, C1);
         if (own.upload(wp.data(), wp.size(), &L.ww)) return 1;
     }
+    L.wraw = nullptr;
+    if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && !up && Cout <= 4 && C1 == 0 && C0 % 4 == 0 &&
+        own.upload(oihw, (size_t)Cout * C0, &L.wraw))
+        return 1;
     L.bias = nullptr;
     if (bias && own.upload(bias, Cout, &L.bias)) return 1;
     return 0;
@@ -408,6 +413,12 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
         out_h = p.Ho; out_w = p.Wo;
         p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, L.KH, L.KW, L.stride, L.C0, L.C1, want_norm && !out_nchw,
                           !out_nchw);
+    }
+    if (L.wraw && out_nchw && !in_nchw && in1 == nullptr && epi == 0) {
+        // a handful of output channels (final_conv): one pixel per thread instead of a 64-column MFMA tile
+        if (c.dry()) return 0;
+        return launch_pointwise_small(in0, L.wraw, L.bias, out, (int64_t)c.B * p.Ho * p.Wo, L.C0, L.Cout, p.Ho * p.Wo,
+                                      c.s);
     }
     // 3x3 / stride 1 convolutions run as Winograd F(2x2,3x3) when the layer has transformed weights
     const bool wino = L.ww && !L.fold && !in_nchw && !out_nchw && wino_use(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);

@@ -334,6 +334,51 @@ int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t 
 }
 
 // ---------------------------------------------------------------------------------------
+// 1x1 convolution to a few output channels, NHWC in -> NCHW out (final_conv, DD/denoising_diffusion.py:319: 64 -> 3).
+// One pixel per thread: the MFMA tile would spend 61 of 64 columns on padding; this is a 256-byte read and three
+// coalesced dword stores per pixel, HBM bound.  Weights (Cout x C) and bias sit in LDS.
+// ---------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void pointwise_small_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             int64_t pixels, int C, int HW) {
+    extern __shared__ __attribute__((aligned(16))) float ws[];  // [COUT][C]
+    for (int i = threadIdx.x; i < COUT * C; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= pixels) return;
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = bias ? bias[o] : 0.f;
+    const f32x4v* xp = reinterpret_cast<const f32x4v*>(x + pix * C);
+    for (int q = 0; q < C / 4; ++q) {
+        const f32x4v v = xp[q];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            const f32x4v wv = *reinterpret_cast<const f32x4v*>(ws + o * C + 4 * q);  // same address in every lane
+            acc[o] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+        }
+    }
+    const int64_t b = pix / HW, sp = pix - b * HW;
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) y[(b * COUT + o) * HW + sp] = acc[o];
+}
+int launch_pointwise_small(const float* x, const float* w_oc, const float* bias, float* y_nchw, int64_t pixels, int C,
+                           int Cout, int HW, hipStream_t s) {
+    DM_REQUIRE(Cout >= 1 && Cout <= 4 && C % 4 == 0, "pointwise_small: 1..4 output channels, C % 4 == 0");
+    const dim3 grid((pixels + 255) / 256), block(256);
+    const size_t lds = (size_t)Cout * C * sizeof(float);
+    switch (Cout) {
+        case 1: hipLaunchKernelGGL(pointwise_small_kernel<1>, grid, block, lds, s, x, w_oc, bias, y_nchw, pixels, C, HW); break;
+        case 2: hipLaunchKernelGGL(pointwise_small_kernel<2>, grid, block, lds, s, x, w_oc, bias, y_nchw, pixels, C, HW); break;
+        case 3: hipLaunchKernelGGL(pointwise_small_kernel<3>, grid, block, lds, s, x, w_oc, bias, y_nchw, pixels, C, HW); break;
+        default: hipLaunchKernelGGL(pointwise_small_kernel<4>, grid, block, lds, s, x, w_oc, bias, y_nchw, pixels, C, HW); break;
+    }
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
