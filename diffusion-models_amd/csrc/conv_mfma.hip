@@ -218,7 +218,21 @@ __device__ __forceinline__ int window_pixel(const ConvParams& p, int hp, int b0,
     const int Ws = p.up ? (p.Win >> 1) : p.Win;
     int sy = p.up ? (iy >> 1) : iy;
     int sx = p.up ? (ix >> 1) : ix;
+    if (p.s2d) return (b * 2 * p.Hin + 2 * iy) * (2 * p.Win) + 2 * ix;  // tap (0,0) of the 2x2 block; taps shift the base
     return (b * Hs + sy) * Ws + sx;
+}
+
+// Source of K chunk `chunk` (CK == 16 path): base pointer for channel 0 of the chunk and the channel count of
+// that source.  s2d: chunk = cin_chunk * 4 + tap, and tap (ky, kx) shifts every window pixel by (ky, kx).
+__device__ __forceinline__ const float* chunk_source(const ConvParams& p, int chunk, int* Cs) {
+    if (p.s2d) {
+        const int tap = chunk & 3;
+        *Cs = p.C0;
+        return p.in0 + (chunk >> 2) * 16 + (size_t)((tap >> 1) * 2 * p.Win + (tap & 1)) * p.C0;
+    }
+    const bool s1 = chunk >= p.chunks0;
+    *Cs = s1 ? p.C1 : p.C0;
+    return (s1 ? p.in1 : p.in0) + (s1 ? chunk - p.chunks0 : chunk) * 16;
 }
 
 // one f32x4 of the input window: source pixel `pix`, channel quad q of chunk `chunk`
@@ -399,9 +413,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int n_h = (halo_items + 255) >> 8;
     auto load_h = [&](int chunk) {
         if constexpr (CK == 16) {
-            const bool src1 = chunk >= p.chunks0;
-            const float* __restrict__ src = (src1 ? p.in1 : p.in0) + (src1 ? chunk - p.chunks0 : chunk) * CK + (tid & 3) * 4;
-            const int Cs = src1 ? p.C1 : p.C0;
+            int Cs;
+            const float* __restrict__ src = chunk_source(p, chunk, &Cs) + (tid & 3) * 4;
 #pragma unroll
             for (int i = 0; i < HREGS; ++i)
                 if (i < n_h)  // zeroing of padding pixels happens at store time: nothing here may touch the data,
@@ -474,11 +487,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         int sic = 0;  // slab index inside the chunk
         const float* __restrict__ hsrc = nullptr;
         int hCs = 0;
-        auto window_source = [&](int nc) {
-            const bool hs1 = nc >= p.chunks0;
-            hsrc = (hs1 ? p.in1 : p.in0) + (hs1 ? nc - p.chunks0 : nc) * CK + (tid & 3) * 4;
-            hCs = hs1 ? p.C1 : p.C0;
-        };
+        auto window_source = [&](int nc) { hsrc = chunk_source(p, nc, &hCs) + (tid & 3) * 4; };
         window_source(cb + 1 < ce ? cb + 1 : cb);
         for (int slab = 0; slab < n_slabs; ++slab) {
             const bool has_next = slab + 1 < n_slabs;
@@ -845,14 +854,14 @@ static int launch_one(const ConvParams& p, hipStream_t s) {
         // (a folded upsample conv is priced as the reference's op: 9 taps at the output resolution)
         const double pix = (double)p.B * p.Ho * p.Wo * (p.fold ? 4 : 1);
         const double cin = p.C0 + p.C1;
-        const double in_pix = (double)p.B * (p.up ? (p.Hin / 2) * (p.Win / 2) : p.Hin * p.Win);
-        const double taps = p.fold ? 9.0 : (double)p.KH * p.KW;
+        const double in_pix = (double)p.B * (p.up ? (p.Hin / 2) * (p.Win / 2) : p.Hin * p.Win) * (p.s2d ? 4 : 1);
+        const double taps = p.fold ? 9.0 : (p.s2d ? 4.0 : (double)p.KH * p.KW);
         const double flops = 2.0 * taps * cin * p.Cout * pix;
         const double bytes = 4.0 * (cin * in_pix + p.Cout * pix + taps * cin * p.Cout);
         char name[64];
         if (prof::detail())
             snprintf(name, sizeof(name), "conv<%d,%d,%d> %dx%d s%d %d+%d->%d @%dx%d%s e%d k%d t%d", WM, WN, CK, p.KH,
-                     p.KW, p.stride, p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.fold ? " upfold" : (p.up ? " up" : ""), p.epi, g.splits, g.TPS);
+                     p.KW, p.stride, p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.fold ? " upfold" : (p.up ? " up" : (p.s2d ? " s2d" : "")), p.epi, g.splits, g.TPS);
         else
             snprintf(name, sizeof(name), "conv_mfma_kernel<%d,%d,%d,%d>", WM, WN, CK, TPSC);
         if (prof::begin(name, flops, bytes, s)) return 1;
@@ -902,6 +911,9 @@ int conv_launch(const ConvParams& pin, hipStream_t s) {
     DM_REQUIRE(!p.partial || !p.out_nchw, "conv: partial sums are NHWC");
     DM_REQUIRE(!p.in_nchw || p.C1 == 0, "conv: NCHW input supports one source");
     DM_REQUIRE(!p.up || ((p.Hin % 2 == 0) && (p.Win % 2 == 0)), "conv: upsampled input must be even");
+    DM_REQUIRE(!p.s2d || (CK == 16 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.C1 == 0 && !p.up &&
+                          !p.fold && !p.in_nchw && p.C0 % 16 == 0 && p.n_chunks == 4 * (p.C0 / 16)),
+               "conv: space-to-depth mode");
     DM_REQUIRE(p.KW % g.TPS == 0, "conv: taps per slab must divide KW");
     {
         // the row epilogue addresses the output with 24-bit pixel indices and 32-bit byte offsets

@@ -404,6 +404,16 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
         p.Ho = p.Hin; p.Wo = p.Win;
         out_h = Hin; out_w = Win;
         p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, 2, 2, 1, L.C0, L.C1, want_norm, true, 4);
+    } else if (L.KH == 2 && L.KW == 2 && L.stride == 2 && L.pad == 0 && !L.up && L.C1 == 0 && L.C0 % 16 == 0 &&
+               !in_nchw && Hin % 2 == 0 && Win % 2 == 0) {
+        // Downsample: space-to-depth, then a 1x1 convolution over 4*C0 channels (ConvParams::s2d)
+        p.fold = 0; p.fold_w_stride = 0; p.up = 0; p.s2d = 1;
+        p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+        p.Ho = Hin / 2; p.Wo = Win / 2;
+        p.Hin = p.Ho; p.Win = p.Wo;
+        p.chunks0 = p.n_chunks = 4 * (L.C0 / 16);
+        out_h = p.Ho; out_w = p.Wo;
+        p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, 1, 1, 1, 4 * L.C0, 0, want_norm && !out_nchw, !out_nchw);
     } else {
         p.fold = 0; p.fold_w_stride = 0; p.up = L.up ? 1 : 0;
         p.KH = L.KH; p.KW = L.KW;

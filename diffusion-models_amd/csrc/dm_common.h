@@ -85,6 +85,10 @@ struct ConvParams {
     // W' = sums of the 3x3 taps that hit the same source pixel.  4/9 of the multiply-adds.  Ho/Wo are the
     // source-grid dims; the output tensor is (2Ho, 2Wo).
     int fold;
+    // 2x2 / stride-2 convolution (Downsample = pixel-unshuffle + 1x1, :54-58) executed as a 1x1 convolution whose K
+    // chunks run over (cin chunk, tap): no overlapping window, so the tile stages only its own 4 source pixels per
+    // output pixel.  Hin/Win are the OUTPUT dims; KH = KW = 1 in the kernel; n_chunks = 4 * C0/16.
+    int s2d;
     int fold_w_stride;   // floats between the four packed weight sets
     unsigned long long* stamps;  // diagnostic build (-DDM_STAMPS) only: per-workgroup phase cycle sums
     int epi;
