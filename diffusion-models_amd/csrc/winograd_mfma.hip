@@ -39,13 +39,17 @@ namespace dm {
 static constexpr int WCK = 8;     // input channels per K chunk
 static constexpr int WTS = 68;    // padded row stride of the transposed epilogue tiles (floats)
 
-// tell the compiler a pointer is wave-uniform (keeps it in SGPRs so that loads use the saddr + voffset form)
-__device__ __forceinline__ gfloat_ptr uniform_ptr(const float* ptr) {
-    const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (gfloat_ptr)(((unsigned long long)hi << 32) | lo);
+// 16-byte load through a buffer resource: base and size in 4 SGPRs, byte offset = VGPR part (per lane, loop invariant)
+// + SGPR part (per chunk / xi / column, scalar arithmetic): no vector address arithmetic at all.  Reads past the
+// size return 0.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)min(bytes, (size_t)0xFFFFFFFFu),
+                                             0x00020000);
 }
+__device__ __forceinline__ f32x4 bufload4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, (int)soff_bytes, 0));
+}
+
 static inline int w_pow2ceil(int v) {
     int p = 1;
     while (p < v) p <<= 1;
@@ -212,21 +216,22 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
         }
     }
     f32x4 hreg[HR];
-    // Addresses are (wave-uniform base) + (32-bit lane offset): the loads take the base from SGPRs and need no
-    // 64-bit vector arithmetic.  Pixel index and channel count are < 2^24 (wino_launch checks): one full-rate
-    // v_mul_u32_u24 per address.
-    gfloat_ptr hsrc = nullptr;  // uniform
-    unsigned hCs = 0;
+    // Window loads: per-lane byte offset hvo[i] = (pixel * C_source + quad) * 4 (recomputed only when the source
+    // changes), per-chunk scalar offset = first channel of the chunk.  Pixel index and channel count are < 2^24
+    // and the tensors < 2^30 elements (wino_launch checks).
+    const size_t in_px = (size_t)p.B * p.Hin * p.Win;
+    const __amdgpu_buffer_rsrc_t rs_in0 = make_rsrc(p.in0, in_px * p.C0 * 4);
+    const __amdgpu_buffer_rsrc_t rs_in1 = make_rsrc(p.C1 ? p.in1 : p.in0, in_px * (p.C1 ? p.C1 : p.C0) * 4);
     const unsigned hq = 4 * (tid & 1);
-    auto window_source = [&](int chunk) {
+    unsigned hvo[HR];
+    auto window_offsets = [&](unsigned Cs) {
+#pragma unroll
+        for (int i = 0; i < HR; ++i) hvo[i] = (__umul24((unsigned)hpix[i], Cs) + hq) * 4;
+    };
+    auto window_value = [&](int chunk, int i) {
         const bool s1 = chunk >= p.chunks0;
-        hsrc = uniform_ptr((s1 ? p.in1 : p.in0) + (s1 ? chunk - p.chunks0 : chunk) * WCK);
-        hCs = s1 ? p.C1 : p.C0;
+        return bufload4(s1 ? rs_in1 : rs_in0, hvo[i], (unsigned)(s1 ? chunk - p.chunks0 : chunk) * (WCK * 4));
     };
-    auto window_value = [&](int i) {
-        return gload4(hsrc, __umul24((unsigned)hpix[i], hCs) + hq);
-    };
-    auto load_window = [&](int i) { hreg[i] = window_value(i); };
     auto store_window = [&](float* raw, int i) { *reinterpret_cast<f32x4*>(raw + hoff[i]) = hreg[i]; };
 
     // ---- input transform of this lane: tiles l31 (and 32 + l31), channel quad lh, row `wave` of B^T d
@@ -251,12 +256,14 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
     f32x4 A[4][R];  // V[wave][j] of tile r: channels 4*lh .. 4*lh+3 of the chunk
     f32x4 U[4][2];  // U[wave*4 + j][cout 32*q + l31][channels 4*lh ..]
     const size_t u_chunk = (size_t)16 * p.Cout * WCK;
-    const float* __restrict__ ucur =  // uniform
-        p.w + (size_t)cb * u_chunk + ((size_t)(4 * wave) * p.Cout + n_tile * 64) * WCK;
-    const unsigned ulane = l31 * WCK + 4 * lh;
-    auto load_u = [&](gfloat_ptr ub, int j) {
-        U[j][0] = gload4(ub + (size_t)j * p.Cout * WCK, ulane);
-        U[j][1] = gload4(ub + ((size_t)j * p.Cout + 32) * WCK, ulane);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (size_t)p.n_chunks * u_chunk * 4);
+    const unsigned uvo = (l31 * WCK + 4 * lh) * 4;  // bytes
+    const unsigned u_row = (unsigned)p.Cout * WCK * 4;  // bytes between consecutive xi
+    const unsigned u_wave = ((unsigned)(4 * wave) * p.Cout + n_tile * 64) * WCK * 4;
+    auto load_u = [&](int chunk, int j) {  // U of (chunk, xi = 4*wave + j): couts l31 and 32 + l31
+        const unsigned so = (unsigned)chunk * (unsigned)(u_chunk * 4) + u_wave + j * u_row;
+        U[j][0] = bufload4(rs_w, uvo, so);
+        U[j][1] = bufload4(rs_w, uvo, so + 32 * WCK * 4);
     };
 
     f32x16 acc[4][R][2];  // first written by the first chunk's MFMAs (C = 0)
@@ -267,15 +274,15 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
     {
         const bool two = cb + 1 < ce;
         f32x4 h2[HR];
-        window_source(cb);
+        window_offsets(cb >= p.chunks0 ? p.C1 : p.C0);
 #pragma unroll
-        for (int i = 0; i < HR; ++i) load_window(i);
-        window_source(two ? cb + 1 : cb);
+        for (int i = 0; i < HR; ++i) hreg[i] = window_value(cb, i);
+        const int c1 = two ? cb + 1 : cb;
+        if (c1 == p.chunks0) window_offsets(p.C1);
 #pragma unroll
-        for (int i = 0; i < HR; ++i)
-            h2[i] = window_value(i);
+        for (int i = 0; i < HR; ++i) h2[i] = window_value(c1, i);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) load_u(uniform_ptr(ucur), j);
+        for (int j = 0; j < 4; ++j) load_u(cb, j);
 #pragma unroll
         for (int i = 0; i < HR; ++i) store_window(raw0, i);
 #pragma unroll
@@ -313,9 +320,9 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
         const int par = (c - cb) & 1;
         const float* rawn = par ? raw0 : raw1;  // chunk c + 1 (stored during iteration c - 1 / the prologue)
         float* rawst = par ? raw1 : raw0;       // chunk c was read from here during iteration c - 1: free
-        window_source(has2 ? c + 2 : c);
-        const float* unext_g = has1 ? ucur + u_chunk : ucur;  // never reads past the packed weights
-        gfloat_ptr unext = uniform_ptr(unext_g);
+        const int cw = has2 ? c + 2 : c;   // chunk whose window is fetched now (c again at the end: never read)
+        const int unext = has1 ? c + 1 : c;  // chunk whose weights are fetched now (never past the packed weights)
+        if (cw == p.chunks0 && p.C1 != p.C0) window_offsets(p.C1);  // uniform, once per kernel, outside the MFMA stream
         f32x4 T[R][4];
         __builtin_amdgcn_s_setprio(0);
         if constexpr (R == 2) {
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
                             const int m = ((j * 4 + s) * 2 + r) * 2 + q;  // 0..63
                             acc[j][r][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                                 A[j][r][s], U[j][q][s], (FIRST && s == 0) ? zero16 : acc[j][r][q], 0, 0, 0);
-                            if (m < HR) load_window(m);  // chunk c + 2 (or c again at the end: never read)
+                            if (m < HR) hreg[m] = window_value(cw, m);
                             if (m >= 6 && m < 14) d[m - 6] = rd(rawn, 0, (m - 6) >> 2, (m - 6) & 3);
                             if (m >= 14 && m < 18) T[0][m - 14] = fma4(d[4 + m - 14], sgn2, d[m - 14]);
                             if (m == 16) load_u(unext, 0);  // the MFMAs of j = 0 were issued by m = 15
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
                         const int m = (j * 4 + s) * 2 + q;  // 0..31
                         acc[j][0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                             A[j][0][s], U[j][q][s], (FIRST && s == 0) ? zero16 : acc[j][0][q], 0, 0, 0);
-                        if (m < HR) load_window(m);
+                        if (m < HR) hreg[m] = window_value(cw, m);
                         if (m >= 3 && m < 7) d[m - 3] = rd(rawn, 0, (m - 3) & 1, (m - 3) >> 1);  // columns 0, 1
                         if (m == 8) load_u(unext, 0);  // j = 0 done at m = 7
                         if (m == 11) T[0][0] = fma4(d[1], sgn2, d[0]);
@@ -389,7 +396,6 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
         }
         load_u(unext, 3);
         __builtin_amdgcn_s_setprio(1);
-        ucur = unext_g;
         __syncthreads();
     };
     chunk_body(cb, std::true_type{});
