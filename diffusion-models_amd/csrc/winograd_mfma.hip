@@ -252,6 +252,21 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
     auto rd = [&](const float* raw, int r, int ab, int b) {  // patch row ra (ab = 0) or rb (1), column b, of tile r
         return *reinterpret_cast<const f32x4*>(raw + rbase[r] + (ab ? offb : offa) + b * WCK);
     };
+    // the same addresses precomputed per LDS buffer: in the main loop (which is unrolled over the two buffers) every
+    // LDS access is then a register base + an immediate offset
+    const float* rdp[2][R][2];  // [buffer][tile r][row a / row b]
+    float* stp[2][HR];          // [buffer][window item]
+#pragma unroll
+    for (int bf = 0; bf < 2; ++bf) {
+        float* base = bf ? raw1 : raw0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            rdp[bf][r][0] = base + rbase[r] + offa;
+            rdp[bf][r][1] = base + rbase[r] + offb;
+        }
+#pragma unroll
+        for (int i = 0; i < HR; ++i) stp[bf][i] = base + hoff[i];
+    }
 
     f32x4 A[4][R];  // V[wave][j] of tile r: channels 4*lh .. 4*lh+3 of the chunk
     f32x4 U[4][2];  // U[wave*4 + j][cout 32*q + l31][channels 4*lh ..]
@@ -314,15 +329,20 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
     f32x16 zero16;
 #pragma unroll
     for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
-    auto chunk_body = [&](int c, auto first_tag) {
+    auto chunk_body = [&](int c, auto first_tag, auto par_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int PAR = decltype(par_tag)::value;  // (c - cb) & 1
         const bool has1 = c + 1 < ce, has2 = c + 2 < ce;
-        const int par = (c - cb) & 1;
-        const float* rawn = par ? raw0 : raw1;  // chunk c + 1 (stored during iteration c - 1 / the prologue)
-        float* rawst = par ? raw1 : raw0;       // chunk c was read from here during iteration c - 1: free
+        // chunk c + 1 sits in buffer PAR ^ 1 (stored during iteration c - 1 / the prologue); chunk c was read from
+        // buffer PAR during iteration c - 1, so it is free for chunk c + 2
+        constexpr int BN = PAR ^ 1, BS = PAR;
         const int cw = has2 ? c + 2 : c;   // chunk whose window is fetched now (c again at the end: never read)
         const int unext = has1 ? c + 1 : c;  // chunk whose weights are fetched now (never past the packed weights)
-        if (cw == p.chunks0 && p.C1 != p.C0) window_offsets(p.C1);  // uniform, once per kernel, outside the MFMA stream
+        if (cw == p.chunks0 && p.C1 != p.C0) {  // uniform, once per kernel, outside the MFMA stream
+            window_offsets(p.C1);
+            asm volatile("" ::: "memory");  // keep this a branch: if-converted it costs a select per offset and chunk
+        }
+        auto rdn = [&](int r, int ab, int b) { return *reinterpret_cast<const f32x4*>(rdp[BN][r][ab] + b * WCK); };
         f32x4 T[R][4];
         __builtin_amdgcn_s_setprio(0);
         if constexpr (R == 2) {
@@ -339,10 +359,10 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
                             acc[j][r][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                                 A[j][r][s], U[j][q][s], (FIRST && s == 0) ? zero16 : acc[j][r][q], 0, 0, 0);
                             if (m < HR) hreg[m] = window_value(cw, m);
-                            if (m >= 6 && m < 14) d[m - 6] = rd(rawn, 0, (m - 6) >> 2, (m - 6) & 3);
+                            if (m >= 6 && m < 14) d[m - 6] = rdn(0, (m - 6) >> 2, (m - 6) & 3);
                             if (m >= 14 && m < 18) T[0][m - 14] = fma4(d[4 + m - 14], sgn2, d[m - 14]);
                             if (m == 16) load_u(unext, 0);  // the MFMAs of j = 0 were issued by m = 15
-                            if (m >= 18 && m < 26) d[m - 18] = rd(rawn, 1, (m - 18) >> 2, (m - 18) & 3);
+                            if (m >= 18 && m < 26) d[m - 18] = rdn(1, (m - 18) >> 2, (m - 18) & 3);
                             if (m >= 26 && m < 30) T[1][m - 26] = fma4(d[4 + m - 26], sgn2, d[m - 26]);
                             if (m == 30) {
                                 A[0][0] = sub4(T[0][0], T[0][2]);
@@ -358,7 +378,7 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
                                 A[2][1] = sub4(T[1][2], T[1][1]);
                             }
                             if (m == 49) load_u(unext, 2);
-                            if (m >= 56 && m < 56 + HR) store_window(rawst, m - 56);
+                            if (m >= 56 && m < 56 + HR) *reinterpret_cast<f32x4*>(stp[BS][m - 56]) = hreg[m - 56];
                             __builtin_amdgcn_sched_barrier(0);
                         }
             A[3][0] = sub4(T[0][1], T[0][3]);
@@ -375,11 +395,11 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
                         acc[j][0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                             A[j][0][s], U[j][q][s], (FIRST && s == 0) ? zero16 : acc[j][0][q], 0, 0, 0);
                         if (m < HR) hreg[m] = window_value(cw, m);
-                        if (m >= 3 && m < 7) d[m - 3] = rd(rawn, 0, (m - 3) & 1, (m - 3) >> 1);  // columns 0, 1
+                        if (m >= 3 && m < 7) d[m - 3] = rdn(0, (m - 3) & 1, (m - 3) >> 1);  // columns 0, 1
                         if (m == 8) load_u(unext, 0);  // j = 0 done at m = 7
                         if (m == 11) T[0][0] = fma4(d[1], sgn2, d[0]);
                         if (m == 12) T[0][1] = fma4(d[3], sgn2, d[2]);
-                        if (m >= 13 && m < 17) d[m - 13] = rd(rawn, 0, (m - 13) & 1, 2 + ((m - 13) >> 1));  // columns 2, 3
+                        if (m >= 13 && m < 17) d[m - 13] = rdn(0, (m - 13) & 1, 2 + ((m - 13) >> 1));  // columns 2, 3
                         if (m == 17) load_u(unext, 1);  // j = 1 done at m = 15
                         if (m == 21) T[0][2] = fma4(d[1], sgn2, d[0]);
                         if (m == 22) {
@@ -389,7 +409,7 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
                         if (m == 23) A[1][0] = add4(T[0][1], T[0][2]);
                         if (m == 24) load_u(unext, 2);  // j = 2 done at m = 23
                         if (m == 25) A[2][0] = sub4(T[0][2], T[0][1]);
-                        if (m >= 27 && m < 27 + HR) store_window(rawst, m - 27);
+                        if (m >= 27 && m < 27 + HR) *reinterpret_cast<f32x4*>(stp[BS][m - 27]) = hreg[m - 27];
                         __builtin_amdgcn_sched_barrier(0);
                     }
             A[3][0] = sub4(T[0][1], T[0][3]);
@@ -398,8 +418,17 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
         __builtin_amdgcn_s_setprio(1);
         __syncthreads();
     };
-    chunk_body(cb, std::true_type{});
-    for (int c = cb + 1; c < ce; ++c) chunk_body(c, std::false_type{});
+    {
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        chunk_body(cb, std::true_type{}, P0{});
+        int c = cb + 1;
+        for (; c + 1 < ce; c += 2) {
+            chunk_body(c, std::false_type{}, P1{});
+            chunk_body(c + 1, std::false_type{}, P0{});
+        }
+        if (c < ce) chunk_body(c, std::false_type{}, P1{});
+    }
 
     DM_STAMP_ADD(1)
     // ---- epilogue: R_i[b] = sum_j M[i][j] A[j][b] per wave, then Y[a][b] = sum_i A^T[a][i] R_i[b] through LDS.
