@@ -182,7 +182,7 @@ def main():
         # separate runs, FETCH_SIZE doubled per the gfx950 correction); collected offline, see profiles/
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r1_step8_pmc_hbm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r1_step9_pmc_hbm_traffic.json")) as f:
                 pmc = {k.replace(" ", ""): v for k, v in json.load(f).items()}
             t = pmc.get(top["kernel"].replace(" ", ""))
             if t:
