@@ -13,7 +13,12 @@ from .spec import (  # noqa: F401
 )
 from .synth import synth_state_dict, synth_tensor  # noqa: F401
 from .unet import Unet  # noqa: F401
-from .diffusion import DenoisingDiffusion, LatentDiffusion, TextConditionalDenoisingDiffusion  # noqa: F401
+from .diffusion import (  # noqa: F401
+    DenoisingDiffusion,
+    ImageConditionalDenoisingDiffusion,
+    LatentDiffusion,
+    TextConditionalDenoisingDiffusion,
+)
 from .vae import VQDecoder  # noqa: F401
 from .dist import gather_shards, sample_sharded, shard_bounds  # noqa: F401
 from .checkpoint import load_trainer_checkpoint, load_vae_checkpoint  # noqa: F401
@@ -22,6 +27,7 @@ __all__ = [
     "Unet",
     "DenoisingDiffusion",
     "TextConditionalDenoisingDiffusion",
+    "ImageConditionalDenoisingDiffusion",
     "LatentDiffusion",
     "VQDecoder",
     "sample_sharded",

@@ -20,7 +20,7 @@ ABI_VERSION = 1
 EXPORTS = (
     "dm_last_error", "dm_abi_version",
     "dm_unet_create", "dm_unet_destroy", "dm_unet_set_param", "dm_unet_missing_params", "dm_unet_finalize",
-    "dm_unet_forward", "dm_sample", "dm_randn",
+    "dm_unet_forward", "dm_sample", "dm_sample_cond", "dm_randn",
     "dm_decoder_create", "dm_decoder_destroy", "dm_decoder_set_param", "dm_decoder_missing_params",
     "dm_decoder_finalize", "dm_decoder_forward",
     "dm_op_conv2d", "dm_op_downsample", "dm_op_rmsnorm", "dm_op_block", "dm_op_linear_attention",
@@ -69,6 +69,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_unet_forward.argtypes = [vp, fp, vp, fp, i32, fp, i32, i32, i32, vp]
     lib.dm_sample.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, u64, fp, i32, fp, fp,
                               i32, i32, i32, i32, i32, vp]
+    lib.dm_sample_cond.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, u64, fp, i32, fp, i32,
+                                   fp, fp, i32, i32, i32, i32, i32, vp]
     lib.dm_randn.argtypes = [fp, i64, u64, u64, vp]
     lib.dm_decoder_create.argtypes = [C.POINTER(DecoderCfg), i32, C.POINTER(vp)]
     lib.dm_decoder_destroy.argtypes = [vp]

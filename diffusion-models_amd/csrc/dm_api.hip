@@ -901,20 +901,29 @@ int dm_unet_forward(dm_unet* u, const float* x, const int64_t* time, const float
     return unet_forward_impl(u, A, x, time, nullptr, nullptr, ctx, ctx_tokens, out, B, H, W, s);
 }
 
-int dm_sample(dm_unet* u, int kind, int n_steps, const int64_t* times_host, const float* coefs_host,
-              const float* x_T, const float* noise, uint64_t seed, const float* ctx, int ctx_tokens, float* out,
-              float* all_steps, int B, int H, int W, int unnormalize, int use_graph, void* stream) {
+}  // extern "C"
+
+// The sampling loop behind dm_sample / dm_sample_cond.  cond (B, cond_channels, H, W) is the image condition of
+// DD/denoising_diffusion_image_conditional.py:51-55,156-180: constant over the loop, concatenated behind x in front of
+// init_conv at every step.
+static int sample_impl(dm_unet* u, int kind, int n_steps, const int64_t* times_host, const float* coefs_host,
+                       const float* x_T, const float* noise, uint64_t seed, const float* ctx, int ctx_tokens,
+                       const float* cond, int cond_channels, float* out, float* all_steps, int B, int H, int W,
+                       int unnormalize, int use_graph, void* stream) {
     DM_REQUIRE(u && times_host && coefs_host && x_T && out, "null argument");
     DM_REQUIRE(u->finalized, "dm_unet_finalize has not been called");
     DM_REQUIRE(kind == DM_SAMPLER_DDPM || kind == DM_SAMPLER_DDIM, "unknown sampler kind");
     DM_REQUIRE(n_steps > 0 && B > 0, "empty run");
     DM_REQUIRE(u->out_dim == u->cfg.channels, "sampler needs out_dim == channels (DD/denoising_diffusion.py:456)");
-    DM_REQUIRE(u->cfg.input_channels == u->cfg.channels, "sampler drives the unconditional / text U-Net input");
+    DM_REQUIRE((cond == nullptr) == (cond_channels == 0) && cond_channels >= 0, "cond and cond_channels come together");
+    DM_REQUIRE(u->cfg.input_channels == u->cfg.channels + cond_channels,
+               "U-Net input channels != channels + cond_channels (self-conditioning is not on this path)");
     if (check_hw(u, H, W)) return 1;
     DM_CHECK_HIP(hipSetDevice(u->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int C = u->cfg.channels;
     const int64_t n = (int64_t)B * C * H * W;
+    const int64_t n_in = (int64_t)B * (C + cond_channels) * H * W;
 
     if (n_steps > u->sampler_cap) {
         DM_CHECK_HIP(hipDeviceSynchronize());
@@ -930,6 +939,7 @@ int dm_sample(dm_unet* u, int kind, int n_steps, const int64_t* times_host, cons
     dry.dry = true;
     dry.alloc(n);
     dry.alloc(n);
+    if (cond) dry.alloc(n_in);
     if (unet_forward_impl(u, dry, nullptr, nullptr, u->times_dev, u->step_dev, ctx, ctx_tokens, nullptr, B, H, W, s))
         return 1;
     if (ensure_workspace(u, dry.off)) return 1;
@@ -945,13 +955,17 @@ int dm_sample(dm_unet* u, int kind, int n_steps, const int64_t* times_host, cons
     A.cap = u->ws_cap;
     float* xbuf = A.alloc(n);
     float* eps = A.alloc(n);
+    float* xin = cond ? A.alloc(n_in) : nullptr;  // [x | cond] per image, what init_conv reads
     const size_t arena_mark = A.off;
     DM_CHECK_HIP(hipMemcpyAsync(xbuf, x_T, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (cond && launch_copy_channels(cond, xin, B, cond_channels, C + cond_channels, C, H * W, s)) return 1;
     if (all_steps) DM_CHECK_HIP(hipMemcpyAsync(all_steps, x_T, n * sizeof(float), hipMemcpyDeviceToDevice, s));
 
     auto one_step = [&](hipStream_t st) -> int {
         A.off = arena_mark;
-        if (unet_forward_impl(u, A, xbuf, nullptr, u->times_dev, u->step_dev, ctx, ctx_tokens, eps, B, H, W, st))
+        if (cond && launch_copy_channels(xbuf, xin, B, C, C + cond_channels, 0, H * W, st)) return 1;
+        if (unet_forward_impl(u, A, cond ? xin : xbuf, nullptr, u->times_dev, u->step_dev, ctx, ctx_tokens, eps, B, H, W,
+                              st))
             return 1;
         if (launch_sampler_update(kind, xbuf, eps, noise, u->coefs_dev, u->step_dev, n, seed, xbuf, all_steps, out,
                                   unnormalize, n_steps, n, st))
@@ -991,6 +1005,24 @@ int dm_sample(dm_unet* u, int kind, int n_steps, const int64_t* times_host, cons
     (void)hipGraphDestroy(graph);
     if (own_stream) (void)hipStreamDestroy(cs);
     return 0;
+}
+
+extern "C" {
+
+int dm_sample(dm_unet* u, int kind, int n_steps, const int64_t* times_host, const float* coefs_host,
+              const float* x_T, const float* noise, uint64_t seed, const float* ctx, int ctx_tokens, float* out,
+              float* all_steps, int B, int H, int W, int unnormalize, int use_graph, void* stream) {
+    return sample_impl(u, kind, n_steps, times_host, coefs_host, x_T, noise, seed, ctx, ctx_tokens, nullptr, 0, out,
+                       all_steps, B, H, W, unnormalize, use_graph, stream);
+}
+
+int dm_sample_cond(dm_unet* u, int kind, int n_steps, const int64_t* times_host, const float* coefs_host,
+                   const float* x_T, const float* noise, uint64_t seed, const float* ctx, int ctx_tokens,
+                   const float* cond, int cond_channels, float* out, float* all_steps, int B, int H, int W,
+                   int unnormalize, int use_graph, void* stream) {
+    DM_REQUIRE(cond && cond_channels > 0, "dm_sample_cond needs a condition image");
+    return sample_impl(u, kind, n_steps, times_host, coefs_host, x_T, noise, seed, ctx, ctx_tokens, cond, cond_channels,
+                       out, all_steps, B, H, W, unnormalize, use_graph, stream);
 }
 
 int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, void* stream) {

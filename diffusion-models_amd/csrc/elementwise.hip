@@ -327,6 +327,21 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = a[i] + b[i];
 }
+// dst[b][c_off + c][sp] = src[b][c][sp]: places a (B, Cs, HW) tensor into channels [c_off, c_off + Cs) of (B, Cd, HW)
+__global__ void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t per_src,
+                                     int64_t per_dst, int64_t off, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t b = i / per_src, r = i - b * per_src;
+    dst[b * per_dst + off + r] = src[i];
+}
+int launch_copy_channels(const float* src, float* dst, int B, int Cs, int Cd, int c_off, int HW, hipStream_t s) {
+    const int64_t n = (int64_t)B * Cs * HW;
+    hipLaunchKernelGGL(copy_channels_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, (int64_t)Cs * HW,
+                       (int64_t)Cd * HW, (int64_t)c_off * HW, n);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(add_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, y, n);
     DM_CHECK_HIP(hipGetLastError());

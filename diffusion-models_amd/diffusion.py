@@ -124,7 +124,7 @@ class DenoisingDiffusion:
         return out
 
     def _run(self, kind, shape, times, coefs, takes_noise: Sequence[bool], return_all_timesteps, noise, seed,
-             text_emb=None, max_steps=None):
+             text_emb=None, max_steps=None, cond=None):
         shape = tuple(int(v) for v in shape)
         B, Cc, H, W = shape
         assert Cc == self.channels, f"shape has {Cc} channels, the model {self.channels}"
@@ -157,10 +157,18 @@ class DenoisingDiffusion:
         coefs = coefs[:n_steps].contiguous()
         coefs_ptr = C.cast(coefs.data_ptr(), C.POINTER(C.c_float))
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self._lib.dm_sample(
-            self.model._handle, kind, n_steps, times_arr, coefs_ptr, _lib.ptr(x_T), _lib.ptr(noise_dev),
-            C.c_uint64(seed), _lib.ptr(ctx), m, _lib.ptr(out), _lib.ptr(all_steps), B, H, W,
-            self._unnormalize_flag, 1 if self.use_graph else 0, stream))
+        if cond is not None:
+            cond = cond.to(self.device, torch.float32).contiguous()
+            assert cond.shape[0] == B and tuple(cond.shape[2:]) == (H, W), "batch / size mismatch between x and cond"
+            _lib.check(self._lib.dm_sample_cond(
+                self.model._handle, kind, n_steps, times_arr, coefs_ptr, _lib.ptr(x_T), _lib.ptr(noise_dev),
+                C.c_uint64(seed), _lib.ptr(ctx), m, _lib.ptr(cond), int(cond.shape[1]), _lib.ptr(out),
+                _lib.ptr(all_steps), B, H, W, self._unnormalize_flag, 1 if self.use_graph else 0, stream))
+        else:
+            _lib.check(self._lib.dm_sample(
+                self.model._handle, kind, n_steps, times_arr, coefs_ptr, _lib.ptr(x_T), _lib.ptr(noise_dev),
+                C.c_uint64(seed), _lib.ptr(ctx), m, _lib.ptr(out), _lib.ptr(all_steps), B, H, W,
+                self._unnormalize_flag, 1 if self.use_graph else 0, stream))
         if not return_all_timesteps:
             return out
         ret = all_steps.permute(1, 0, 2, 3, 4).contiguous()  # (B, n_steps+1, C, H, W) like torch.stack(imgs, dim=1)
@@ -267,6 +275,82 @@ class TextConditionalDenoisingDiffusion(DenoisingDiffusion):
         sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
         return sample_fn((batch_size, channels, h, w), save_path_for_text, return_all_timesteps=return_all_timesteps,
                          **kw)
+
+
+class ImageConditionalDenoisingDiffusion(DenoisingDiffusion):
+    """``ImageConditionalDenoisingDiffusion`` (denoising_diffusion_image_conditional.py:62-229): the condition image
+    is concatenated behind x in front of ``init_conv`` at every step (``Unet(cond_channels=...)``, :42-55).
+
+    ``cond=`` (B, cond_channels, H, W; the reference feeds ToTensor() images in [0, 1]) may be passed to every sampling method; without it the condition
+    batch is drawn from ``condition_data_folder`` as the reference does (:123-153, needs PIL + torchvision).  The
+    reference's ``sample()`` only works for the DDPM loop (its DDIM call passes ``return_condition_image`` into the
+    ``sampling_timesteps`` slot and never fetches a condition, :182,225-229); here both samplers take the condition."""
+
+    def __init__(self, *args, condition_data_folder=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.condition_data_folder = condition_data_folder
+        assert getattr(self.model.cfg, "cond_channels", 0) > 0, "the model was built without cond_channels"
+
+    def get_random_condition(self, batch, device):
+        """:123-153: `batch` random images of the folder, resized / centre-cropped to image_size."""
+        if self.condition_data_folder is None:
+            raise RuntimeError("no condition_data_folder given; pass cond= to the sampling call")
+        from pathlib import Path
+
+        from PIL import Image
+        from torchvision import transforms as T
+
+        tf = T.Compose([T.Resize(self.image_size), T.CenterCrop(self.image_size), T.ToTensor()])  # [0, 1], as :130-136
+        paths = random.choices(list(Path(self.condition_data_folder).glob("*.*")), k=batch)
+        return torch.stack([tf(Image.open(p).convert("RGB")) for p in paths], dim=0).to(device)
+
+    def _cond(self, batch, cond):
+        return cond if cond is not None else self.get_random_condition(batch, self.device)
+
+    @torch.inference_mode()
+    def p_sample_loop(self, shape, return_condition_image=False, return_all_timesteps=False, *, cond=None, noise=None,
+                      seed=None, max_steps=None):
+        # the reference draws x_T first, then the condition (:159-163); the order only matters for its global RNG
+        times, coefs = self._ddpm_tables()
+        cond = self._cond(shape[0], cond)
+        ret = self._run(DDPM, shape, times, coefs, [t > 0 for t in times], return_all_timesteps, noise, seed, None,
+                        max_steps, cond=cond)
+        return (cond, ret) if return_condition_image else ret
+
+    @torch.inference_mode()
+    def ddim_sample(self, shape, sampling_timesteps=None, cond=None, return_all_timesteps=False, *, noise=None,
+                    seed=None, max_steps=None):
+        if sampling_timesteps is None:
+            sampling_timesteps = self.sampling_timesteps
+        times, coefs = self._ddim_tables(sampling_timesteps)
+        cond = self._cond(shape[0], cond)
+        return self._run(DDIM, shape, times, coefs, [bool(c[5] != 0) for c in coefs], return_all_timesteps, noise, seed,
+                         None, max_steps, cond=cond)
+
+    @torch.inference_mode()
+    def sample(self, batch_size=16, return_condition_image=False, return_all_timesteps=False, *, cond=None, **kw):
+        (h, w), channels = self.image_size, self.channels
+        shape = (batch_size, channels, h, w)
+        if not self.is_ddim_sampling:
+            return self.p_sample_loop(shape, return_condition_image, return_all_timesteps, cond=cond, **kw)
+        cond = self._cond(batch_size, cond)
+        ret = self.ddim_sample(shape, None, cond, return_all_timesteps, **kw)
+        return (cond, ret) if return_condition_image else ret
+
+    @torch.inference_mode()
+    def p_sample(self, x, t: int, cond=None, x_self_cond=None, *, noise=None):
+        """:114-120."""
+        inner = self.model
+
+        class _WithCond:  # the parent's p_sample calls self.model(x, bt)
+            def __call__(_, xx, tt, **kw):
+                return inner(xx, tt, cond=cond)
+
+        self.model = _WithCond()
+        try:
+            return super().p_sample(x, t, noise=noise)
+        finally:
+            self.model = inner
 
 
 class LatentDiffusion(DenoisingDiffusion):

@@ -110,6 +110,15 @@ int dm_sample(dm_unet* u, int kind, int n_steps, const int64_t* times_host, cons
               const float* x_T, const float* noise, uint64_t seed, const float* ctx, int ctx_tokens,
               float* out, float* all_steps, int B, int H, int W, int unnormalize, int use_graph, void* stream);
 
+/* The same loop for the image-conditional variant (replaces ImageConditionalDenoisingDiffusion.p_sample_loop /
+ * ddim_sample, DD/denoising_diffusion_image_conditional.py:156-224; its Unet.forward concatenates `cond` behind x in
+ * front of init_conv, :51-55).  cond is (B, cond_channels, H, W) fp32 on the device, constant over the loop; the
+ * handle must have input_channels == channels + cond_channels. */
+int dm_sample_cond(dm_unet* u, int kind, int n_steps, const int64_t* times_host, const float* coefs_host,
+                   const float* x_T, const float* noise, uint64_t seed, const float* ctx, int ctx_tokens,
+                   const float* cond, int cond_channels, float* out, float* all_steps, int B, int H, int W,
+                   int unnormalize, int use_graph, void* stream);
+
 /* N(0,1) noise from the library's Philox4x32-10 stream (what dm_sample uses when noise == NULL);
  * element e of the tensor of draw `draw` uses counter (e/4, draw) under key `seed`. */
 int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, void* stream);

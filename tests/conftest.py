@@ -53,3 +53,9 @@ def golden_vae():
 @pytest.fixture(scope="session")
 def golden_schedule():
     return load_golden("schedule.pt")
+
+
+@pytest.fixture(scope="session")
+def golden_imgcond():
+    """Image-conditional variant (tests/golden/make_golden_imgcond.py)."""
+    return load_golden("imgcond.pt")

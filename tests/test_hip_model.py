@@ -187,3 +187,26 @@ def test_latent_diffusion_sample_shape(golden_vae):
     assert img.shape == (2, 3, 32, 32)
     assert lat.min() >= -1.0 and lat.max() <= 1.0  # identity unnormalize: clamp(x0) stays in [-1, 1]
     assert rel_l2(vae.decode(lat), img) < 1e-6
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_image_conditional(golden_imgcond, use_graph):
+    """ImageConditionalDenoisingDiffusion (dm_sample_cond): condition concatenated in front of init_conv every step."""
+    g = golden_imgcond
+    u = build_unet(salt=7, dim=32, dim_mults=(1, 2), channels=3, cond_channels=3)
+    b = g["unet_imgcond"]
+    err = rel_l2(u(b["x"], b["t"], cond=b["cond"]).cpu(), b["y"])
+    print("unet_imgcond", err)
+    assert err < FWD_TOL
+    d = dm.ImageConditionalDenoisingDiffusion(u, image_size=16, timesteps=50, use_graph=use_graph)
+    b = g["imgcond_ddpm50"]
+    cond, y = d.sample(batch_size=2, return_condition_image=True, cond=b["cond"], noise=so.NoiseStream(b["seed"]))
+    assert torch.equal(cond.cpu(), b["cond"])
+    print("imgcond_ddpm50", use_graph, rel_l2(y.cpu(), b["y"]))
+    assert rel_l2(y.cpu(), b["y"]) < LOOP_TOL
+    b = g["imgcond_ddim7"]
+    y = d.ddim_sample(b["shape"], sampling_timesteps=b["S"], cond=b["cond"], noise=so.NoiseStream(b["seed"])).cpu()
+    print("imgcond_ddim7", use_graph, rel_l2(y, b["y"]))
+    assert rel_l2(y, b["y"]) < LOOP_TOL
+    with pytest.raises(RuntimeError):
+        d.sample(batch_size=2)  # no folder and no cond=

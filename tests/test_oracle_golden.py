@@ -203,3 +203,18 @@ def test_full_ddim50(golden_samplers):
     y = so.ddim_sample(lambda x, t: uo.unet_forward(sd, cfg, x, t), dm.make_schedule(1000, "linear"),
                        b["shape"], so.NoiseStream(b["seed"]), b["S"], eta=b["eta"])
     assert rel_l2(y, b["y"]) < 1e-4
+
+
+def test_image_conditional(golden_imgcond):
+    """DD/denoising_diffusion_image_conditional.py: cond is concatenated behind x in front of init_conv (:51-55)
+    and held constant over the loop (:156-224)."""
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3, cond_channels=3)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=7)
+    b = golden_imgcond["unet_imgcond"]
+    assert rel_l2(uo.unet_forward(sd, cfg, b["x"], b["t"], cond=b["cond"]), b["y"]) < TOL
+    sched = dm.make_schedule(50, "linear")
+    b = golden_imgcond["imgcond_ddpm50"]
+    model = lambda x, t: uo.unet_forward(sd, cfg, x, t, cond=b["cond"])  # noqa: E731
+    assert rel_l2(so.p_sample_loop(model, sched, b["shape"], so.NoiseStream(b["seed"])), b["y"]) < 1e-4
+    b = golden_imgcond["imgcond_ddim7"]
+    assert rel_l2(so.ddim_sample(model, sched, b["shape"], so.NoiseStream(b["seed"]), b["S"]), b["y"]) < 1e-4
