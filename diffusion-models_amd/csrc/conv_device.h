@@ -144,7 +144,11 @@ __device__ __forceinline__ void rows_prefetch(const ConvParams& p, const RowsEpi
     // fields are only read by rows_epilogue under the same epilogue flags they are loaded under: no defaults
     const int cgc = cvalid ? cg : 0;
 #pragma unroll
-    for (int j = 0; j < NR; ++j) f.off[j] = __umul24((unsigned)max(pixv[j], 0), (unsigned)p.Cout) + cgc;
+    for (int j = 0; j < NR; ++j) {
+        // full-rate 24-bit multiply while pixel indices allow it (they do for every benchmark shape)
+        const unsigned px = (unsigned)max(pixv[j], 0);
+        f.off[j] = (e.M < (1u << 24) ? __umul24(px, (unsigned)p.Cout) : px * (unsigned)p.Cout) + cgc;
+    }
     if (p.partial) return;
     const int epi = p.epi;
     if (epi & EPI_BIAS) f.b4 = *reinterpret_cast<const f32x4*>(p.bias + cgc);

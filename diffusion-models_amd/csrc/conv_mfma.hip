@@ -916,9 +916,9 @@ int conv_launch(const ConvParams& pin, hipStream_t s) {
                "conv: space-to-depth mode");
     DM_REQUIRE(p.KW % g.TPS == 0, "conv: taps per slab must divide KW");
     {
-        // the row epilogue addresses the output with 24-bit pixel indices and 32-bit byte offsets
+        // the row epilogue addresses the output with 32-bit byte offsets
         const size_t M = (size_t)p.B * p.Ho * p.Wo * (p.fold ? 4 : 1);
-        DM_REQUIRE(M < (1u << 24) && M * (size_t)p.Cout < (1ull << 30), "conv: output tensor too large (2^30 elements)");
+        DM_REQUIRE(M * (size_t)p.Cout < (1ull << 30), "conv: output tensor too large (2^30 elements)");
     }
     if (CK == 16) DM_REQUIRE(p.C0 % 4 == 0 && p.C1 % 4 == 0, "conv: CK16 needs C % 4 == 0");
     int red_floats = (p.epi & EPI_NORM) && g.WN > 1 ? g.WN * g.WM * 64 : 0;
