@@ -336,8 +336,9 @@ static int build_attn(dm_unet* u, AttnLayer& A, const std::string& p, int dim, b
                 std::vector<float> ogs(og.data);
                 for (float& v : ogs) v *= std::sqrt((float)dim);
                 float *dq, *dk, *dv, *dwo, *dkb, *dog;
+                const HostTensor& wor = P(u, p + ".to_out.0.weight");
                 if (u->own.upload(wq.data(), wq.size(), &dq) || u->own.upload(wk.data(), wk.size(), &dk) ||
-                    u->own.upload(wv.data(), wv.size(), &dv) || u->own.upload(wo.data(), wo.size(), &dwo) ||
+                    u->own.upload(wv.data(), wv.size(), &dv) || u->own.upload(wor.data.data(), wor.data.size(), &dwo) ||
                     u->own.upload(kb.data(), kb.size(), &dkb) || u->own.upload(ogs.data(), ogs.size(), &dog))
                     return 1;
                 A.fused = LinAttnFused{dim, dq, dk, dv, dwo, A.out.bias, dog, dkb, A.mem_kv};

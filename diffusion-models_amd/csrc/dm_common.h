@@ -189,7 +189,7 @@ int launch_attention_core(const float* q, int ldq, const float* k, const float* 
 struct LinAttnFused {
     int C;
     const float *wq, *wk, *wv;  // packed projections with the RMSNorm gain folded in
-    const float* wo;            // packed to_out weight
+    const float* wo_raw;        // to_out weight (C, 128) as in the state dict
     const float* bias;          // to_out bias [C]
     const float* og;            // to_out RMSNorm gain * sqrt(C) [C]
     const float* kbound;        // softmax shift per (head, d) [128]

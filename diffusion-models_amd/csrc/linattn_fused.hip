@@ -11,9 +11,10 @@
 //      invariant to the shift, so the bound replaces the running maximum: no max pass over the tokens, and partial
 //      sums of different token blocks simply add.  (Layers whose bound exceeds 40 -- exp(-2*bound) must stay a
 //      normal float -- keep the unfused path.)
-//   (a tiny kernel sums the block partials, divides by the denominators and packs the context in lane order)
-//   2. linattn_out_fused_kernel   (token block, image): q = W_q x^, softmax over dim_head, out = ctx^T q,
-//      z = W_out out + b, RMSNorm(z) * g, + x, one store.
+//   (a tiny kernel sums the block partials, divides by the denominators and folds the context into to_out:
+//    z = W_out (ctx^T q) = (W_out ctx^T) q =: M q with M (C x 32) per image and head, packed in lane order)
+//   2. linattn_out_fused_kernel   (token block, image): q = W_q x^, softmax over dim_head, z = M q + b,
+//      RMSNorm(z) * g, + x, one store.
 //
 // MFMA bookkeeping (v_mfma_f32_32x32x2_f32, wave = head): the accumulator of one product is used DIRECTLY as an
 // operand of the next one, without any data movement: accumulator register e of lane (l, half) is element
@@ -32,7 +33,8 @@ static constexpr int LA_DH = 32;
 static constexpr int LA_HEADS = 4;
 static constexpr int LA_HID = LA_DH * LA_HEADS;
 static constexpr int LA_CTX = LA_DH * LA_DH + LA_DH;  // partial context + partial denominators per (image, block, head)
-static constexpr int LA_TOK1 = 128;                   // tokens per workgroup, kernel 1
+static constexpr int LA_TOK1 = 128;                   // tokens per workgroup, kernel 1 (C = 128; 256 for C = 64)
+__host__ __device__ constexpr int la_tok1(int C) { return C <= 64 ? 256 : LA_TOK1; }
 static constexpr int LA_TOK2 = 64;                    // tokens per workgroup, kernel 2
 
 __host__ __device__ static inline int la_row_of(int e, int half) { return (e & 3) + 8 * (e >> 2) + 4 * half; }
@@ -47,7 +49,7 @@ bool linattn_fused_eligible(int C, int heads, int dh) {
 bool linattn_fused_pack(const float* w_qkv, const float* norm_g, const float* w_out, const float* mem_kv, int C,
                         std::vector<float>& wq, std::vector<float>& wk, std::vector<float>& wv, std::vector<float>& wo,
                         std::vector<float>& kbound) {
-    const int G = C / 8, MT = C / 32;
+    const int G = C / 8;
     const float sq = std::sqrt((float)C);
     auto pack_proj = [&](int which, std::vector<float>& dst) {
         // [head][g][lane = half*32 + l][4]: W'[head*32 + l][8g + 4*half + s],  W' = W * g * sqrt(C) per input channel
@@ -64,16 +66,8 @@ bool linattn_fused_pack(const float* w_qkv, const float* norm_g, const float* w_
     pack_proj(0, wq);
     pack_proj(1, wk);
     pack_proj(2, wv);
-    // [head][mt][e>>2][lane][e&3]: W_out[32*mt + l][head*32 + row_of(e, half)]
-    wo.assign((size_t)LA_HEADS * MT * 4 * 64 * 4, 0.f);
-    for (int h = 0; h < LA_HEADS; ++h)
-        for (int mt = 0; mt < MT; ++mt)
-            for (int e = 0; e < 16; ++e)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int l = lane & 31, half = lane >> 5;
-                    wo[((((size_t)h * MT + mt) * 4 + (e >> 2)) * 64 + lane) * 4 + (e & 3)] =
-                        w_out[(size_t)(32 * mt + l) * LA_HID + h * LA_DH + la_row_of(e, half)];
-                }
+    wo.clear();  // to_out is folded with the per-image context on the device (linattn_ctx_reduce_kernel)
+    (void)w_out;
     kbound.assign(LA_HID, 0.f);
     bool ok = true;
     for (int h = 0; h < LA_HEADS; ++h)
@@ -92,9 +86,9 @@ bool linattn_fused_pack(const float* w_qkv, const float* norm_g, const float* w_
 }
 
 size_t linattn_fused_ws_floats(int B, int n) {
-    const int nblk = (n + LA_TOK1 - 1) / LA_TOK1;
-    // per-block partial contexts, then the normalised context packed as the A operand of kernel 2
-    return (size_t)B * nblk * LA_HEADS * LA_CTX + (size_t)B * LA_HEADS * LA_DH * LA_DH;
+    const int nblk = (n + LA_TOK1 - 1) / LA_TOK1;  // upper bound over C
+    // per-block partial contexts, then M = W_out ctx^T per (image, head) packed as the A operand of kernel 2 (C <= 128)
+    return (size_t)B * nblk * LA_HEADS * LA_CTX + (size_t)B * LA_HEADS * 128 * LA_DH;
 }
 
 // x rows [t0, t0 + TOK) of image b -> LDS (zero rows past the image), rn[t] = 1 / max(||x_t||, 1e-12)
@@ -125,7 +119,7 @@ __device__ __forceinline__ void la_stage_rows(const float* __restrict__ xb, int 
 template <int C>
 __global__ __launch_bounds__(256) void linattn_ctx_fused_kernel(const float* __restrict__ x, const LinAttnFused w,
                                                                 float* __restrict__ ws, int n, int nblk) {
-    constexpr int G = C / 8, XS = C + 4, TOK = LA_TOK1;
+    constexpr int G = C / 8, XS = C + 4, TOK = la_tok1(C);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;
     float* rn = smem + TOK * XS;
@@ -201,31 +195,52 @@ __global__ __launch_bounds__(256) void linattn_ctx_fused_kernel(const float* __r
     if (lh == 0) cp[LA_DH * LA_DH + l31] = ksum;
 }
 
-// Sum the per-block partial contexts in block order, divide by the softmax denominator (k.softmax(dim=-1), :186) and
-// store the result in the lane order kernel 2 consumes: [image][head][e>>2][lane][e&3] = ctx[row_of(e, half)][l].
-__global__ __launch_bounds__(256) void linattn_ctx_reduce_kernel(const float* __restrict__ ws, float* __restrict__ ctxn,
-                                                                 int nblk) {
+// Sum the per-block partial contexts in block order, divide by the softmax denominator (k.softmax(dim=-1), :186), and
+// fold the result into to_out: out = ctx^T q (:189) followed by z = W_out[:, head] out (:191) is z = M q with
+// M[c][d] = sum_e W_out[c][head*32 + e] ctx[d][e].  M is stored in the lane order kernel 2 consumes as an MFMA A
+// operand: [image][head][mt][e>>2][lane][e&3] = M[32*mt + l][row_of(e, half)].
+template <int C>
+__global__ __launch_bounds__(256) void linattn_ctx_reduce_kernel(const float* __restrict__ ws,
+                                                                 const float* __restrict__ w_out,
+                                                                 float* __restrict__ mz, int nblk) {
+    constexpr int MT = C / 32;
+    __shared__ float cs[LA_DH][LA_DH + 1];  // normalised context [d][e]
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, e4 = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    f32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int d = la_row_of(4 * e4 + i, lh);
-        float cs = 0.f, ks = 0.f;
-        for (int k = 0; k < nblk; ++k) {
-            const float* cp = ws + (((size_t)b * nblk + k) * LA_HEADS + h) * LA_CTX;
-            cs += cp[d * LA_DH + l31];
-            ks += cp[LA_DH * LA_DH + d];
+        const int d = 8 * e4 + 4 * lh + i;  // every (d, e = l31) once
+        float c = 0.f, k = 0.f;
+        for (int kb = 0; kb < nblk; ++kb) {
+            const float* cp = ws + (((size_t)b * nblk + kb) * LA_HEADS + h) * LA_CTX;
+            c += cp[d * LA_DH + l31];
+            k += cp[LA_DH * LA_DH + d];
         }
-        o[i] = cs / ks;
+        cs[d][l31] = c / k;
     }
-    *reinterpret_cast<f32x4*>(ctxn + ((((size_t)b * LA_HEADS + h) * 4 + e4) * 64 + lane) * 4) = o;
+    __syncthreads();
+    // M^T (d x c) = ctx (d x e) W_out[:, head]^T (e x c) on the MFMA, one 32-channel column tile per wave: the
+    // accumulator layout (row d on the registers, column c on the lanes) IS the packed layout
+    const int mt = e4;
+    if (mt < MT) {
+        const float* wr = w_out + (size_t)(32 * mt + l31) * LA_HID + h * LA_DH;  // W_out[c][head*32 .. +32)
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 16; ++st)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cs[l31][2 * st + lh], wr[2 * st + lh], acc, 0, 0, 0);
+        float* op = mz + ((((size_t)b * LA_HEADS + h) * MT + mt) * 4) * 64 * 4 + lane * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(op + q * 64 * 4) = make_f32x4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
 }
 
 template <int C>
 __global__ __launch_bounds__(256) void linattn_out_fused_kernel(const float* __restrict__ x, const LinAttnFused w,
-                                                                const float* __restrict__ ctxn, float* __restrict__ y,
+                                                                const float* __restrict__ mz, float* __restrict__ y,
                                                                 int n, int add_x, float scale) {
     constexpr int G = C / 8, XS = C + 4, TOK = LA_TOK2, MT = C / 32, Q = C / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -241,13 +256,14 @@ __global__ __launch_bounds__(256) void linattn_out_fused_kernel(const float* __r
     f32x4 wq[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) wq[g] = *reinterpret_cast<const f32x4*>(w.wq + (((size_t)h * G + g) * 64 + lane) * 4);
-    // normalised context as the A operand of out = ctx^T q: step e reduces over d = row_of(e, half)
-    float actx[16];
+    // M of this image / head: the A operand of z = M q, loaded once
+    f32x4 mreg[MT][4];
+    {
+        const float* mzp = mz + ((size_t)b * LA_HEADS + h) * MT * 4 * 64 * 4 + lane * 4;
 #pragma unroll
-    for (int e4 = 0; e4 < 4; ++e4) {
-        const f32x4 c4 = *reinterpret_cast<const f32x4*>(ctxn + ((((size_t)b * LA_HEADS + h) * 4 + e4) * 64 + lane) * 4);
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) actx[4 * e4 + i] = c4[i];
+            for (int e4 = 0; e4 < 4; ++e4) mreg[mt][e4] = *reinterpret_cast<const f32x4*>(mzp + (mt * 4 + e4) * 64 * 4);
     }
     la_stage_rows<C, TOK>(x + ((size_t)b * n + t0) * C, nt, xs, rn);
     __syncthreads();
@@ -282,13 +298,9 @@ __global__ __launch_bounds__(256) void linattn_out_fused_kernel(const float* __r
         }
         ssum += __shfl_xor(ssum, 32);
         const float inv = scale / ssum;
-        // out (e x tokens) = ctx^T q: B operand of step e is q's accumulator register e
-        f32x16 oacc;
+        // this head's share of z (C x tokens) = M q: the B operand of step e is q's accumulator register e
 #pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(actx[e], qacc[e] * inv, oacc, 0, 0, 0);
-        // this head's share of z (C x tokens) = W_out[:, head] out; B operand of step e is out's register e
+        for (int e = 0; e < 16; ++e) qacc[e] *= inv;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             f32x16 zacc;
@@ -296,11 +308,9 @@ __global__ __launch_bounds__(256) void linattn_out_fused_kernel(const float* __r
             for (int e = 0; e < 16; ++e) zacc[e] = 0.f;
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
-                const f32x4 wo4 =
-                    *reinterpret_cast<const f32x4*>(w.wo + ((((size_t)h * MT + mt) * 4 + e4) * 64 + lane) * 4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    zacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wo4[i], oacc[4 * e4 + i], zacc, 0, 0, 0);
+                    zacc = __builtin_amdgcn_mfma_f32_32x32x2f32(mreg[mt][e4][i], qacc[4 * e4 + i], zacc, 0, 0, 0);
             }
             // register e = channel 32*mt + row_of(e, lh) of token l31: four consecutive channels per b128 store
             float* zr = zb + (h * 32 + l31) * XS + 32 * mt + 4 * lh;
@@ -332,8 +342,9 @@ __global__ __launch_bounds__(256) void linattn_out_fused_kernel(const float* __r
 
 template <int C>
 static int launch_c(const LinAttnFused& w, const float* x, float* ws, float* y, int B, int n, bool add_x, hipStream_t s) {
-    const int nblk = (n + LA_TOK1 - 1) / LA_TOK1;
-    const size_t lds1 = (size_t)(LA_TOK1 * (C + 4) + LA_TOK1) * 4;
+    constexpr int TOK1 = la_tok1(C);
+    const int nblk = (n + TOK1 - 1) / TOK1;
+    const size_t lds1 = (size_t)(TOK1 * (C + 4) + TOK1) * 4;
     const size_t lds2 = (size_t)(LA_TOK2 * (C + 4) + LA_TOK2 + LA_HEADS * 32 * (C + 4)) * 4;
     static bool attr_set = false;
     if (!attr_set) {
@@ -351,8 +362,8 @@ static int launch_c(const LinAttnFused& w, const float* x, float* ws, float* y, 
     hipLaunchKernelGGL(linattn_ctx_fused_kernel<C>, dim3(nblk, B), dim3(256), lds1, s, x, w, ws, n, nblk);
     DM_CHECK_HIP(hipGetLastError());
     if (timed && prof::end(s)) return 1;
-    float* ctxn = ws + (size_t)B * nblk * LA_HEADS * LA_CTX;
-    hipLaunchKernelGGL(linattn_ctx_reduce_kernel, dim3(LA_HEADS, B), dim3(256), 0, s, ws, ctxn, nblk);
+    float* ctxn = ws + (size_t)B * nblk * LA_HEADS * LA_CTX;  // M = W_out ctx^T, lane-packed
+    hipLaunchKernelGGL(linattn_ctx_reduce_kernel<C>, dim3(LA_HEADS, B), dim3(256), 0, s, ws, w.wo_raw, ctxn, nblk);
     DM_CHECK_HIP(hipGetLastError());
     if (timed && prof::begin("linattn_out_fused_kernel", 2.0 * tokens * (2.0 * LA_HID * C + LA_HID * LA_DH),
                              8.0 * tokens * C, s))
