@@ -89,11 +89,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    # DM_BENCH_REHEARSE=1: every rank on GPU 0 with the gloo backend -- exercises the N > 1 code path on a one-GPU box
+    rehearse = os.environ.get("DM_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import diffusion_models_amd as dm
     from diffusion_models_amd import _lib

@@ -32,6 +32,11 @@ def gather_shards(local: torch.Tensor, batch_size: int, group=None) -> torch.Ten
     world = dist.get_world_size(group)
     sizes = shard_sizes(batch_size, world)
     mx = max(sizes)
+    if min(sizes) == mx and local.is_cuda and dist.get_backend(group) == "nccl":
+        # equal shards: one collective straight into the result tensor
+        out = local.new_empty((batch_size,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
     pad = local
     if local.shape[0] < mx:  # ragged tail: pad to the common size for the collective
         pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
