@@ -8,6 +8,8 @@
 // qkv tensors are NHWC, i.e. one row of 3*heads*32 floats per token: [q(h,d) | k(h,d) | v(h,d)].
 #include "dm_common.h"
 
+#include <algorithm>
+
 #include <cstdlib>
 
 namespace dm {
@@ -308,7 +310,8 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const float* __rest
     __syncthreads();
     float* pw = Ps + wave * ntok;
     float* qw = Qs + wave * DH;
-    for (int i = wave; i < nq; i += 4) {
+    // blockIdx.z splits the queries when (heads x batch) alone leaves CUs idle (small batches, 64-token stages)
+    for (int i = blockIdx.z * 4 + wave; i < nq; i += 4 * gridDim.z) {
         if (lane < DH) qw[lane] = q[((size_t)b * nq + i) * ldq + h * DH + lane] * scale;
         __builtin_amdgcn_wave_barrier();
         // scores for keys j = lane, lane+64, ...
@@ -352,8 +355,9 @@ int launch_attention_core(const float* q, int ldq, const float* k, const float* 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(attention_core_kernel, dim3(heads, B), dim3(256), lds, s, q, ldq, k, v, ldk, mem_k, mem_v,
-                       n_mem, out, ldo, nq, nk, scale);
+    const int qblocks = std::max(1, std::min((nq + 3) / 4, (512 + heads * B - 1) / (heads * B)));
+    hipLaunchKernelGGL(attention_core_kernel, dim3(heads, B, qblocks), dim3(256), lds, s, q, ldq, k, v, ldk, mem_k,
+                       mem_v, n_mem, out, ldo, nq, nk, scale);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }

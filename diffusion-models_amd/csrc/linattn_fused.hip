@@ -116,10 +116,10 @@ __device__ __forceinline__ void la_stage_rows(const float* __restrict__ xb, int 
     }
 }
 
-template <int C>
+template <int C, int TOK>
 __global__ __launch_bounds__(256) void linattn_ctx_fused_kernel(const float* __restrict__ x, const LinAttnFused w,
                                                                 float* __restrict__ ws, int n, int nblk) {
-    constexpr int G = C / 8, XS = C + 4, TOK = la_tok1(C);
+    constexpr int G = C / 8, XS = C + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;
     float* rn = smem + TOK * XS;
@@ -340,16 +340,29 @@ __global__ __launch_bounds__(256) void linattn_out_fused_kernel(const float* __r
     }
 }
 
+template <int C, int TOK1>
+static int launch_ctx(const LinAttnFused& w, const float* x, float* ws, int B, int n, int nblk, hipStream_t s) {
+    const size_t lds1 = (size_t)(TOK1 * (C + 4) + TOK1) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_ctx_fused_kernel<C, TOK1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((linattn_ctx_fused_kernel<C, TOK1>), dim3(nblk, B), dim3(256), lds1, s, x, w, ws, n, nblk);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int C>
 static int launch_c(const LinAttnFused& w, const float* x, float* ws, float* y, int B, int n, bool add_x, hipStream_t s) {
-    constexpr int TOK1 = la_tok1(C);
-    const int nblk = (n + TOK1 - 1) / TOK1;
-    const size_t lds1 = (size_t)(TOK1 * (C + 4) + TOK1) * 4;
+    // 256-token blocks halve the partial-context traffic, but only when they still fill the chip
+    const bool big = la_tok1(C) == 256 && (size_t)B * ((n + 255) / 256) >= 512;
+    const int tok1 = big ? 256 : LA_TOK1;
+    const int nblk = (n + tok1 - 1) / tok1;
     const size_t lds2 = (size_t)(LA_TOK2 * (C + 4) + LA_TOK2 + LA_HEADS * 32 * (C + 4)) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_ctx_fused_kernel<C>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_out_fused_kernel<C>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -359,8 +372,9 @@ static int launch_c(const LinAttnFused& w, const float* x, float* ws, float* y, 
     if (timed && prof::begin("linattn_ctx_fused_kernel", 2.0 * tokens * (2.0 * LA_HID * C + LA_HID * LA_DH),
                              4.0 * tokens * C, s))
         return 1;
-    hipLaunchKernelGGL(linattn_ctx_fused_kernel<C>, dim3(nblk, B), dim3(256), lds1, s, x, w, ws, n, nblk);
-    DM_CHECK_HIP(hipGetLastError());
+    if (big ? launch_ctx<C, (C <= 64 ? 256 : LA_TOK1)>(w, x, ws, B, n, nblk, s)
+            : launch_ctx<C, LA_TOK1>(w, x, ws, B, n, nblk, s))
+        return 1;
     if (timed && prof::end(s)) return 1;
     float* ctxn = ws + (size_t)B * nblk * LA_HEADS * LA_CTX;  // M = W_out ctx^T, lane-packed
     hipLaunchKernelGGL(linattn_ctx_reduce_kernel<C>, dim3(LA_HEADS, B), dim3(256), 0, s, ws, w.wo_raw, ctxn, nblk);
