@@ -210,3 +210,61 @@ def test_image_conditional(golden_imgcond, use_graph):
     assert rel_l2(y, b["y"]) < LOOP_TOL
     with pytest.raises(RuntimeError):
         d.sample(batch_size=2)  # no folder and no cond=
+
+
+def test_edge_shapes_against_oracle():
+    """Cases the golden files do not hold, checked against the (golden-pinned) oracle: a non-square image, a single
+    image, a three-stage network wide enough for the Winograd / fused-attention kernels, cosine schedule, DDIM with
+    all iterates returned."""
+    from oracle import unet_oracle as uo
+
+    cfg = UnetConfig(dim=64, dim_mults=(1, 2, 2), channels=3)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=9)
+    u = dm.Unet(dim=64, dim_mults=(1, 2, 2), channels=3, device=DEV)
+    u.load_state_dict(sd)
+    g = torch.Generator().manual_seed(5)
+    for shape in ((1, 3, 32, 16), (3, 3, 8, 24)):
+        x = torch.randn(shape, generator=g)
+        t = torch.randint(0, 1000, (shape[0],), generator=g)
+        with torch.inference_mode():
+            want = uo.unet_forward(sd, cfg, x, t)
+        err = rel_l2(u(x, t).cpu(), want)
+        print("edge fwd", shape, err)
+        assert err < FWD_TOL
+    d = dm.DenoisingDiffusion(u, image_size=(16, 8), timesteps=200, beta_schedule="cosine", sampling_timesteps=9,
+                              ddim_sampling_eta=0.3)
+    got = d.ddim_sample((1, 3, 16, 8), return_all_timesteps=True, noise=so.NoiseStream(77)).cpu()
+    with torch.inference_mode():
+        want = so.ddim_sample(lambda x, t: uo.unet_forward(sd, cfg, x, t), dm.make_schedule(200, "cosine"), (1, 3, 16, 8),
+                              so.NoiseStream(77), 9, eta=0.3, return_all_timesteps=True)
+    assert got.shape == want.shape == (1, 10, 3, 16, 8)
+    err = rel_l2(got, want)
+    print("edge ddim cosine all-steps", err)
+    assert err < LOOP_TOL
+
+
+def test_text_conditional_loop():
+    """TextConditionalDenoisingDiffusion.sample / p_sample_loop with explicit embeddings (the pickle lookup of random
+    captions, denoising_diffusion_text_conditional.py:320-363, is host-side harness): text_emb rides through every step."""
+    from oracle import unet_oracle as uo
+
+    for cross in (True, False):
+        cfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3, text_condition=True, use_cross_attn=cross)
+        sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=11)
+        u = dm.Unet(dim=32, dim_mults=(1, 2), channels=3, text_condition=True, use_cross_attn=cross, device=DEV)
+        u.load_state_dict(sd)
+        emb = torch.randn(2, 512, generator=torch.Generator().manual_seed(3))
+        d = dm.TextConditionalDenoisingDiffusion(model=u, image_size=16, timesteps=40, sampling_timesteps=6)
+        got = d.sample(batch_size=2, text_emb=emb, noise=so.NoiseStream(21)).cpu()
+        model = lambda x, t: uo.unet_forward(sd, cfg, x, t, text_emb=emb)  # noqa: E731
+        with torch.inference_mode():
+            want = so.ddim_sample(model, dm.make_schedule(40, "linear"), (2, 3, 16, 16), so.NoiseStream(21), 6)
+        err = rel_l2(got, want)
+        print("text ddim", cross, err)
+        assert err < LOOP_TOL
+        got = d.p_sample_loop((2, 3, 16, 16), text_emb=emb, noise=so.NoiseStream(22)).cpu()
+        with torch.inference_mode():
+            want = so.p_sample_loop(model, dm.make_schedule(40, "linear"), (2, 3, 16, 16), so.NoiseStream(22))
+        err = rel_l2(got, want)
+        print("text ddpm", cross, err)
+        assert err < LOOP_TOL
