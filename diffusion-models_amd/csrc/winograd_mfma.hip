@@ -285,7 +285,6 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
 
     DM_STAMP_ADD(4)
     // ---- prologue: chunks cb and cb + 1 -> LDS (both loads in flight together), operands of chunk cb -> registers
-    __builtin_amdgcn_s_setprio(1);
     {
         const bool two = cb + 1 < ce;
         f32x4 h2[HR];
@@ -344,7 +343,6 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
         }
         auto rdn = [&](int r, int ab, int b) { return *reinterpret_cast<const f32x4*>(rdp[BN][r][ab] + b * WCK); };
         f32x4 T[R][4];
-        __builtin_amdgcn_s_setprio(0);
         if constexpr (R == 2) {
             f32x4 d[8];
 #pragma unroll
@@ -415,7 +413,6 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
             A[3][0] = sub4(T[0][1], T[0][3]);
         }
         load_u(unext, 3);
-        __builtin_amdgcn_s_setprio(1);
         __syncthreads();
     };
     {
