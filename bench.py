@@ -213,6 +213,9 @@ def main():
             "traffic_unit": "HBM bytes per launch (PMC, offline pass)",
             "algorithmic_bytes_per_launch": top["algorithmic_bytes_per_launch"],
             "avg_launch_ms": top["avg_ms"],
+            "timing": "HIP events on the launch stream around every launch of an eager run behind a parked GPU, minus the "
+                      "calibrated interval of an empty-kernel bracket (dispatch + event packets, ~9 us): kernel "
+                      "execution time, comparable with rocprofv3 --kernel-trace",
             "note": "achieved/frac: ALGORITHMIC FLOPs of the reference's direct 3x3 convolution "
                     "(2*9*Cin*Cout*pixels per launch) over the HIP-event launch time, against the f32-input MFMA peak "
                     "(== f32 vector peak); the kernel is Winograd F(2x2,3x3) and issues 16/36 of those multiply-adds, "

@@ -156,6 +156,7 @@ int launch_sinusoid(const int64_t* t, const int64_t* step_times, const int* step
 int launch_group_norm(const float* x, const float* w, const float* b, float* y, float* stats_ws, int B, int HW,
                       int C, int groups, float eps, int swish, hipStream_t s);
 int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s);
+int launch_spin(double milliseconds, hipStream_t s);
 int launch_copy_channels(const float* src, float* dst, int B, int Cs, int Cd, int c_off, int HW, hipStream_t s);
 // y_nchw[b][o][sp] = bias[o] + sum_c x[pixel][c] * w[o][c]  for Cout <= 4 (NHWC in, NCHW out)
 int launch_pointwise_small(const float* x, const float* w_oc, const float* bias, float* y_nchw, int64_t pixels, int C,

@@ -342,6 +342,18 @@ int launch_copy_channels(const float* src, float* dst, int B, int Cs, int Cd, in
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
+// Holds the stream for `ticks` of the 100 MHz wall clock.  Used only by the profiling leg: with the GPU parked the
+// host can enqueue a whole run of (event, kernel, event) triples, which then execute back to back, so the event
+// intervals measure the kernels and not the host's launch rate.
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+int launch_spin(double milliseconds, hipStream_t s) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, s, (long long)(milliseconds * 1.0e5));
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(add_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, y, n);
     DM_CHECK_HIP(hipGetLastError());
