@@ -178,9 +178,11 @@ int dm_op_sampler_update(int kind, const float* x, const float* eps, const float
                          float* out, int64_t n, void* stream);
 
 /* ---- measurement (bench.py's roofline leg; not part of the reference surface) -------------
- * While enabled, every convolution launch is bracketed by two HIP events recorded on the stream
- * the kernel is launched on.  Do not combine with use_graph.  dm_profile_read synchronises the
- * device, aggregates the recorded launches per kernel instance, and clears the records.
+ * While enabled, every convolution / fused-attention launch is bracketed by two HIP events recorded on
+ * the stream the kernel is launched on.  Do not combine with use_graph.  dm_profile_enable(1) first
+ * measures the interval of an EMPTY-kernel bracket (dispatch + event packets); dm_profile_read
+ * synchronises the device, subtracts that interval from every bracket (total_ms is kernel execution
+ * time), aggregates the recorded launches per kernel instance, and clears the records.
  * total_flops / total_bytes are ALGORITHMIC (2*k*k*Cin*Cout*pixels; input + output + weights
  * each moved once), see DESIGN.md. */
 typedef struct dm_profile_row {
