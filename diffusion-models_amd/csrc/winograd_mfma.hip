@@ -189,7 +189,9 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
             const int hy = (int)(((unsigned)rem * (unsigned)g.magic_row) >> 24);  // rem / IW
             const int hx = rem - hy * g.IW;
             const int b = b0 + nb, iy = iy0 + hy, ix = ix0 + hx;
-            const int off = (nb * g.IH + hy) * RS + hx * WCK + 4 * (tid & 1);
+            // the two channel quads of a pixel swap places in every other group of 8 columns: the 16 lanes of a
+            // ds_read_b128 pass (8 tiles = every second pixel, x 2 tile rows) then hit 16 different 4-bank groups
+            const int off = (nb * g.IH + hy) * RS + hx * WCK + 4 * ((tid & 1) ^ ((hx >> 3) & 1));
             if (b < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) {
                 hpix[i] = (b * p.Hin + iy) * p.Win + ix;
                 hoff[i] = off;
@@ -239,31 +241,38 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int t = 32 * r + l31;
-        const int tx = t & (g.TW - 1);
         const int ty = (t >> g.lTW) & (g.TH - 1);
         const int nb = t >> (g.lTW + g.lTH);
-        rbase[r] = (nb * g.IH + 2 * ty) * RS + 2 * tx * WCK + 4 * lh;
+        rbase[r] = (nb * g.IH + 2 * ty) * RS;
     }
     // B^T row i = d[ra] + sgn * d[rb]:  i=0: d0 - d2;  i=1: d1 + d2;  i=2: d2 - d1;  i=3: d1 - d3
     const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
     const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sgn = wave == 1 ? 1.0f : -1.0f;
     const int offa = ra * RS, offb = rb * RS;
+    int colq[4];  // window column 2*tx + b of this lane's tiles: pixel slot + (swizzled) quad of this lane half
+    {
+        const int tx = l31 & (g.TW - 1);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) colq[b] = (2 * tx + b) * WCK + 4 * (lh ^ (((2 * tx + b) >> 3) & 1));
+    }
     auto rd = [&](const float* raw, int r, int ab, int b) {  // patch row ra (ab = 0) or rb (1), column b, of tile r
-        return *reinterpret_cast<const f32x4*>(raw + rbase[r] + (ab ? offb : offa) + b * WCK);
+        return *reinterpret_cast<const f32x4*>(raw + rbase[r] + (ab ? offb : offa) + colq[b]);
     };
     // the same addresses precomputed per LDS buffer: in the main loop (which is unrolled over the two buffers) every
     // LDS access is then a register base + an immediate offset
-    const float* rdp[2][R][2];  // [buffer][tile r][row a / row b]
-    float* stp[2][HR];          // [buffer][window item]
+    const float* rdp[2][R][2][4];  // [buffer][tile r][row a / row b][column]
+    float* stp[2][HR];             // [buffer][window item]
 #pragma unroll
     for (int bf = 0; bf < 2; ++bf) {
         float* base = bf ? raw1 : raw0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            rdp[bf][r][0] = base + rbase[r] + offa;
-            rdp[bf][r][1] = base + rbase[r] + offb;
-        }
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                rdp[bf][r][0][b] = base + rbase[r] + offa + colq[b];
+                rdp[bf][r][1][b] = base + rbase[r] + offb + colq[b];
+            }
 #pragma unroll
         for (int i = 0; i < HR; ++i) stp[bf][i] = base + hoff[i];
     }
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
             window_offsets(p.C1);
             asm volatile("" ::: "memory");  // keep this a branch: if-converted it costs a select per offset and chunk
         }
-        auto rdn = [&](int r, int ab, int b) { return *reinterpret_cast<const f32x4*>(rdp[BN][r][ab] + b * WCK); };
+        auto rdn = [&](int r, int ab, int b) { return *reinterpret_cast<const f32x4*>(rdp[BN][r][ab][b]); };
         f32x4 T[R][4];
         if constexpr (R == 2) {
             f32x4 d[8];
