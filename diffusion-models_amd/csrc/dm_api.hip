@@ -345,8 +345,22 @@ static int build_attn(dm_unet* u, AttnLayer& A, const std::string& p, int dim, b
                     u->own.upload(wv.data(), wv.size(), &dv) || u->own.upload(wor.data.data(), wor.data.size(), &dwo) ||
                     u->own.upload(kb.data(), kb.size(), &dkb) || u->own.upload(ogs.data(), ogs.size(), &dog))
                     return 1;
-                A.fused = LinAttnFused{dim, dq, dk, dv, dwo, A.out.bias, dog, dkb, A.mem_kv};
+                A.fused = LinAttnFused{dim, dq, dk, dv, dwo, A.out.bias, dog, dkb, A.mem_kv, nullptr, nullptr, nullptr, 0};
                 A.has_fused = true;
+                static const bool bf16x6 = std::getenv("DM_LINATTN_BF16X6") != nullptr;
+                if (bf16x6 && dim == 64) {  // experimental: fp32 products on the bf16 matrix cores
+                    float* d3[3];
+                    for (int which = 0; which < 3; ++which) {
+                        std::vector<float> w3;
+                        linattn_bf16x6_pack_proj(P(u, p + ".to_qkv.weight").data.data(), P(u, p + ".norm.g").data.data(),
+                                                 dim, which, w3);
+                        if (u->own.upload(w3.data(), w3.size(), &d3[which])) return 1;
+                    }
+                    A.fused.wq3 = d3[0];
+                    A.fused.wk3 = d3[1];
+                    A.fused.wv3 = d3[2];
+                    A.fused.bf16x6 = 1;
+                }
             }
         }
     }

@@ -195,12 +195,18 @@ struct LinAttnFused {
     const float* og;            // to_out RMSNorm gain * sqrt(C) [C]
     const float* kbound;        // softmax shift per (head, d) [128]
     const float* mem_kv;        // (2, heads, 32, 4)
+    // experimental, off by default (DM_LINATTN_BF16X6=1, C == 64): projection weights as bf16 triples (linattn_bf16x6.hip)
+    const void *wq3, *wk3, *wv3;
+    int bf16x6;
 };
 bool linattn_fused_eligible(int C, int heads, int dh);
 bool linattn_fused_pack(const float* w_qkv, const float* norm_g, const float* w_out, const float* mem_kv, int C,
                         std::vector<float>& wq, std::vector<float>& wk, std::vector<float>& wv, std::vector<float>& wo,
                         std::vector<float>& kbound);
 size_t linattn_fused_ws_floats(int B, int n);
+void linattn_bf16x6_pack_proj(const float* w_qkv, const float* norm_g, int C, int which, std::vector<float>& dst);
+int launch_linattn_bf16x6(const LinAttnFused& w, const float* x, float* ws, float* y, int B, int n, bool add_x,
+                          hipStream_t s);
 int launch_linattn_fused(const LinAttnFused& w, const float* x, float* ws, float* y, int B, int n, bool add_x,
                          hipStream_t s);
 

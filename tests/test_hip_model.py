@@ -268,3 +268,19 @@ def test_text_conditional_loop():
         err = rel_l2(got, want)
         print("text ddpm", cross, err)
         assert err < LOOP_TOL
+
+
+def test_bf16x6_linear_attention_in_child_process():
+    """The experimental LinearAttention with fp32 products on the bf16 matrix cores (linattn_bf16x6.hip; off by default,
+    the switch is read once per process): the same operator and full-model parity tests, same tolerances, in a child
+    process with DM_LINATTN_BF16X6=1."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, DM_LINATTN_BF16X6="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "tests/test_hip_ops.py::test_linear_attention",
+                        "tests/test_hip_model.py::test_unet_full_forward", "tests/test_hip_model.py::test_full_samplers"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
