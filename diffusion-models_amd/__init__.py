@@ -8,6 +8,7 @@ from .spec import (  # noqa: F401
     UnetConfig,
     ddim_time_pairs,
     decoder_param_spec,
+    encoder_param_spec,
     make_schedule,
     unet_param_spec,
 )
@@ -16,10 +17,11 @@ from .unet import Unet  # noqa: F401
 from .diffusion import (  # noqa: F401
     DenoisingDiffusion,
     ImageConditionalDenoisingDiffusion,
+    ImageConditionalLatentDiffusion,
     LatentDiffusion,
     TextConditionalDenoisingDiffusion,
 )
-from .vae import VQDecoder  # noqa: F401
+from .vae import VQDecoder, VQEncoder, VQModel  # noqa: F401
 from .dist import gather_shards, sample_sharded, shard_bounds  # noqa: F401
 from .checkpoint import load_trainer_checkpoint, load_vae_checkpoint  # noqa: F401
 
@@ -28,8 +30,11 @@ __all__ = [
     "DenoisingDiffusion",
     "TextConditionalDenoisingDiffusion",
     "ImageConditionalDenoisingDiffusion",
+    "ImageConditionalLatentDiffusion",
     "LatentDiffusion",
     "VQDecoder",
+    "VQEncoder",
+    "VQModel",
     "sample_sharded",
     "gather_shards",
     "shard_bounds",

@@ -23,6 +23,8 @@ EXPORTS = (
     "dm_unet_forward", "dm_sample", "dm_sample_cond", "dm_randn",
     "dm_decoder_create", "dm_decoder_destroy", "dm_decoder_set_param", "dm_decoder_missing_params",
     "dm_decoder_finalize", "dm_decoder_forward",
+    "dm_encoder_create", "dm_encoder_destroy", "dm_encoder_set_param", "dm_encoder_missing_params",
+    "dm_encoder_finalize", "dm_encoder_forward",
     "dm_op_conv2d", "dm_op_downsample", "dm_op_rmsnorm", "dm_op_block", "dm_op_linear_attention",
     "dm_op_attention", "dm_op_sampler_update",
     "dm_profile_enable", "dm_profile_read",
@@ -44,6 +46,15 @@ class DecoderCfg(C.Structure):
         ("ch", C.c_int32), ("out_ch", C.c_int32), ("n_levels", C.c_int32), ("ch_mult", C.c_int32 * DM_MAX_STAGES),
         ("num_res_blocks", C.c_int32), ("n_attn_res", C.c_int32), ("attn_resolutions", C.c_int32 * DM_MAX_STAGES),
         ("resolution", C.c_int32), ("z_channels", C.c_int32), ("embed_dim", C.c_int32),
+    ]
+
+
+class EncoderCfg(C.Structure):
+    _fields_ = [
+        ("ch", C.c_int32), ("in_channels", C.c_int32), ("n_levels", C.c_int32), ("ch_mult", C.c_int32 * DM_MAX_STAGES),
+        ("num_res_blocks", C.c_int32), ("n_attn_res", C.c_int32), ("attn_resolutions", C.c_int32 * DM_MAX_STAGES),
+        ("resolution", C.c_int32), ("z_channels", C.c_int32), ("embed_dim", C.c_int32), ("n_embed", C.c_int32),
+        ("double_z", C.c_int32),
     ]
 
 
@@ -79,6 +90,13 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_decoder_missing_params.argtypes = [vp]
     lib.dm_decoder_finalize.argtypes = [vp]
     lib.dm_decoder_forward.argtypes = [vp, fp, fp, i32, i32, i32, vp]
+    lib.dm_encoder_create.argtypes = [C.POINTER(EncoderCfg), i32, C.POINTER(vp)]
+    lib.dm_encoder_destroy.argtypes = [vp]
+    lib.dm_encoder_destroy.restype = None
+    lib.dm_encoder_set_param.argtypes = [vp, C.c_char_p, fp, C.POINTER(i64), i32]
+    lib.dm_encoder_missing_params.argtypes = [vp]
+    lib.dm_encoder_finalize.argtypes = [vp]
+    lib.dm_encoder_forward.argtypes = [vp, fp, fp, fp, vp, i32, i32, i32, vp]
     lib.dm_op_conv2d.argtypes = [fp, i32, fp, i32, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.dm_op_downsample.argtypes = [fp, i32, fp, fp, fp, i32, i32, i32, i32, vp]
     lib.dm_op_rmsnorm.argtypes = [fp, fp, fp, i32, i32, i32, i32, vp]

@@ -108,6 +108,7 @@ struct Arena {
 
 struct ConvLayer {
     int C0 = 0, C1 = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0;
+    int pad_hi = 0;     // extra zero rows / columns at the bottom / right only (VAE Encoder Downsample, model.py:89-93)
     bool up = false;    // nearest x2 in front of the conv (Upsample, DD/denoising_diffusion.py:48-52)
     bool fold = false;  // ... executed as four 2x2 parity convs on the source grid (ConvParams::fold)
     int fold_w_stride = 0;
@@ -235,8 +236,9 @@ static std::string idx(const std::string& a, int i) { return a + "." + std::to_s
 
 // ---- weight upload ----------------------------------------------------------------------
 static int make_conv(DeviceOwner& own, ConvLayer& L, const float* oihw, const float* bias, int Cout, int C0, int C1, int KH,
-                     int KW, int stride, int pad, bool up) {
+                     int KW, int stride, int pad, bool up, int pad_hi = 0) {
     L.C0 = C0; L.C1 = C1; L.Cout = Cout; L.KH = KH; L.KW = KW; L.stride = stride; L.pad = pad; L.up = up;
+    L.pad_hi = pad_hi;
     static const bool no_fold = std::getenv("DM_NO_UPFOLD") != nullptr;
     L.fold = up && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !no_fold;
     std::vector<float> packed;
@@ -437,8 +439,9 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
         p.fold = 0; p.fold_w_stride = 0; p.up = L.up ? 1 : 0;
         p.KH = L.KH; p.KW = L.KW;
         p.Hin = Hin; p.Win = Win;
-        p.Ho = (Hin + 2 * L.pad - L.KH) / L.stride + 1;
-        p.Wo = (Win + 2 * L.pad - L.KW) / L.stride + 1;
+        // the kernel zero-fills every window pixel outside the image, so bottom / right padding is only an output size
+        p.Ho = (Hin + 2 * L.pad + L.pad_hi - L.KH) / L.stride + 1;
+        p.Wo = (Win + 2 * L.pad + L.pad_hi - L.KW) / L.stride + 1;
         out_h = p.Ho; out_w = p.Wo;
         p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, L.KH, L.KW, L.stride, L.C0, L.C1, want_norm && !out_nchw,
                           !out_nchw);

@@ -375,3 +375,60 @@ class LatentDiffusion(DenoisingDiffusion):
         sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
         latents = sample_fn((batch_size, channels, h, w), return_all_timesteps=return_all_timesteps, **kw)
         return self.decode(latents)
+
+
+class ImageConditionalLatentDiffusion(ImageConditionalDenoisingDiffusion):
+    """``ImageConditionalLatentDiffusion`` (latent-diffusion/ldm/models/latent_diffusion_image_conditional.py:16-166):
+    the image-conditional loop on VAE latents.  The condition image is encoded by the (condition) VQ model and rides
+    through every step concatenated behind the latent; the result is decoded at the end.  The reference re-encodes the
+    (loop-invariant) condition inside every one of its T iterations (:127); here it is encoded once -- the same value.
+    normalize / unnormalize are the identity (:43-44)."""
+
+    def __init__(self, model, vae, latent_shape, init_image_size, cond_vae=None, **kwargs):
+        kwargs.setdefault("auto_normalize", False)
+        super().__init__(model, image_size=tuple(latent_shape[1:]), **kwargs)
+        self.vae = vae
+        self.cond_vae = cond_vae if cond_vae is not None else vae
+        self.init_image_size = init_image_size
+        self.latent_channels = latent_shape[0]
+
+    def encode(self, images, cond=False):
+        latents = (self.cond_vae if cond else self.vae).encode(images)
+        return latents[0] if isinstance(latents, tuple) else latents
+
+    def decode(self, latents, cond=False):
+        return (self.cond_vae if cond else self.vae).decode(latents)
+
+    def get_random_condition(self, batch, device):
+        """:82-111: like the pixel-space variant, at ``init_image_size``."""
+        size, self.image_size = self.image_size, (
+            self.init_image_size if isinstance(self.init_image_size, (tuple, list)) else (self.init_image_size,) * 2)
+        try:
+            return super().get_random_condition(batch, device)
+        finally:
+            self.image_size = size
+
+    @torch.inference_mode()
+    def p_sample_loop(self, shape, return_condition_image=False, return_all_timesteps=False, *, cond=None, **kw):
+        cond = self._cond(shape[0], cond)
+        ret = super().p_sample_loop(shape, False, return_all_timesteps, cond=self.encode(cond, cond=True), **kw)
+        return (cond, ret) if return_condition_image else ret
+
+    @torch.inference_mode()
+    def ddim_sample(self, shape, sampling_timesteps=None, cond=None, return_all_timesteps=False, **kw):
+        """``cond`` is the condition IMAGE (encoded here), unlike the parent's method which takes what the U-Net sees."""
+        cond = self._cond(shape[0], cond)
+        return super().ddim_sample(shape, sampling_timesteps, self.encode(cond, cond=True), return_all_timesteps, **kw)
+
+    @torch.inference_mode()
+    def sample(self, batch_size=16, return_condition_image=False, return_all_timesteps=False, *, cond=None, **kw):
+        (h, w), channels = self.image_size, self.channels
+        shape = (batch_size, channels, h, w)
+        cond = self._cond(batch_size, cond)
+        if not self.is_ddim_sampling:
+            lat = self.p_sample_loop(shape, False, return_all_timesteps, cond=cond, **kw)
+        else:
+            lat = self.ddim_sample(shape, None, cond, return_all_timesteps, **kw)
+        img = self.decode(lat)
+        return (cond, img) if return_condition_image else img
+

@@ -421,3 +421,68 @@ def decoder_param_spec(cfg: DecoderConfig, prefix: str = "") -> ParamSpec:
         (f"{p}decoder.conv_out.bias", (cfg.out_ch,)),
     ]
     return spec
+
+
+@dataclass(frozen=True)
+class EncoderConfig:
+    """``ddconfig`` keys the Encoder reads (latent-diffusion/ldm/modules/diffusionmodules/model.py:385-449) plus the
+    VQModel's codebook shape (latent-diffusion/ldm/models/autoencoder.py:31-49)."""
+
+    ch: int = 64
+    in_channels: int = 3
+    ch_mult: Tuple[int, ...] = (1, 2)
+    num_res_blocks: int = 2
+    attn_resolutions: Tuple[int, ...] = ()
+    resolution: int = 32
+    z_channels: int = 3
+    embed_dim: int = 3
+    n_embed: int = 8192
+    double_z: bool = False
+
+    @property
+    def num_resolutions(self) -> int:
+        return len(self.ch_mult)
+
+
+def encoder_param_spec(cfg: EncoderConfig, prefix: str = "") -> ParamSpec:
+    """Parameters of ``VQModel.encoder`` + ``quant_conv`` + ``quantize.embedding`` in ``state_dict()`` order of the
+    Encoder (down.{l}.block.*, down.{l}.attn.*, down.{l}.downsample, mid, norm_out, conv_out)."""
+    p = prefix
+    spec: ParamSpec = [
+        (f"{p}encoder.conv_in.weight", (cfg.ch, cfg.in_channels, 3, 3)),
+        (f"{p}encoder.conv_in.bias", (cfg.ch,)),
+    ]
+    curr_res = cfg.resolution
+    in_ch_mult = (1,) + tuple(cfg.ch_mult)
+    block_in = cfg.ch
+    for lvl in range(cfg.num_resolutions):
+        block_in = cfg.ch * in_ch_mult[lvl]
+        block_out = cfg.ch * cfg.ch_mult[lvl]
+        attn: ParamSpec = []
+        for b in range(cfg.num_res_blocks):
+            spec += _vae_resblock_spec(f"{p}encoder.down.{lvl}.block.{b}", block_in, block_out)
+            block_in = block_out
+            if curr_res in cfg.attn_resolutions:
+                attn += _vae_attn_spec(f"{p}encoder.down.{lvl}.attn.{b}", block_in)
+        spec += attn
+        if lvl != cfg.num_resolutions - 1:
+            spec += [
+                (f"{p}encoder.down.{lvl}.downsample.conv.weight", (block_in, block_in, 3, 3)),
+                (f"{p}encoder.down.{lvl}.downsample.conv.bias", (block_in,)),
+            ]
+            curr_res //= 2
+    spec += _vae_resblock_spec(f"{p}encoder.mid.block_1", block_in, block_in)
+    spec += _vae_attn_spec(f"{p}encoder.mid.attn_1", block_in)
+    spec += _vae_resblock_spec(f"{p}encoder.mid.block_2", block_in, block_in)
+    zc = 2 * cfg.z_channels if cfg.double_z else cfg.z_channels
+    spec += [
+        (f"{p}encoder.norm_out.weight", (block_in,)),
+        (f"{p}encoder.norm_out.bias", (block_in,)),
+        (f"{p}encoder.conv_out.weight", (zc, block_in, 3, 3)),
+        (f"{p}encoder.conv_out.bias", (zc,)),
+        (f"{p}quant_conv.weight", (cfg.embed_dim, zc, 1, 1)),
+        (f"{p}quant_conv.bias", (cfg.embed_dim,)),
+        (f"{p}quantize.embedding.weight", (cfg.n_embed, cfg.embed_dim)),
+    ]
+    return spec
+

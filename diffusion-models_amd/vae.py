@@ -9,7 +9,7 @@ from typing import Dict
 import torch
 
 from . import _lib
-from .spec import DecoderConfig, decoder_param_spec
+from .spec import DecoderConfig, EncoderConfig, decoder_param_spec, encoder_param_spec
 from .unet import _device_index
 
 
@@ -84,3 +84,125 @@ class VQDecoder:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self._lib.dm_decoder_forward(self._handle, _lib.ptr(z), _lib.ptr(out), B, h, w, stream))
         return out
+
+
+class VQEncoder:
+    """Mirror of ``VQModel.encode`` / ``encode_to_prequant`` (autoencoder.py:102-111): ``Encoder`` -> ``quant_conv`` ->
+    nearest-codebook quantisation, executed by ``dm_encoder_forward``.  ``load_state_dict`` takes the ``VQModel``
+    state dict and uses its ``encoder.*``, ``quant_conv.*`` and ``quantize.embedding.weight`` entries."""
+
+    def __init__(self, ddconfig: Dict, embed_dim: int, n_embed: int, device="cuda:0"):
+        self.cfg = EncoderConfig(
+            ch=ddconfig["ch"], in_channels=ddconfig.get("in_channels", 3), ch_mult=tuple(ddconfig["ch_mult"]),
+            num_res_blocks=ddconfig["num_res_blocks"], attn_resolutions=tuple(ddconfig.get("attn_resolutions", ())),
+            resolution=ddconfig["resolution"], z_channels=ddconfig["z_channels"], embed_dim=embed_dim, n_embed=n_embed,
+            double_z=bool(ddconfig.get("double_z", False)),
+        )
+        cfg = self.cfg
+        self.device = torch.device(device)
+        self._lib = _lib.load()
+        self._handle = C.c_void_p()
+        self._loaded = False
+        c = _lib.EncoderCfg()
+        c.ch, c.in_channels, c.n_levels = cfg.ch, cfg.in_channels, cfg.num_resolutions
+        for i, m in enumerate(cfg.ch_mult):
+            c.ch_mult[i] = m
+        c.num_res_blocks = cfg.num_res_blocks
+        c.n_attn_res = len(cfg.attn_resolutions)
+        for i, r in enumerate(cfg.attn_resolutions):
+            c.attn_resolutions[i] = r
+        c.resolution, c.z_channels, c.embed_dim, c.n_embed = cfg.resolution, cfg.z_channels, cfg.embed_dim, cfg.n_embed
+        c.double_z = int(cfg.double_z)
+        _lib.check(self._lib.dm_encoder_create(C.byref(c), _device_index(device), C.byref(self._handle)))
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            self._lib.dm_encoder_destroy(h)
+            h.value = None
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        return iter(())
+
+    def param_spec(self):
+        return encoder_param_spec(self.cfg)
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        spec = dict(self.param_spec())
+        missing = [k for k in spec if k not in state_dict]
+        if missing:
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]}")
+        for name, shape in spec.items():
+            t = state_dict[name].detach().to(device="cpu", dtype=torch.float32).contiguous()
+            if tuple(t.shape) != tuple(shape):
+                raise RuntimeError(f"size mismatch for {name}: {tuple(t.shape)} vs {tuple(shape)}")
+            shp = (C.c_int64 * t.dim())(*t.shape)
+            _lib.check(self._lib.dm_encoder_set_param(self._handle, name.encode(), t.data_ptr(), shp, t.dim()))
+        _lib.check(self._lib.dm_encoder_finalize(self._handle))
+        self._loaded = True
+        return self
+
+    def _run(self, x, want_quant: bool):
+        if not self._loaded:
+            raise RuntimeError("load_state_dict() must be called before encode()")
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        B, Cin, H, W = x.shape
+        if Cin != self.cfg.in_channels:
+            raise RuntimeError(f"expected {self.cfg.in_channels} image channels, got {Cin}")
+        f = 2 ** (self.cfg.num_resolutions - 1)
+        shape = (B, self.cfg.embed_dim, H // f, W // f)
+        pre = torch.empty(shape, device=self.device, dtype=torch.float32)
+        zq = torch.empty(shape, device=self.device, dtype=torch.float32) if want_quant else None
+        idx = torch.empty((B * shape[2] * shape[3],), device=self.device, dtype=torch.int32) if want_quant else None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.dm_encoder_forward(self._handle, _lib.ptr(x), _lib.ptr(zq), _lib.ptr(pre), _lib.ptr(idx), B, H,
+                                                W, stream))
+        return zq, pre, idx
+
+    @torch.inference_mode()
+    def encode(self, x):
+        """(quant, emb_loss, (perplexity, min_encodings, indices)) like ``VQModel.encode``; the loss terms are training
+        quantities and come back as ``None``."""
+        zq, _, idx = self._run(x, True)
+        return zq, None, (None, None, idx.to(torch.int64))
+
+    @torch.inference_mode()
+    def encode_to_prequant(self, x):
+        return self._run(x, False)[1]
+
+
+class VQModel:
+    """``VQModel`` of the reference restricted to inference: ``encode`` / ``encode_to_prequant`` / ``decode`` over one
+    ``state_dict`` (autoencoder.py:14-121)."""
+
+    def __init__(self, ddconfig: Dict, n_embed: int, embed_dim: int, device="cuda:0", **_ignored):
+        self.encoder = VQEncoder(ddconfig, embed_dim, n_embed, device=device)
+        self.decoder = VQDecoder(ddconfig, embed_dim, device=device)
+        self.device = torch.device(device)
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        return iter(())
+
+    def param_spec(self):
+        return self.encoder.param_spec() + self.decoder.param_spec()
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        self.encoder.load_state_dict(state_dict, strict)
+        self.decoder.load_state_dict(state_dict, strict)
+        return self
+
+    def encode(self, x):
+        return self.encoder.encode(x)
+
+    def encode_to_prequant(self, x):
+        return self.encoder.encode_to_prequant(x)
+
+    def decode(self, quant):
+        return self.decoder.decode(quant)
+

@@ -147,6 +147,36 @@ int dm_decoder_finalize(dm_decoder* d);
 /* z (B, embed_dim, h, w) -> out (B, out_ch, h*2^(n_levels-1), w*2^(n_levels-1)) */
 int dm_decoder_forward(dm_decoder* d, const float* z, float* out, int B, int h, int w, void* stream);
 
+/* ---- VAE encode (replaces VQModel.encode, LD/models/autoencoder.py:102-106 -> Encoder.forward
+ *      LD/modules/diffusionmodules/model.py:451-476 -> quant_conv -> VectorQuantizer2 of taming-transformers):
+ *      the condition image of ImageConditionalLatentDiffusion (LD/models/latent_diffusion_image_conditional.py:55-66)
+ * Parameter names: VQModel.state_dict() entries "encoder.*", "quant_conv.*", "quantize.embedding.weight". ---- */
+typedef struct dm_encoder_cfg {
+    int32_t ch;
+    int32_t in_channels;
+    int32_t n_levels;
+    int32_t ch_mult[DM_MAX_STAGES];
+    int32_t num_res_blocks;
+    int32_t n_attn_res;
+    int32_t attn_resolutions[DM_MAX_STAGES];
+    int32_t resolution;
+    int32_t z_channels;
+    int32_t embed_dim;
+    int32_t n_embed;
+    int32_t double_z;
+} dm_encoder_cfg;
+typedef struct dm_encoder dm_encoder;
+int dm_encoder_create(const dm_encoder_cfg* cfg, int device, dm_encoder** out);
+void dm_encoder_destroy(dm_encoder* e);
+int dm_encoder_set_param(dm_encoder* e, const char* name, const float* data_host, const int64_t* shape, int ndim);
+int dm_encoder_missing_params(dm_encoder* e);
+int dm_encoder_finalize(dm_encoder* e);
+/* x (B, in_channels, H, W) device fp32 -> zq (B, embed_dim, H/f, W/f) = z + (nearest code - z); optional outputs:
+ * pre_quant (same shape, the quant_conv output = VQModel.encode_to_prequant) and indices (B*h*w int32 code ids).
+ * zq may be NULL when only pre_quant is wanted. */
+int dm_encoder_forward(dm_encoder* e, const float* x, float* zq, float* pre_quant, int32_t* indices, int B, int H, int W,
+                       void* stream);
+
 /* ---- single operators (the kernels behind the calls above, exposed so that parity tests
  *      can check each one against the reference module it replaces) -------------------------
  * All tensors NCHW fp32 device pointers; weights in the reference layout, DEVICE pointers. */

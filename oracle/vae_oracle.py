@@ -78,3 +78,51 @@ def vq_decode(sd: SD, cfg, quant: torch.Tensor) -> torch.Tensor:
     """LD/models/autoencoder.py:113-116."""
     q = F.conv2d(quant, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
     return decoder_forward(sd, cfg, q)
+
+
+def encoder_forward(sd: SD, cfg, x: torch.Tensor, prefix: str = "encoder") -> torch.Tensor:
+    """LD/modules/diffusionmodules/model.py:451-476 (Encoder.forward, temb=None); Downsample :89-93 pads (0,1,0,1)
+    and convolves 3x3 with stride 2."""
+    p = prefix
+    h = F.conv2d(x, sd[p + ".conv_in.weight"], sd[p + ".conv_in.bias"], padding=1)
+    for lvl in range(cfg.num_resolutions):
+        for b in range(cfg.num_res_blocks):
+            h = vae_resnet_block(sd, f"{p}.down.{lvl}.block.{b}", h)
+            if f"{p}.down.{lvl}.attn.{b}.norm.weight" in sd:
+                h = vae_attn_block(sd, f"{p}.down.{lvl}.attn.{b}", h)
+        if lvl != cfg.num_resolutions - 1:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)
+            h = F.conv2d(h, sd[f"{p}.down.{lvl}.downsample.conv.weight"], sd[f"{p}.down.{lvl}.downsample.conv.bias"],
+                         stride=2, padding=0)
+    h = vae_resnet_block(sd, p + ".mid.block_1", h)
+    h = vae_attn_block(sd, p + ".mid.attn_1", h)
+    h = vae_resnet_block(sd, p + ".mid.block_2", h)
+    h = _swish(_gn(sd, p + ".norm_out", h))
+    return F.conv2d(h, sd[p + ".conv_out.weight"], sd[p + ".conv_out.bias"], padding=1)
+
+
+def vq_encode_to_prequant(sd: SD, cfg, x: torch.Tensor) -> torch.Tensor:
+    """LD/models/autoencoder.py:108-111."""
+    return F.conv2d(encoder_forward(sd, cfg, x), sd["quant_conv.weight"], sd["quant_conv.bias"])
+
+
+def vector_quantize(sd: SD, z: torch.Tensor):
+    """PARITY UNPINNED: the quantizer is ``taming.modules.vqvae.quantize.VectorQuantizer2`` (taming-transformers, a pip
+    dependency imported at LD/models/autoencoder.py:11 and absent from the reference tree and from this image), restated
+    from its published source (forward, legacy / remap off): distances ``|z|^2 + |e|^2 - 2 z.e`` over the flattened
+    (b h w, c) rows, ``argmin``, embedding lookup, straight-through ``z + (z_q - z).detach()``, back to (b c h w).
+    Returns (z_q, indices)."""
+    e = sd["quantize.embedding.weight"]
+    zf = z.permute(0, 2, 3, 1).contiguous()
+    flat = zf.view(-1, e.shape[1])
+    d = (flat ** 2).sum(dim=1, keepdim=True) + (e ** 2).sum(dim=1) - 2 * torch.einsum("bd,dn->bn", flat, e.t())
+    idx = torch.argmin(d, dim=1)
+    zq = e[idx].view(zf.shape)
+    zq = zf + (zq - zf)
+    return zq.permute(0, 3, 1, 2).contiguous(), idx
+
+
+def vq_encode(sd: SD, cfg, x: torch.Tensor):
+    """LD/models/autoencoder.py:102-106: (quant, indices)."""
+    return vector_quantize(sd, vq_encode_to_prequant(sd, cfg, x))
+

@@ -59,3 +59,10 @@ def golden_schedule():
 def golden_imgcond():
     """Image-conditional variant (tests/golden/make_golden_imgcond.py)."""
     return load_golden("imgcond.pt")
+
+
+@pytest.fixture(scope="session")
+def golden_encoder():
+    """VAE Encoder outputs of the reference (tests/golden/make_golden_encoder.py)."""
+    return load_golden("encoder.pt")
+

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import diffusion_models_amd as dm
-from diffusion_models_amd.spec import DecoderConfig, UnetConfig
+from diffusion_models_amd.spec import DecoderConfig, EncoderConfig, UnetConfig, encoder_param_spec
 from oracle import sampler_oracle as so
 
 from conftest import rel_l2
@@ -284,3 +284,69 @@ def test_bf16x6_linear_attention_in_child_process():
                         "tests/test_hip_model.py::test_unet_full_forward", "tests/test_hip_model.py::test_full_samplers"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_vae_encode(golden_encoder):
+    """dm_encoder_forward: Encoder + quant_conv against the reference's Encoder outputs pushed through the oracle's
+    quant_conv, and the nearest-code quantiser against the oracle's restatement (same winner unless two codes tie to
+    within fp32 rounding of the distances)."""
+    from oracle import vae_oracle as vo
+
+    cases = {
+        "encode_cifar": (EncoderConfig(), 6),
+        "encode_attn3": (EncoderConfig(ch=32, ch_mult=(1, 2, 4), num_res_blocks=1, attn_resolutions=(8,), resolution=32,
+                                       z_channels=4, embed_dim=4, n_embed=64), 7),
+    }
+    for name, (cfg, salt) in cases.items():
+        sd = dm.synth_state_dict(encoder_param_spec(cfg), salt=salt)
+        enc = dm.VQEncoder(dict(ch=cfg.ch, in_channels=3, ch_mult=cfg.ch_mult, num_res_blocks=cfg.num_res_blocks,
+                                attn_resolutions=cfg.attn_resolutions, resolution=cfg.resolution,
+                                z_channels=cfg.z_channels, double_z=False), cfg.embed_dim, cfg.n_embed, device=DEV)
+        enc.load_state_dict(sd)
+        b = golden_encoder[name]
+        with torch.inference_mode():
+            want_pre = torch.nn.functional.conv2d(b["h"], sd["quant_conv.weight"], sd["quant_conv.bias"])
+            want_zq, want_idx = vo.vector_quantize(sd, want_pre)
+        pre = enc.encode_to_prequant(b["x"]).cpu()
+        err = rel_l2(pre, want_pre)
+        print(name, "prequant", err)
+        assert err < FWD_TOL
+        zq, _, (_, _, idx) = enc.encode(b["x"])
+        same = (idx.cpu() == want_idx).float().mean().item()
+        print(name, "same code", same, "zq", rel_l2(zq.cpu(), want_zq))
+        assert same > 0.99
+        # every chosen code is a nearest one for the HIP pre-quant values
+        flat = pre.permute(0, 2, 3, 1).reshape(-1, cfg.embed_dim).double()
+        d = torch.cdist(flat, sd["quantize.embedding.weight"].double())
+        assert torch.allclose(d.gather(1, idx.cpu()[:, None]).squeeze(1), d.min(dim=1).values, rtol=1e-4, atol=1e-5)
+
+
+def test_image_conditional_latent_diffusion():
+    """ImageConditionalLatentDiffusion (latent_diffusion_image_conditional.py): encode the condition image with the VQ
+    model, run the image-conditional loop on latents, decode.  Checked against the oracle assembled from the same parts."""
+    from oracle import unet_oracle as uo
+    from oracle import vae_oracle as vo
+
+    ecfg = EncoderConfig(ch=32, ch_mult=(1, 2), num_res_blocks=1, resolution=32, z_channels=3, embed_dim=3, n_embed=256)
+    dcfg = DecoderConfig(ch=32, ch_mult=(1, 2), num_res_blocks=1, resolution=32, z_channels=3, embed_dim=3)
+    vsd = dm.synth_state_dict(encoder_param_spec(ecfg) + dm.decoder_param_spec(dcfg), salt=12)
+    vae = dm.VQModel(dict(ch=32, out_ch=3, in_channels=3, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(),
+                          resolution=32, z_channels=3, double_z=False), n_embed=256, embed_dim=3, device=DEV)
+    vae.load_state_dict(vsd)
+    ucfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3, cond_channels=3)
+    usd = dm.synth_state_dict(dm.unet_param_spec(ucfg), salt=13)
+    u = dm.Unet(dim=32, dim_mults=(1, 2), channels=3, cond_channels=3, device=DEV)
+    u.load_state_dict(usd)
+    ld = dm.ImageConditionalLatentDiffusion(u, vae, latent_shape=(3, 16, 16), init_image_size=32, timesteps=30)
+    cond = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(4))
+    c, img = ld.sample(batch_size=2, return_condition_image=True, cond=cond, noise=so.NoiseStream(31))
+    assert torch.equal(c.cpu(), cond) and img.shape == (2, 3, 32, 32)
+    with torch.inference_mode():
+        cl, _ = vo.vq_encode(vsd, ecfg, cond)
+        lat = so.p_sample_loop(lambda x, t: uo.unet_forward(usd, ucfg, x, t, cond=cl), dm.make_schedule(30, "linear"),
+                               (2, 3, 16, 16), so.NoiseStream(31), unnormalize=False)
+        want = vo.vq_decode(vsd, dcfg, lat)
+    err = rel_l2(img.cpu(), want)
+    print("imgcond latent", err)
+    assert err < LOOP_TOL
+

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import diffusion_models_amd as dm
-from diffusion_models_amd.spec import DecoderConfig, UnetConfig
+from diffusion_models_amd.spec import DecoderConfig, EncoderConfig, UnetConfig, encoder_param_spec
 from oracle import sampler_oracle as so
 from oracle import unet_oracle as uo
 from oracle import vae_oracle as vo
@@ -218,3 +218,29 @@ def test_image_conditional(golden_imgcond):
     assert rel_l2(so.p_sample_loop(model, sched, b["shape"], so.NoiseStream(b["seed"])), b["y"]) < 1e-4
     b = golden_imgcond["imgcond_ddim7"]
     assert rel_l2(so.ddim_sample(model, sched, b["shape"], so.NoiseStream(b["seed"]), b["S"]), b["y"]) < 1e-4
+
+
+ENC_CASES = {
+    "encode_cifar": (EncoderConfig(), 6),
+    "encode_attn3": (EncoderConfig(ch=32, ch_mult=(1, 2, 4), num_res_blocks=1, attn_resolutions=(8,), resolution=32,
+                                   z_channels=4, embed_dim=4, n_embed=64), 7),
+}
+
+
+def test_vae_encoder(golden_encoder):
+    """Encoder.forward against the reference's outputs; the quantiser (taming-transformers, absent) is checked for its
+    defining properties only (parity unpinned, see oracle/vae_oracle.py)."""
+    for name, (cfg, salt) in ENC_CASES.items():
+        sd = dm.synth_state_dict(encoder_param_spec(cfg), salt=salt)
+        b = golden_encoder[name]
+        h = vo.encoder_forward(sd, cfg, b["x"])
+        assert rel_l2(h, b["h"]) < TOL
+        pre = vo.vq_encode_to_prequant(sd, cfg, b["x"])
+        zq, idx = vo.vector_quantize(sd, pre)
+        e = sd["quantize.embedding.weight"]
+        assert zq.shape == pre.shape and idx.shape == (pre.numel() // cfg.embed_dim,)
+        flat = pre.permute(0, 2, 3, 1).reshape(-1, cfg.embed_dim)
+        d = torch.cdist(flat.double(), e.double())
+        assert torch.allclose(d.gather(1, idx[:, None]).squeeze(1), d.min(dim=1).values, rtol=1e-5, atol=1e-6)
+        assert rel_l2(zq.permute(0, 2, 3, 1).reshape(-1, cfg.embed_dim), e[idx]) < 1e-6
+
