@@ -37,9 +37,11 @@ def load_trainer_checkpoint(path: str, prefer_ema: bool = True) -> Dict[str, tor
 
 
 def vae_state_dict_from_checkpoint(data: Dict) -> Dict[str, torch.Tensor]:
-    """Lightning ``.ckpt`` (``{'state_dict': ...}``) or a bare state dict -> the entries ``VQDecoder`` needs."""
+    """Lightning ``.ckpt`` (``{'state_dict': ...}``) or a bare state dict -> the entries ``VQDecoder`` / ``VQEncoder`` /
+    ``VQModel`` need (the loss network and EMA shadows of the checkpoint are dropped)."""
     sd = data["state_dict"] if "state_dict" in data else data
-    return {k: v for k, v in sd.items() if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
+    keep = ("decoder.", "post_quant_conv.", "encoder.", "quant_conv.", "quantize.embedding.")
+    return {k: v for k, v in sd.items() if k.startswith(keep)}
 
 
 def load_vae_checkpoint(path: str) -> Dict[str, torch.Tensor]:
