@@ -1,30 +1,36 @@
 #!/usr/bin/env python3
-"""Headline benchmark: sampled images/sec of the 32x32 denoising U-Net on MI355X.
+"""Headline benchmark: sampled images/sec of the 32x32 denoising U-Net, DDPM-1000, on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1 via torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch: a complete ``sample()`` call
-(BASELINE.json configs[1]: 32x32 U-Net dim 64 mults (1,2,4,8), DDIM 50 steps, eta 0, batch 256
-per GPU, hipGraph-captured denoise step, device Philox noise, name-seeded random-init weights).
-With N>1 every rank samples its own 256 images (weak scaling) and ONE all-gather over RCCL
-assembles the (256*N) batch at the end of each step, inside the timed region.
+BASELINE.json's metric: "sampled images/sec (and denoise-steps/sec) at 32x32 DDPM-1000, 1/2/4/8 GPU".
+One "step" = one pass of the hot path over one batch = one complete ``sample()`` call: 32x32 U-Net (dim 64, mults
+(1,2,4,8)), ``p_sample_loop`` with T = 1000 reverse steps, 256 images per GPU, the denoise step replayed as a hipGraph
+captured once, device Philox noise, name-seeded random-init weights (no network for checkpoints).  Everything is resident
+in HBM when the timed region starts; the boundary takes device pointers, so there is no PCIe leg.
 
-Rank 0 prints ONE JSON line.  `value` is whole-job images/s with all inputs resident in HBM.
-Also reported: denoise image-steps/s, the DDPM-1000 equivalent (same per-step cost, 1000 steps),
-the roofline of the dominant kernel (HIP-event timed inside this script) and the CPU baseline
-(the oracle on this box's host cores, bounded sample).
+N > 1: ``python bench.py --gpus N`` starts N ranks itself (``python -m torch.distributed.run`` as a child process, before
+this process touches the GPU); under a launcher (WORLD_SIZE set) it is a rank.  Every rank samples its own 256 images of
+the global batch (weak scaling; Philox counters are global element indices, so the gathered batch equals the batch one
+GPU would produce) and ONE all-gather over RCCL assembles the (256*N) batch inside the timed region.
+``--scaling strong --global-batch G`` fixes the global batch instead (G/N per GPU).
+
+Rank 0 prints ONE JSON line.  Besides the contract's fields: ``roofline`` of the dominant kernel (timed live by HIP
+events on its launch stream), ``cpu_baseline`` (the oracle on this box's host cores on BASELINE config 1, bounded
+sample), per-kernel rows and the DDIM-50 rate of the same step (``--workload ddim50`` measures that one directly).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3  # MI355X f32 vector == f32-input MFMA peak (MI355X_MICROARCH.md)
 IMAGE, CHANNELS, T = 32, 3, 1000
@@ -33,61 +39,131 @@ IMAGE, CHANNELS, T = 32, 3, 1000
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU per sample() call")
-    ap.add_argument("--workload", default="ddim50", choices=["ddim50", "ddpm1000"])
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per sample() call (weak scaling)")
+    ap.add_argument("--workload", default="ddpm1000", choices=["ddpm1000", "ddim50"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--global-batch", type=int, default=256, help="global batch of --scaling strong")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=4, help="denoise steps of the CPU baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=20, help="DDPM steps of the CPU baseline sample (config 1)")
     return ap.parse_args()
 
 
-def cpu_baseline(sd, cfg, batch, n_steps, sampler_steps):
-    """The oracle (CPU restatement pinned to the reference) on the host cores: `n_steps` DDIM
-    iterations at the benchmark batch, extrapolated linearly to the full loop (steps are homogeneous)."""
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` typed as is: start N fresh ranks as a child process.  Nothing in this process has
+    touched the GPU (torch is not even imported yet), and the parent only waits and forwards the exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def csrc_sha() -> str:
+    """Hash of the kernel sources: a PMC traffic file only applies to the kernels it was collected on."""
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "diffusion-models_amd", "csrc", "*"))):
+        if path.endswith((".hip", ".h", ".inc")):
+            with open(path, "rb") as f:
+                h.update(os.path.basename(path).encode())
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the newest committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs, FETCH_SIZE doubled per the gfx950 correction; tools/pmc_traffic.py).  PMC cannot run inside this
+    process, so the figure is an offline pass of the same command on the same kernels: it is used only when the file's
+    source hash equals the hash of the sources this library was built from."""
+    import re
+
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json"))
+    if not files:
+        return None, "no profiles/r*_pmc_hbm_traffic.json"
+    # newest = highest (round, step) in the name: r2_step10 is later than r2_step9
+    newest = max(files, key=lambda p: tuple(int(v) for v in re.findall(r"\d+", os.path.basename(p))))
+    with open(newest) as f:
+        doc = json.load(f)
+    sha = doc.get("_csrc_sha")
+    if sha != csrc_sha():
+        return None, f"{os.path.basename(newest)} was collected on other kernel sources ({sha} != {csrc_sha()})"
+    rows = {k.replace(" ", ""): v for k, v in doc.items() if isinstance(v, dict)}
+    row = rows.get(kernel.replace(" ", ""))
+    if not row:
+        return None, f"{os.path.basename(newest)} has no row for {kernel}"
+    return row["fetch_bytes_per_launch_corrected"] + row["write_bytes_per_launch"], os.path.basename(newest)
+
+
+def cpu_baseline(n_steps):
+    """BASELINE config 1 exactly: Unet(dim 64, mults (1,2,4,8), channels 3), 32x32, linear beta,
+    T = 1000, p_sample_loop, B = 64, fp32 -- the oracle (CPU restatement pinned to the reference's outputs) on this
+    box's host cores.  The loop is per-step homogeneous: `n_steps` DDPM steps are timed after one warm-up step and
+    extrapolated linearly to 1000.  The thread count is swept over {8, 16, 32, 64} (2 steps each) and the best is used."""
+    import torch
+
     import diffusion_models_amd as dm
+    from diffusion_models_amd.spec import UnetConfig
     from oracle import sampler_oracle as so
     from oracle import unet_oracle as uo
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 64))
-    torch.set_num_threads(cores)
+    B = 64
+    cfg = UnetConfig(dim=64, dim_mults=(1, 2, 4, 8), channels=CHANNELS)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=0)
     sched = dm.make_schedule(T, "linear")
-    pairs = so.ddim_pairs(T, 50)
-    stream = so.NoiseStream(0)
-    shape = (batch, CHANNELS, IMAGE, IMAGE)
-    with torch.inference_mode():
-        x = stream(shape)
-        bt = torch.full((batch,), pairs[0][0], dtype=torch.long)
-        uo.unet_forward(sd, cfg, x[:8], bt[:8])  # warm the thread pool / allocator
-        t0 = time.perf_counter()
-        for t, tn in pairs[:n_steps]:
-            bt = torch.full((batch,), t, dtype=torch.long)
-            eps = uo.unet_forward(sd, cfg, x, bt)
-            x0 = so.predict_start_from_noise(sched, x, t, eps).clamp(-1.0, 1.0)
-            eps = so.predict_noise_from_start(sched, x, t, x0)
-            a, an = sched["alphas_cumprod"][t], sched["alphas_cumprod"][tn]
-            x = x0 * an.sqrt() + (1 - an).sqrt() * eps
-        dt = time.perf_counter() - t0
-    img_steps_per_s = batch * n_steps / dt
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    model = lambda x, t: uo.unet_forward(sd, cfg, x, t)  # noqa: E731
+    shape = (B, CHANNELS, IMAGE, IMAGE)
+
+    def run(steps, seed=0):
+        stream = so.NoiseStream(seed)
+        with torch.inference_mode():
+            x = stream(shape)
+            x, _ = so.p_sample(model, sched, x, T - 1, stream(shape))  # warm-up step (thread pool, allocator)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                x, _ = so.p_sample(model, sched, x, T - 2 - i, stream(shape))
+            return time.perf_counter() - t0
+
+    sweep = {}
+    for n in sorted({min(c, avail) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(n)
+        sweep[n] = run(2) / 2
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    dt = run(n_steps)
+    step_s = dt / n_steps
     return {
-        "value": img_steps_per_s / sampler_steps,
+        "value": B / (step_s * T),
         "unit": "images/s",
-        "cores": cores,
+        "cores": best,
         "kind": "port",
-        "sample": f"{n_steps} of {sampler_steps} denoise steps at batch {batch} ({dt:.1f} s), linear extrapolation; "
-                  f"{img_steps_per_s:.1f} image-steps/s; torch {torch.__version__} CPU ops, fp32",
+        "image_steps_per_s": B / step_s,
+        "sample": f"BASELINE config 1: B=64, 32x32, p_sample (DDPM), {n_steps} of 1000 steps timed ({dt:.1f} s) after 1 "
+                  f"warm-up step, linear extrapolation to 1000; threads swept {{"
+                  + ", ".join(f"{k}: {1e3 * v:.0f} ms/step" for k, v in sweep.items())
+                  + f"}} of {avail} available, best = {best}; torch {torch.__version__} CPU ops, fp32",
     }
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     # DM_BENCH_REHEARSE=1: every rank on GPU 0 with the gloo backend -- exercises the N > 1 code path on a one-GPU box
     rehearse = os.environ.get("DM_BENCH_REHEARSE") == "1"
@@ -113,12 +189,17 @@ def main():
     S = 50 if args.workload == "ddim50" else T
     diff = dm.DenoisingDiffusion(unet, image_size=IMAGE, timesteps=T,
                                  sampling_timesteps=S if S < T else None, use_graph=not args.no_graph)
-    B = args.batch
+    if args.scaling == "weak":
+        B_global = args.batch * world
+    else:
+        B_global = args.global_batch
+    lo, hi = dm.shard_bounds(B_global, world, rank)
+    B = hi - lo
 
     def step(i):
-        # key the Philox stream by (step, global shard) so no two ranks draw the same noise
-        local = diff.sample(batch_size=B, seed=1 + i * world + rank)
-        return dm.gather_shards(local, B * world) if world > 1 else local
+        # one seed per call for every rank; this rank draws the noise of ITS global sample indices [lo, hi)
+        local = diff.sample(batch_size=B, seed=1000 + i, sample_offset=lo)
+        return dm.gather_shards(local, B_global) if world > 1 else local
 
     def barrier():
         if world > 1:
@@ -135,16 +216,18 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    assert out.shape == (B * world, CHANNELS, IMAGE, IMAGE) and bool(torch.isfinite(out).all())
+    assert out.shape == (B_global, CHANNELS, IMAGE, IMAGE) and bool(torch.isfinite(out).all())
+    assert unet.graph_captures <= 1, "the step graph must be captured once, not per sample() call"
 
-    images = B * world * args.steps
+    images = B_global * args.steps
     value = images / elapsed
+    ms_denoise = 1e3 * elapsed / args.steps / S
     result = {
-        "metric": "sampled images/sec, 32x32 U-Net (dim 64, mults 1-2-4-8), DDIM-50" if S == 50
-                  else "sampled images/sec, 32x32 U-Net (dim 64, mults 1-2-4-8), DDPM-1000",
+        "metric": "sampled images/sec, 32x32 U-Net (dim 64, mults 1-2-4-8), DDPM-1000" if S == T
+                  else "sampled images/sec, 32x32 U-Net (dim 64, mults 1-2-4-8), DDIM-50",
         "value": value,
         "unit": "images/s",
         "n_gpus": world,
@@ -152,83 +235,78 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (name-seeded random-init weights, device Philox noise)",
+        "data": "synthetic (name-seeded random-init weights, device Philox noise keyed by global sample index)",
         "config": {
-            "workload": f"{args.workload}_32x32_unet64_b{B}_per_gpu",
+            "workload": f"{args.workload}_32x32_unet64_b{args.batch if args.scaling == 'weak' else B}_per_gpu",
+            "sampler": "p_sample_loop (DDPM)" if S == T else "ddim_sample (eta 0)",
             "sampler_steps": S,
             "batch_per_gpu": B,
-            "global_batch": B * world,
+            "global_batch": B_global,
             "hip_graph": not args.no_graph,
+            "graph_captures": unet.graph_captures,
             "parallelism": f"batch-shard x{world}, one all-gather per sample()",
         },
-        "image_steps_per_s": value * S,
-        "ddpm1000_equiv_images_per_s": value * S / 1000.0,
+        "denoise_image_steps_per_s": value * S,
+        "ms_per_denoise_step": ms_denoise,
+        "ddim50_equiv_images_per_s": value * S / 50.0,
     }
 
     if rank == 0 and not args.no_roofline:
-        # roofline leg: the same workload, eager launches, every conv bracketed by HIP events on its stream
-        diff_e = dm.DenoisingDiffusion(unet, image_size=IMAGE, timesteps=T, sampling_timesteps=50, use_graph=False)
+        # roofline leg: the same denoise step, eager launches, every conv bracketed by HIP events on its stream
+        diff_e = dm.DenoisingDiffusion(unet, image_size=IMAGE, timesteps=T, use_graph=False)
         _lib.profile_enable(True)
-        diff_e.ddim_sample((B, CHANNELS, IMAGE, IMAGE), sampling_timesteps=50, seed=3, max_steps=4)
+        diff_e.p_sample_loop((B, CHANNELS, IMAGE, IMAGE), seed=3, max_steps=4)
         rows = _lib.profile_read()
         _lib.profile_enable(False)
         rows.sort(key=lambda r: -r["total_ms"])
         kern = []
         for r in rows:
             avg_ms = r["total_ms"] / r["launches"]
-            tf = r["total_flops"] / (r["total_ms"] * 1e-3) / 1e12
+            # the Winograd F(2x2,3x3) kernel multiplies 16 instead of 36 times per (2x2 outputs, cin, cout): its own
+            # matrix work is 16/36 of the direct convolution's FLOP count that the rows are priced in
+            executed = 16.0 / 36.0 if r["kernel"].startswith("wino") else 1.0
+            tf_direct = r["total_flops"] / (r["total_ms"] * 1e-3) / 1e12
             kern.append({"kernel": r["kernel"], "launches_per_unet_fwd": r["launches"] // 4,
-                         "avg_ms": avg_ms, "tflops": tf, "frac_f32_peak": tf / PEAK_F32_TFLOPS,
+                         "avg_ms": avg_ms, "mfma_tflops": tf_direct * executed,
+                         "frac_f32_peak": tf_direct * executed / PEAK_F32_TFLOPS,
+                         "direct_conv_equiv_tflops": tf_direct,
                          "algorithmic_bytes_per_launch": r["total_bytes"] / r["launches"],
                          "algorithmic_GBps": r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e9})
         top = kern[0]
-        # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-        # separate runs, FETCH_SIZE doubled per the gfx950 correction); collected offline, see profiles/
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_step9_pmc_hbm_traffic.json")) as f:
-                pmc = {k.replace(" ", ""): v for k, v in json.load(f).items()}
-            t = pmc.get(top["kernel"].replace(" ", ""))
-            if t:
-                traffic = t["fetch_bytes_per_launch_corrected"] + t["write_bytes_per_launch"]
-        except OSError:
-            pass
-        # The Winograd F(2x2,3x3) kernel executes 16/36 of the multiply-adds of the direct form it is priced as
-        # (2*9*Cin*Cout*pixels), so its algorithmic rate can exceed the MFMA peak; the rate the
-        # matrix cores actually run at is reported next to it.
-        executed = 16.0 / 36.0 if top["kernel"].startswith("wino") else 1.0
+        traffic, traffic_src = pmc_traffic(top["kernel"])
         result["roofline"] = {
             "bound": "mfma",
             "kernel": top["kernel"],
-            "achieved": top["tflops"],
+            "achieved": top["mfma_tflops"],
             "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s",
-            "frac": top["tflops"] / PEAK_F32_TFLOPS,
-            "executed_tflops": top["tflops"] * executed,
-            "executed_frac": top["tflops"] * executed / PEAK_F32_TFLOPS,
+            "frac": top["mfma_tflops"] / PEAK_F32_TFLOPS,
+            "algorithmic_equiv": top["direct_conv_equiv_tflops"],
             "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (PMC, offline pass)",
+            "traffic_source": traffic_src,
+            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, offline pass of this command)",
             "algorithmic_bytes_per_launch": top["algorithmic_bytes_per_launch"],
             "avg_launch_ms": top["avg_ms"],
             "timing": "HIP events on the launch stream around every launch of an eager run behind a parked GPU, minus the "
                       "calibrated interval of an empty-kernel bracket (dispatch + event packets, ~9 us): kernel "
                       "execution time, comparable with rocprofv3 --kernel-trace",
-            "note": "achieved/frac: ALGORITHMIC FLOPs of the reference's direct 3x3 convolution "
-                    "(2*9*Cin*Cout*pixels per launch) over the HIP-event launch time, against the f32-input MFMA peak "
-                    "(== f32 vector peak); the kernel is Winograd F(2x2,3x3) and issues 16/36 of those multiply-adds, "
-                    "so frac > 1 is possible; executed_* is what the matrix cores sustain",
+            "note": "achieved = f32-MFMA FLOPs the kernel executes per launch (Winograd F(2x2,3x3): 2*16*Cin*Cout per 2x2 "
+                    "output pixels) / its average launch time; frac = achieved / f32 MFMA peak.  algorithmic_equiv prices "
+                    "the same launches as the reference's direct 3x3 convolution (2*9*Cin*Cout per pixel, SURVEY 8(d)) "
+                    "and can exceed the peak; it is not a roofline fraction",
         }
         result["kernels"] = kern
-        conv_ms = sum(r["total_ms"] for r in rows) / 4
-        result["conv_ms_per_unet_fwd"] = conv_ms
-        result["unet_fwd_ms_graph"] = 1e3 * elapsed / args.steps / S
+        result["conv_ms_per_unet_fwd"] = sum(r["total_ms"] for r in rows) / 4
+        # whole step: algorithmic FLOPs of one U-Net forward (3.651 GFLOP per image) over the graph time
+        result["step_direct_conv_equiv_tflops"] = 3.651e9 * B / (ms_denoise * 1e-3) / 1e12
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(sd, cfg, B, args.cpu_steps, S)
-        result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+        result["cpu_baseline"] = cpu_baseline(args.cpu_steps)
+        gpu_ddpm = value if S == T else value * S / T
+        result["gpu_over_cpu"] = gpu_ddpm / result["cpu_baseline"]["value"]
 
     if rank == 0:
         print(json.dumps(result))

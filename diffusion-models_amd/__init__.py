@@ -20,9 +20,10 @@ from .diffusion import (  # noqa: F401
     ImageConditionalLatentDiffusion,
     LatentDiffusion,
     TextConditionalDenoisingDiffusion,
+    TextConditionalLatentDiffusion,
 )
 from .vae import VQDecoder, VQEncoder, VQModel  # noqa: F401
-from .dist import gather_shards, sample_sharded, shard_bounds  # noqa: F401
+from .dist import gather_shards, sample_global, sample_sharded, shard_bounds, shared_seed  # noqa: F401
 from .checkpoint import load_trainer_checkpoint, load_vae_checkpoint  # noqa: F401
 
 __all__ = [
@@ -32,10 +33,12 @@ __all__ = [
     "ImageConditionalDenoisingDiffusion",
     "ImageConditionalLatentDiffusion",
     "LatentDiffusion",
+    "TextConditionalLatentDiffusion",
     "VQDecoder",
     "VQEncoder",
     "VQModel",
     "sample_sharded",
+    "sample_global",
     "gather_shards",
     "shard_bounds",
     "UnetConfig",

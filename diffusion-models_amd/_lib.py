@@ -14,12 +14,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DM_LIB") or os.path.join(_HERE, "libdm_hip.so")
 DM_MAX_STAGES = 8
 DM_COEFS = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/dm_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
     "dm_last_error", "dm_abi_version",
     "dm_unet_create", "dm_unet_destroy", "dm_unet_set_param", "dm_unet_missing_params", "dm_unet_finalize",
+    "dm_unet_update_param", "dm_unet_refresh", "dm_unet_graph_captures",
     "dm_unet_forward", "dm_sample", "dm_sample_cond", "dm_randn",
     "dm_decoder_create", "dm_decoder_destroy", "dm_decoder_set_param", "dm_decoder_missing_params",
     "dm_decoder_finalize", "dm_decoder_forward",
@@ -78,11 +79,14 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_unet_missing_params.argtypes = [vp]
     lib.dm_unet_finalize.argtypes = [vp]
     lib.dm_unet_forward.argtypes = [vp, fp, vp, fp, i32, fp, i32, i32, i32, vp]
-    lib.dm_sample.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, u64, fp, i32, fp, fp,
+    lib.dm_unet_update_param.argtypes = [vp, C.c_char_p, fp, C.POINTER(i64), i32]
+    lib.dm_unet_refresh.argtypes = [vp]
+    lib.dm_unet_graph_captures.argtypes = [vp]
+    lib.dm_sample.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, u64, u64, fp, i32, fp, fp,
                               i32, i32, i32, i32, i32, vp]
-    lib.dm_sample_cond.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, u64, fp, i32, fp, i32,
-                                   fp, fp, i32, i32, i32, i32, i32, vp]
-    lib.dm_randn.argtypes = [fp, i64, u64, u64, vp]
+    lib.dm_sample_cond.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, u64, u64, fp, i32, fp,
+                                   i32, fp, fp, i32, i32, i32, i32, i32, vp]
+    lib.dm_randn.argtypes = [fp, i64, u64, u64, u64, vp]
     lib.dm_decoder_create.argtypes = [C.POINTER(DecoderCfg), i32, C.POINTER(vp)]
     lib.dm_decoder_destroy.argtypes = [vp]
     lib.dm_decoder_destroy.restype = None

@@ -71,6 +71,7 @@ struct HostTensor {
     std::vector<int64_t> shape;
     std::vector<float> data;
     bool set = false;
+    bool dirty = false;  // changed by dm_unet_update_param since the device copy was packed
     size_t numel() const {
         size_t n = 1;
         for (auto d : shape) n *= (size_t)d;
@@ -78,15 +79,29 @@ struct HostTensor {
     }
 };
 
+// Owner of every repacked weight buffer of a handle.  The first build allocates one buffer per upload; a REFRESH
+// (dm_unet_refresh: new values for parameters of the same shapes) replays the same upload sequence into the same
+// buffers, so every device pointer -- and with them a captured step graph -- stays valid.
 struct DeviceOwner {
     std::vector<void*> ptrs;
+    std::vector<size_t> sizes;
+    bool refreshing = false;
+    size_t cursor = 0;
     ~DeviceOwner() {
         for (void* p : ptrs) (void)hipFree(p);
     }
     int upload(const float* host, size_t n, float** out) {
+        if (refreshing) {
+            DM_REQUIRE(cursor < ptrs.size() && sizes[cursor] == n, "refresh: the upload sequence differs from the first build");
+            void* p = ptrs[cursor++];
+            if (n) DM_CHECK_HIP(hipMemcpy(p, host, n * sizeof(float), hipMemcpyHostToDevice));
+            *out = static_cast<float*>(p);
+            return 0;
+        }
         void* p = nullptr;
         DM_CHECK_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)));
         ptrs.push_back(p);
+        sizes.push_back(n);
         if (n) DM_CHECK_HIP(hipMemcpy(p, host, n * sizeof(float), hipMemcpyHostToDevice));
         *out = static_cast<float*>(p);
         return 0;
@@ -172,10 +187,34 @@ struct dm_unet {
     char* ws = nullptr;
     size_t ws_cap = 0;
     // sampler state (device)
-    int* step_dev = nullptr;
+    SamplerState* state_dev = nullptr;
     int64_t* times_dev = nullptr;
     float* coefs_dev = nullptr;
     int sampler_cap = 0;
+    // weight groups: parameter-name prefix -> [first upload, count) in `own` (dm_unet_refresh skips clean groups)
+    std::map<std::string, std::pair<size_t, size_t>> groups;
+    std::vector<std::pair<std::string, ResBlock*>> resnets;  // in ss_off order
+    // the instantiated graph of one denoise step, reused while the key (shape, kind, every captured pointer) holds
+    struct GraphKey {
+        int kind = -1, B = 0, H = 0, W = 0, ctx_tokens = 0, cond_channels = 0;
+        const void *noise = nullptr, *all_steps = nullptr, *ws = nullptr, *times = nullptr, *coefs = nullptr;
+        bool operator==(const GraphKey& o) const {
+            return kind == o.kind && B == o.B && H == o.H && W == o.W && ctx_tokens == o.ctx_tokens &&
+                   cond_channels == o.cond_channels && noise == o.noise && all_steps == o.all_steps && ws == o.ws &&
+                   times == o.times && coefs == o.coefs;
+        }
+    } gkey;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    hipStream_t cap_stream = nullptr;  // capture / replay stream when the caller passes the legacy default stream
+    int graph_captures = 0;            // diagnostics (dm_unet_graph_captures)
+    void drop_graph() {
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        if (graph) (void)hipGraphDestroy(graph);
+        gexec = nullptr;
+        graph = nullptr;
+        gkey = GraphKey{};
+    }
 };
 
 namespace dm {
@@ -296,30 +335,78 @@ static int up1(dm_unet* u, const std::string& n, float** out) {
     return u->own.upload(t.data.data(), t.data.size(), out);
 }
 
-static int build_resnet(dm_unet* u, ResBlock& R, const std::string& p, int C0, int C1, int dout, int& ss_off,
-                        std::vector<float>& ssw, std::vector<float>& ssb) {
-    int din = C0 + C1;
-    R.dout = dout;
-    R.ss_off = ss_off;
-    const HostTensor& mw = P(u, p + ".mlp.1.weight");
-    const HostTensor& mb = P(u, p + ".mlp.1.bias");
-    ssw.insert(ssw.end(), mw.data.begin(), mw.data.end());
-    ssb.insert(ssb.end(), mb.data.begin(), mb.data.end());
-    ss_off += 2 * dout;
-    if (make_conv(u->own, R.c1, P(u, p + ".block1.proj.weight").data.data(), P(u, p + ".block1.proj.bias").data.data(),
-                  dout, C0, C1, 3, 3, 1, 1, false)) return 1;
-    if (make_conv(u->own, R.c2, P(u, p + ".block2.proj.weight").data.data(), P(u, p + ".block2.proj.bias").data.data(),
-                  dout, dout, 0, 3, 3, 1, 1, false)) return 1;
-    if (up1(u, p + ".block1.norm.g", &R.g1) || up1(u, p + ".block2.norm.g", &R.g2)) return 1;
-    R.has_res = din != dout;
-    if (R.has_res) {
-        if (make_conv(u->own, R.res, P(u, p + ".res_conv.weight").data.data(), P(u, p + ".res_conv.bias").data.data(),
-                      dout, C0, C1, 1, 1, 1, 0, false)) return 1;
+// One weight group = everything packed from the parameters under one name prefix.  First build: run `build` and
+// record which uploads it made.  Refresh: re-run it into the same buffers if any of its parameters changed, else skip.
+static bool prefix_dirty(dm_unet* u, const std::string& prefix) {
+    for (auto it = u->params.lower_bound(prefix); it != u->params.end(); ++it) {
+        const std::string& k = it->first;
+        if (k.compare(0, prefix.size(), prefix) != 0) break;
+        if ((k.size() == prefix.size() || k[prefix.size()] == '.') && it->second.dirty) return true;
     }
+    return false;
+}
+template <class F>
+static int weight_group(dm_unet* u, const std::string& prefix, F build) {
+    DeviceOwner& own = u->own;
+    if (own.refreshing) {
+        auto it = u->groups.find(prefix);
+        DM_REQUIRE(it != u->groups.end(), "refresh: unknown weight group");
+        DM_REQUIRE(own.cursor == it->second.first, "refresh: weight groups out of order");
+        if (!prefix_dirty(u, prefix)) {
+            own.cursor += it->second.second;
+            return 0;
+        }
+        if (build()) return 1;
+        DM_REQUIRE(own.cursor == it->second.first + it->second.second, "refresh: upload count differs from the first build");
+        return 0;
+    }
+    const size_t start = own.ptrs.size();
+    if (build()) return 1;
+    u->groups[prefix] = {start, own.ptrs.size() - start};
     return 0;
 }
 
-static int build_attn(dm_unet* u, AttnLayer& A, const std::string& p, int dim, bool full) {
+static int build_resnet(dm_unet* u, ResBlock& R, const std::string& p, int C0, int C1, int dout, int& ss_off) {
+    // the mlp (SiLU -> Linear) of every ResnetBlock is one row block of the concatenated [ss_total][time_dim] matrix
+    // assembled by build_scale_shift
+    R.dout = dout;
+    R.ss_off = ss_off;
+    ss_off += 2 * dout;
+    if (!u->own.refreshing) u->resnets.emplace_back(p, &R);
+    return weight_group(u, p, [&]() -> int {
+        int din = C0 + C1;
+        if (make_conv(u->own, R.c1, P(u, p + ".block1.proj.weight").data.data(), P(u, p + ".block1.proj.bias").data.data(),
+                      dout, C0, C1, 3, 3, 1, 1, false)) return 1;
+        if (make_conv(u->own, R.c2, P(u, p + ".block2.proj.weight").data.data(), P(u, p + ".block2.proj.bias").data.data(),
+                      dout, dout, 0, 3, 3, 1, 1, false)) return 1;
+        if (up1(u, p + ".block1.norm.g", &R.g1) || up1(u, p + ".block2.norm.g", &R.g2)) return 1;
+        R.has_res = din != dout;
+        if (R.has_res) {
+            if (make_conv(u->own, R.res, P(u, p + ".res_conv.weight").data.data(), P(u, p + ".res_conv.bias").data.data(),
+                          dout, C0, C1, 1, 1, 1, 0, false)) return 1;
+        }
+        return 0;
+    });
+}
+
+static int build_scale_shift(dm_unet* u) {
+    bool dirty = false;
+    for (auto& pr : u->resnets) dirty = dirty || P(u, pr.first + ".mlp.1.weight").dirty || P(u, pr.first + ".mlp.1.bias").dirty;
+    if (u->own.refreshing && !dirty) {
+        u->own.cursor += 2;
+        return 0;
+    }
+    std::vector<float> ssw, ssb;
+    for (auto& pr : u->resnets) {
+        const HostTensor& mw = P(u, pr.first + ".mlp.1.weight");
+        const HostTensor& mb = P(u, pr.first + ".mlp.1.bias");
+        ssw.insert(ssw.end(), mw.data.begin(), mw.data.end());
+        ssb.insert(ssb.end(), mb.data.begin(), mb.data.end());
+    }
+    return u->own.upload(ssw.data(), ssw.size(), &u->ss_w) || u->own.upload(ssb.data(), ssb.size(), &u->ss_b);
+}
+
+static int build_attn_body(dm_unet* u, AttnLayer& A, const std::string& p, int dim, bool full) {
     A.full = full;
     A.dim = dim;
     int hidden = u->heads * u->dh;
@@ -369,7 +456,11 @@ static int build_attn(dm_unet* u, AttnLayer& A, const std::string& p, int dim, b
     return 0;
 }
 
-static int build_cross(dm_unet* u, CrossLayer& C, const std::string& p, int dim) {
+static int build_attn(dm_unet* u, AttnLayer& A, const std::string& p, int dim, bool full) {
+    return weight_group(u, p, [&]() -> int { return build_attn_body(u, A, p, dim, full); });
+}
+
+static int build_cross_body(dm_unet* u, CrossLayer& C, const std::string& p, int dim) {
     int inner = 4 * u->dh;
     // nn.Linear weights [out, in] are 1x1 conv weights (out, in, 1, 1)
     if (make_conv(u->own, C.q, P(u, p + ".to_q.weight").data.data(), nullptr, inner, dim, 0, 1, 1, 1, 0, false)) return 1;
@@ -377,6 +468,101 @@ static int build_cross(dm_unet* u, CrossLayer& C, const std::string& p, int dim)
                   inner, 0, 1, 1, 1, 0, false)) return 1;
     if (up1(u, p + ".to_k.weight", &C.wk) || up1(u, p + ".to_v.weight", &C.wv) || up1(u, p + ".to_out.1.g", &C.g))
         return 1;
+    return 0;
+}
+
+static int build_cross(dm_unet* u, CrossLayer& C, const std::string& p, int dim) {
+    return weight_group(u, p, [&]() -> int { return build_cross_body(u, C, p, dim); });
+}
+
+// Pack every parameter into its kernel layout and upload it: the first build (dm_unet_finalize) and, with
+// own.refreshing set, the in-place refresh of changed parameters (dm_unet_refresh).
+static int build_all(dm_unet* u) {
+    const dm_unet_cfg& cfg = u->cfg;
+    const int n = cfg.n_stages;
+    // sinusoid frequencies, fp32 as the reference computes them (DD/denoising_diffusion.py:79-81)
+    if (weight_group(u, "#freqs", [&]() -> int {
+            int half = cfg.dim / 2;
+            double k = std::log((double)cfg.sinusoidal_theta) / (half - 1);
+            float kf = (float)(-k);
+            std::vector<float> f(half);
+            for (int i = 0; i < half; ++i) f[i] = std::exp((float)i * kf);
+            return u->own.upload(f.data(), f.size(), &u->freqs);
+        }))
+        return 1;
+    if (weight_group(u, "time_mlp", [&]() -> int {
+            return up1(u, "time_mlp.1.weight", &u->tw1) || up1(u, "time_mlp.1.bias", &u->tb1) ||
+                   up1(u, "time_mlp.3.weight", &u->tw2) || up1(u, "time_mlp.3.bias", &u->tb2);
+        }))
+        return 1;
+    if (weight_group(u, "init_conv", [&]() -> int {
+            return make_conv(u->own, u->init_conv, P(u, "init_conv.weight").data.data(), P(u, "init_conv.bias").data.data(),
+                             u->init_dim, cfg.input_channels, 0, 7, 7, 1, 3, false);
+        }))
+        return 1;
+    int ss_off = 0;
+    u->downs.resize(n);
+    u->ups.resize(n);
+    for (int i = 0; i < n; ++i) {
+        int din = u->dims[i], dout = u->dims[i + 1];
+        std::string q = idx("downs", i);
+        Stage& S = u->downs[i];
+        if (build_resnet(u, S.b1, q + ".0", din, 0, din, ss_off)) return 1;
+        if (build_resnet(u, S.b2, q + ".1", din, 0, din, ss_off)) return 1;
+        if (build_attn(u, S.attn, q + ".2", din, cfg.full_attn[i] != 0)) return 1;
+        if (weight_group(u, q + ".3", [&]() -> int {
+                if (i < n - 1) {
+                    // pixel-unshuffle + 1x1  ==  2x2 stride-2 conv: W'[o][c][p1][p2] = W[o][c*4 + p1*2 + p2]
+                    return make_conv(u->own, S.resample, P(u, q + ".3.1.weight").data.data(),
+                                     P(u, q + ".3.1.bias").data.data(), dout, din, 0, 2, 2, 2, 0, false);
+                }
+                return make_conv(u->own, S.resample, P(u, q + ".3.weight").data.data(), P(u, q + ".3.bias").data.data(),
+                                 dout, din, 0, 3, 3, 1, 1, false);
+            }))
+            return 1;
+    }
+    int mid = u->dims.back();
+    if (build_resnet(u, u->mid1, "mid_block1", mid, 0, mid, ss_off)) return 1;
+    if (build_attn(u, u->mid_attn, "mid_attn", mid, true)) return 1;
+    if (build_resnet(u, u->mid2, "mid_block2", mid, 0, mid, ss_off)) return 1;
+    for (int j = 0; j < n; ++j) {
+        int din = u->dims[n - 1 - j], dout = u->dims[n - j];
+        std::string q = idx("ups", j);
+        Stage& S = u->ups[j];
+        if (build_resnet(u, S.b1, q + ".0", dout, din, dout, ss_off)) return 1;
+        if (build_resnet(u, S.b2, q + ".1", dout, din, dout, ss_off)) return 1;
+        if (build_attn(u, S.attn, q + ".2", dout, cfg.full_attn[n - 1 - j] != 0)) return 1;
+        if (weight_group(u, q + ".3", [&]() -> int {
+                if (j < n - 1)
+                    return make_conv(u->own, S.resample, P(u, q + ".3.1.weight").data.data(),
+                                     P(u, q + ".3.1.bias").data.data(), din, dout, 0, 3, 3, 1, 1, /*up=*/true);
+                return make_conv(u->own, S.resample, P(u, q + ".3.weight").data.data(), P(u, q + ".3.bias").data.data(),
+                                 din, dout, 0, 3, 3, 1, 1, false);
+            }))
+            return 1;
+    }
+    if (build_resnet(u, u->final_res, "final_res_block", u->init_dim, u->init_dim, u->init_dim, ss_off)) return 1;
+    if (weight_group(u, "final_conv", [&]() -> int {
+            return make_conv(u->own, u->final_conv, P(u, "final_conv.weight").data.data(),
+                             P(u, "final_conv.bias").data.data(), u->out_dim, u->init_dim, 0, 1, 1, 1, 0, false);
+        }))
+        return 1;
+    u->ss_total = ss_off;
+    if (build_scale_shift(u)) return 1;
+    if (cfg.text_mode == DM_TEXT_CONCAT) {
+        if (weight_group(u, "text_proj", [&]() -> int {
+                return up1(u, "text_proj.0.weight", &u->tp_w0) || up1(u, "text_proj.0.bias", &u->tp_b0) ||
+                       up1(u, "text_proj.2.weight", &u->tp_w2) || up1(u, "text_proj.2.bias", &u->tp_b2);
+            }) ||
+            weight_group(u, "text_concat_proj", [&]() -> int {
+                return up1(u, "text_concat_proj.weight", &u->tc_w) || up1(u, "text_concat_proj.bias", &u->tc_b);
+            }))
+            return 1;
+    } else if (cfg.text_mode == DM_TEXT_CROSS) {
+        if (build_cross(u, u->cross_mid, "cross_attn", mid) || build_cross(u, u->cross_down, "cross_attn_down", mid) ||
+            build_cross(u, u->cross_up, "cross_attn_up", mid))
+            return 1;
+    }
     return 0;
 }
 
@@ -569,7 +755,7 @@ static int run_cross(Ctx& c, const CrossLayer& Cr, const float* x, int H, int W,
 
 // Unet.forward (DD/denoising_diffusion.py:349-390; text hooks DD/denoising_diffusion_text_conditional.py:131-214)
 static int unet_forward_impl(dm_unet* u, Arena& A, const float* x_nchw, const int64_t* t_dev,
-                             const int64_t* step_times, const int* step_dev, const float* ctx, int ctx_tokens,
+                             const int64_t* step_times, const SamplerState* step_dev, const float* ctx, int ctx_tokens,
                              float* out_nchw, int B, int H, int W, hipStream_t s) {
     const dm_unet_cfg& cfg = u->cfg;
     Ctx c{u, &A, s, B, nullptr, 0};
@@ -596,13 +782,13 @@ static int unet_forward_impl(dm_unet* u, Arena& A, const float* x_nchw, const in
         float* tf0 = A.alloc((size_t)B * td);
         float* t2 = A.alloc((size_t)B * td);
         if (!A.dry) {
-            // left half: the time embedding of every row (broadcast when Rt == 1)
-            for (int r = 0; r < (Rt == 1 ? B : 0); ++r)
-                DM_CHECK_HIP(hipMemcpyAsync(cat + (size_t)r * 2 * td, temb, td * sizeof(float),
-                                            hipMemcpyDeviceToDevice, s));
-            if (Rt != 1)
+            // left half: the time embedding of every row (one broadcast launch when the batch shares t)
+            if (Rt == 1) {
+                if (launch_broadcast_rows(temb, cat, B, td, 2 * td, s)) return 1;
+            } else {
                 DM_CHECK_HIP(hipMemcpy2DAsync(cat, 2 * td * sizeof(float), temb, td * sizeof(float),
                                               td * sizeof(float), B, hipMemcpyDeviceToDevice, s));
+            }
             if (launch_linear_rows(ctx, cfg.text_emb_dim, u->tp_w0, u->tp_b0, tf0, td, B, cfg.text_emb_dim, td, 0, 2, s))
                 return 1;
             if (launch_linear_rows(tf0, td, u->tp_w2, u->tp_b2, cat + td, 2 * td, B, td, td, 0, 0, s)) return 1;
@@ -670,6 +856,7 @@ static int unet_forward_impl(dm_unet* u, Arena& A, const float* x_nchw, const in
 static int ensure_workspace(dm_unet* u, size_t bytes) {
     if (bytes <= u->ws_cap) return 0;
     DM_CHECK_HIP(hipDeviceSynchronize());
+    u->drop_graph();  // the captured step points into the old arena
     if (u->ws) (void)hipFree(u->ws);
     u->ws = nullptr;
     u->ws_cap = 0;
@@ -698,7 +885,7 @@ static int check_hw(dm_unet* u, int H, int W) {
 extern "C" {
 
 const char* dm_last_error(void) { return g_err.c_str(); }
-int dm_abi_version(void) { return 1; }
+int dm_abi_version(void) { return 2; }
 
 int dm_unet_create(const dm_unet_cfg* cfg, int device, dm_unet** out) {
     DM_REQUIRE(cfg && out, "null argument");
@@ -782,8 +969,10 @@ int dm_unet_create(const dm_unet_cfg* cfg, int device, dm_unet** out) {
 void dm_unet_destroy(dm_unet* u) {
     if (!u) return;
     (void)hipSetDevice(u->device);
+    u->drop_graph();
+    if (u->cap_stream) (void)hipStreamDestroy(u->cap_stream);
     if (u->ws) (void)hipFree(u->ws);
-    if (u->step_dev) (void)hipFree(u->step_dev);
+    if (u->state_dev) (void)hipFree(u->state_dev);
     if (u->times_dev) (void)hipFree(u->times_dev);
     if (u->coefs_dev) (void)hipFree(u->coefs_dev);
     delete u;
@@ -827,83 +1016,54 @@ int dm_unet_finalize(dm_unet* u) {
     DM_REQUIRE(!u->finalized, "already finalized");
     if (dm_unet_missing_params(u) != 0) return 1;
     DM_CHECK_HIP(hipSetDevice(u->device));
-    const dm_unet_cfg& cfg = u->cfg;
-    const int n = cfg.n_stages;
-    // sinusoid frequencies, fp32 as the reference computes them (DD/denoising_diffusion.py:79-81)
-    {
-        int half = cfg.dim / 2;
-        double k = std::log((double)cfg.sinusoidal_theta) / (half - 1);
-        float kf = (float)(-k);
-        std::vector<float> f(half);
-        for (int i = 0; i < half; ++i) f[i] = std::exp((float)i * kf);
-        if (u->own.upload(f.data(), f.size(), &u->freqs)) return 1;
-    }
-    if (up1(u, "time_mlp.1.weight", &u->tw1) || up1(u, "time_mlp.1.bias", &u->tb1) ||
-        up1(u, "time_mlp.3.weight", &u->tw2) || up1(u, "time_mlp.3.bias", &u->tb2))
-        return 1;
-    if (make_conv(u->own, u->init_conv, P(u, "init_conv.weight").data.data(), P(u, "init_conv.bias").data.data(),
-                  u->init_dim, cfg.input_channels, 0, 7, 7, 1, 3, false)) return 1;
-    std::vector<float> ssw, ssb;
-    int ss_off = 0;
-    u->downs.resize(n);
-    u->ups.resize(n);
-    for (int i = 0; i < n; ++i) {
-        int din = u->dims[i], dout = u->dims[i + 1];
-        std::string q = idx("downs", i);
-        Stage& S = u->downs[i];
-        if (build_resnet(u, S.b1, q + ".0", din, 0, din, ss_off, ssw, ssb)) return 1;
-        if (build_resnet(u, S.b2, q + ".1", din, 0, din, ss_off, ssw, ssb)) return 1;
-        if (build_attn(u, S.attn, q + ".2", din, cfg.full_attn[i] != 0)) return 1;
-        if (i < n - 1) {
-            // pixel-unshuffle + 1x1  ==  2x2 stride-2 conv: W'[o][c][p1][p2] = W[o][c*4 + p1*2 + p2]
-            const HostTensor& w = P(u, q + ".3.1.weight");
-            if (make_conv(u->own, S.resample, w.data.data(), P(u, q + ".3.1.bias").data.data(), dout, din, 0, 2, 2, 2, 0,
-                          false)) return 1;
-        } else {
-            if (make_conv(u->own, S.resample, P(u, q + ".3.weight").data.data(), P(u, q + ".3.bias").data.data(), dout,
-                          din, 0, 3, 3, 1, 1, false)) return 1;
-        }
-    }
-    int mid = u->dims.back();
-    if (build_resnet(u, u->mid1, "mid_block1", mid, 0, mid, ss_off, ssw, ssb)) return 1;
-    if (build_attn(u, u->mid_attn, "mid_attn", mid, true)) return 1;
-    if (build_resnet(u, u->mid2, "mid_block2", mid, 0, mid, ss_off, ssw, ssb)) return 1;
-    for (int j = 0; j < n; ++j) {
-        int din = u->dims[n - 1 - j], dout = u->dims[n - j];
-        std::string q = idx("ups", j);
-        Stage& S = u->ups[j];
-        if (build_resnet(u, S.b1, q + ".0", dout, din, dout, ss_off, ssw, ssb)) return 1;
-        if (build_resnet(u, S.b2, q + ".1", dout, din, dout, ss_off, ssw, ssb)) return 1;
-        if (build_attn(u, S.attn, q + ".2", dout, cfg.full_attn[n - 1 - j] != 0)) return 1;
-        if (j < n - 1) {
-            if (make_conv(u->own, S.resample, P(u, q + ".3.1.weight").data.data(), P(u, q + ".3.1.bias").data.data(), din,
-                          dout, 0, 3, 3, 1, 1, /*up=*/true)) return 1;
-        } else {
-            if (make_conv(u->own, S.resample, P(u, q + ".3.weight").data.data(), P(u, q + ".3.bias").data.data(), din,
-                          dout, 0, 3, 3, 1, 1, false)) return 1;
-        }
-    }
-    if (build_resnet(u, u->final_res, "final_res_block", u->init_dim, u->init_dim, u->init_dim, ss_off, ssw, ssb))
-        return 1;
-    if (make_conv(u->own, u->final_conv, P(u, "final_conv.weight").data.data(), P(u, "final_conv.bias").data.data(),
-                  u->out_dim, u->init_dim, 0, 1, 1, 1, 0, false)) return 1;
-    u->ss_total = ss_off;
-    if (u->own.upload(ssw.data(), ssw.size(), &u->ss_w) || u->own.upload(ssb.data(), ssb.size(), &u->ss_b)) return 1;
-    if (cfg.text_mode == DM_TEXT_CONCAT) {
-        if (up1(u, "text_proj.0.weight", &u->tp_w0) || up1(u, "text_proj.0.bias", &u->tp_b0) ||
-            up1(u, "text_proj.2.weight", &u->tp_w2) || up1(u, "text_proj.2.bias", &u->tp_b2) ||
-            up1(u, "text_concat_proj.weight", &u->tc_w) || up1(u, "text_concat_proj.bias", &u->tc_b))
-            return 1;
-    } else if (cfg.text_mode == DM_TEXT_CROSS) {
-        if (build_cross(u, u->cross_mid, "cross_attn", mid) || build_cross(u, u->cross_down, "cross_attn_down", mid) ||
-            build_cross(u, u->cross_up, "cross_attn_up", mid))
-            return 1;
-    }
-    // the host copies are no longer needed
-    for (auto& kv : u->params) std::vector<float>().swap(kv.second.data);
+    if (build_all(u)) return 1;
+    // the host copies stay: dm_unet_update_param / dm_unet_refresh re-pack from them
     u->finalized = true;
     return 0;
 }
+
+int dm_unet_update_param(dm_unet* u, const char* name, const float* data_host, const int64_t* shape, int ndim) {
+    DM_REQUIRE(u && name && data_host && shape, "null argument");
+    DM_REQUIRE(u->finalized, "dm_unet_update_param before dm_unet_finalize (use dm_unet_set_param)");
+    auto it = u->params.find(name);
+    if (it == u->params.end()) {
+        set_error(std::string("unexpected parameter: ") + name);
+        return 1;
+    }
+    HostTensor& t = it->second;
+    bool ok = (int)t.shape.size() == ndim;
+    for (int i = 0; ok && i < ndim; ++i) ok = t.shape[i] == shape[i];
+    if (!ok) {
+        set_error(std::string("shape mismatch for ") + name);
+        return 1;
+    }
+    if (std::memcmp(t.data.data(), data_host, t.numel() * sizeof(float)) == 0) return 0;  // unchanged
+    t.data.assign(data_host, data_host + t.numel());
+    t.dirty = true;
+    return 0;
+}
+
+int dm_unet_refresh(dm_unet* u) {
+    DM_REQUIRE(u, "null handle");
+    DM_REQUIRE(u->finalized, "dm_unet_refresh before dm_unet_finalize");
+    bool any = false;
+    for (auto& kv : u->params) any = any || kv.second.dirty;
+    if (!any) return 0;
+    DM_CHECK_HIP(hipSetDevice(u->device));
+    DM_CHECK_HIP(hipDeviceSynchronize());  // no kernel may be reading the buffers that are rewritten
+    u->own.refreshing = true;
+    u->own.cursor = 0;
+    int rc = build_all(u);
+    if (!rc && u->own.cursor != u->own.ptrs.size()) {
+        set_error("refresh: not every weight buffer was visited");
+        rc = 1;
+    }
+    u->own.refreshing = false;
+    for (auto& kv : u->params) kv.second.dirty = false;
+    return rc;
+}
+
+int dm_unet_graph_captures(dm_unet* u) { return u ? u->graph_captures : -1; }
 
 int dm_unet_forward(dm_unet* u, const float* x, const int64_t* time, const float* ctx, int ctx_tokens, float* out,
                     int B, int H, int W, void* stream) {
@@ -928,10 +1088,16 @@ int dm_unet_forward(dm_unet* u, const float* x, const int64_t* time, const float
 // The sampling loop behind dm_sample / dm_sample_cond.  cond (B, cond_channels, H, W) is the image condition of
 // DD/denoising_diffusion_image_conditional.py:51-55,156-180: constant over the loop, concatenated behind x in front of
 // init_conv at every step.
+//
+// One denoise step (U-Net forward + update + step counter) touches only handle-owned memory: x, eps, the [x | cond]
+// input, the text context and the final image live at fixed offsets of the workspace, and everything that differs
+// between two calls of one shape (seed, Philox offset, step tables) is device DATA, not a kernel argument.  The step is
+// therefore captured into a hipGraph once per (shape, sampler kind) and the instantiated graph is replayed by every
+// later call; it is re-captured only when the shape, an injected-noise / all-steps pointer or the workspace changes.
 static int sample_impl(dm_unet* u, int kind, int n_steps, const int64_t* times_host, const float* coefs_host,
-                       const float* x_T, const float* noise, uint64_t seed, const float* ctx, int ctx_tokens,
-                       const float* cond, int cond_channels, float* out, float* all_steps, int B, int H, int W,
-                       int unnormalize, int use_graph, void* stream) {
+                       const float* x_T, const float* noise, uint64_t seed, uint64_t sample_offset, const float* ctx,
+                       int ctx_tokens, const float* cond, int cond_channels, float* out, float* all_steps, int B, int H,
+                       int W, int unnormalize, int use_graph, void* stream) {
     DM_REQUIRE(u && times_host && coefs_host && x_T && out, "null argument");
     DM_REQUIRE(u->finalized, "dm_unet_finalize has not been called");
     DM_REQUIRE(kind == DM_SAMPLER_DDPM || kind == DM_SAMPLER_DDIM, "unknown sampler kind");
@@ -940,37 +1106,61 @@ static int sample_impl(dm_unet* u, int kind, int n_steps, const int64_t* times_h
     DM_REQUIRE((cond == nullptr) == (cond_channels == 0) && cond_channels >= 0, "cond and cond_channels come together");
     DM_REQUIRE(u->cfg.input_channels == u->cfg.channels + cond_channels,
                "U-Net input channels != channels + cond_channels (self-conditioning is not on this path)");
+    DM_REQUIRE((ctx == nullptr) == (ctx_tokens == 0), "ctx and ctx_tokens come together");
     if (check_hw(u, H, W)) return 1;
     DM_CHECK_HIP(hipSetDevice(u->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int C = u->cfg.channels;
     const int64_t n = (int64_t)B * C * H * W;
     const int64_t n_in = (int64_t)B * (C + cond_channels) * H * W;
+    const int64_t n_ctx = ctx ? (int64_t)B * ctx_tokens * u->cfg.text_emb_dim : 0;
+    const uint64_t elem_off = sample_offset * (uint64_t)C * H * W;  // global element index of this shard's first value
+    DM_REQUIRE(elem_off % 4 == 0, "sample_offset * C * H * W must be a multiple of 4");
 
+    if (!u->state_dev) DM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&u->state_dev), 256));
     if (n_steps > u->sampler_cap) {
         DM_CHECK_HIP(hipDeviceSynchronize());
+        u->drop_graph();
         if (u->times_dev) (void)hipFree(u->times_dev);
         if (u->coefs_dev) (void)hipFree(u->coefs_dev);
-        if (!u->step_dev) DM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&u->step_dev), 64));
+        u->times_dev = nullptr;
+        u->coefs_dev = nullptr;
+        u->sampler_cap = 0;
         DM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&u->times_dev), n_steps * sizeof(int64_t)));
         DM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&u->coefs_dev), (size_t)n_steps * DM_COEFS * sizeof(float)));
         u->sampler_cap = n_steps;
     }
-    // workspace: [x | eps | forward arena]
+    // graph mode on the legacy default stream: that stream cannot be captured, so the whole call runs on a stream of
+    // the handle, ordered after the caller's work by a synchronisation here and finished before return
+    const bool own_stream = use_graph && s == nullptr;
+    if (own_stream) {
+        if (!u->cap_stream) DM_CHECK_HIP(hipStreamCreateWithFlags(&u->cap_stream, hipStreamNonBlocking));
+        DM_CHECK_HIP(hipStreamSynchronize(nullptr));
+        s = u->cap_stream;
+    }
+    // workspace: [x | eps | [x | cond] | ctx | forward arena]
     Arena dry;
     dry.dry = true;
     dry.alloc(n);
     dry.alloc(n);
     if (cond) dry.alloc(n_in);
-    if (unet_forward_impl(u, dry, nullptr, nullptr, u->times_dev, u->step_dev, ctx, ctx_tokens, nullptr, B, H, W, s))
+    if (ctx) dry.alloc(n_ctx);
+    const float* ctx_marker = ctx ? reinterpret_cast<const float*>(16) : nullptr;
+    if (unet_forward_impl(u, dry, nullptr, nullptr, u->times_dev, u->state_dev, ctx_marker, ctx_tokens, nullptr, B, H, W, s))
         return 1;
     if (ensure_workspace(u, dry.off)) return 1;
 
+    SamplerState st_host{};
+    st_host.step = 0;
+    st_host.n_steps = n_steps;
+    st_host.unnormalize = unnormalize;
+    st_host.seed = seed;
+    st_host.off4 = elem_off / 4;
     DM_CHECK_HIP(hipMemcpyAsync(u->times_dev, times_host, n_steps * sizeof(int64_t), hipMemcpyHostToDevice, s));
     DM_CHECK_HIP(hipMemcpyAsync(u->coefs_dev, coefs_host, (size_t)n_steps * DM_COEFS * sizeof(float),
                                 hipMemcpyHostToDevice, s));
-    DM_CHECK_HIP(hipMemsetAsync(u->step_dev, 0, sizeof(int), s));
-    DM_CHECK_HIP(hipStreamSynchronize(s));  // host tables may be freed by the caller after return anyway
+    DM_CHECK_HIP(hipMemcpyAsync(u->state_dev, &st_host, sizeof(st_host), hipMemcpyHostToDevice, s));
+    DM_CHECK_HIP(hipStreamSynchronize(s));  // the host tables and st_host may go away when this function returns
 
     Arena A;
     A.base = u->ws;
@@ -978,21 +1168,27 @@ static int sample_impl(dm_unet* u, int kind, int n_steps, const int64_t* times_h
     float* xbuf = A.alloc(n);
     float* eps = A.alloc(n);
     float* xin = cond ? A.alloc(n_in) : nullptr;  // [x | cond] per image, what init_conv reads
+    float* ctxbuf = ctx ? A.alloc(n_ctx) : nullptr;
     const size_t arena_mark = A.off;
     DM_CHECK_HIP(hipMemcpyAsync(xbuf, x_T, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (ctx) DM_CHECK_HIP(hipMemcpyAsync(ctxbuf, ctx, n_ctx * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (cond && launch_copy_channels(cond, xin, B, cond_channels, C + cond_channels, C, H * W, s)) return 1;
     if (all_steps) DM_CHECK_HIP(hipMemcpyAsync(all_steps, x_T, n * sizeof(float), hipMemcpyDeviceToDevice, s));
 
     auto one_step = [&](hipStream_t st) -> int {
         A.off = arena_mark;
         if (cond && launch_copy_channels(xbuf, xin, B, C, C + cond_channels, 0, H * W, st)) return 1;
-        if (unet_forward_impl(u, A, cond ? xin : xbuf, nullptr, u->times_dev, u->step_dev, ctx, ctx_tokens, eps, B, H, W,
-                              st))
+        if (unet_forward_impl(u, A, cond ? xin : xbuf, nullptr, u->times_dev, u->state_dev, ctxbuf, ctx_tokens, eps, B, H,
+                              W, st))
             return 1;
-        if (launch_sampler_update(kind, xbuf, eps, noise, u->coefs_dev, u->step_dev, n, seed, xbuf, all_steps, out,
-                                  unnormalize, n_steps, n, st))
+        if (launch_sampler_update(kind, xbuf, eps, noise, u->coefs_dev, u->state_dev, n, xbuf, all_steps, nullptr, n, st))
             return 1;
-        return launch_step_advance(u->step_dev, st);
+        return launch_step_advance(u->state_dev, st);
+    };
+    auto finish = [&]() -> int {  // out = x_0 [ (x + 1) / 2 ]
+        if (launch_finalize(xbuf, out, n, unnormalize, s)) return 1;
+        if (own_stream) DM_CHECK_HIP(hipStreamSynchronize(s));
+        return 0;
     };
 
     if (!use_graph) {
@@ -1000,58 +1196,60 @@ static int sample_impl(dm_unet* u, int kind, int n_steps, const int64_t* times_h
         if (prof::enabled() && n_steps <= 8 && launch_spin(8.0 * n_steps, s)) return 1;
         for (int i = 0; i < n_steps; ++i)
             if (one_step(s)) return 1;
-        return 0;
+        return finish();
     }
-    // capture one denoise step (all pointers and shapes are static; t, coefficients and the
-    // noise row are read through the device-side step counter) and replay it n_steps times
-    hipStream_t cs = s;
-    bool own_stream = false;
-    if (cs == nullptr) {  // the legacy default stream cannot be captured
-        DM_CHECK_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        own_stream = true;
-        DM_CHECK_HIP(hipStreamSynchronize(s));
+    dm_unet::GraphKey key;
+    key.kind = kind; key.B = B; key.H = H; key.W = W; key.ctx_tokens = ctx_tokens; key.cond_channels = cond_channels;
+    key.noise = noise; key.all_steps = all_steps; key.ws = u->ws; key.times = u->times_dev; key.coefs = u->coefs_dev;
+    if (!u->gexec || !(u->gkey == key)) {
+        u->drop_graph();
+        DM_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int rc = one_step(s);
+        hipGraph_t graph = nullptr;
+        hipError_t ce = hipStreamEndCapture(s, &graph);
+        if (rc || ce != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            if (!rc) set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+            return 1;
+        }
+        hipGraphExec_t exec = nullptr;
+        hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) {
+            (void)hipGraphDestroy(graph);
+            set_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+            return 1;
+        }
+        u->graph = graph;
+        u->gexec = exec;
+        u->gkey = key;
+        u->graph_captures += 1;
     }
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    DM_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-    int rc = one_step(cs);
-    hipError_t ce = hipStreamEndCapture(cs, &graph);
-    if (rc || ce != hipSuccess) {
-        if (graph) (void)hipGraphDestroy(graph);
-        if (own_stream) (void)hipStreamDestroy(cs);
-        if (!rc) set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-        return 1;
-    }
-    DM_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    for (int i = 0; i < n_steps; ++i) DM_CHECK_HIP(hipGraphLaunch(exec, cs));
-    DM_CHECK_HIP(hipStreamSynchronize(cs));
-    (void)hipGraphExecDestroy(exec);
-    (void)hipGraphDestroy(graph);
-    if (own_stream) (void)hipStreamDestroy(cs);
-    return 0;
+    for (int i = 0; i < n_steps; ++i) DM_CHECK_HIP(hipGraphLaunch(u->gexec, s));
+    return finish();
 }
 
 extern "C" {
 
 int dm_sample(dm_unet* u, int kind, int n_steps, const int64_t* times_host, const float* coefs_host,
-              const float* x_T, const float* noise, uint64_t seed, const float* ctx, int ctx_tokens, float* out,
-              float* all_steps, int B, int H, int W, int unnormalize, int use_graph, void* stream) {
-    return sample_impl(u, kind, n_steps, times_host, coefs_host, x_T, noise, seed, ctx, ctx_tokens, nullptr, 0, out,
-                       all_steps, B, H, W, unnormalize, use_graph, stream);
+              const float* x_T, const float* noise, uint64_t seed, uint64_t sample_offset, const float* ctx,
+              int ctx_tokens, float* out, float* all_steps, int B, int H, int W, int unnormalize, int use_graph,
+              void* stream) {
+    return sample_impl(u, kind, n_steps, times_host, coefs_host, x_T, noise, seed, sample_offset, ctx, ctx_tokens,
+                       nullptr, 0, out, all_steps, B, H, W, unnormalize, use_graph, stream);
 }
 
 int dm_sample_cond(dm_unet* u, int kind, int n_steps, const int64_t* times_host, const float* coefs_host,
-                   const float* x_T, const float* noise, uint64_t seed, const float* ctx, int ctx_tokens,
-                   const float* cond, int cond_channels, float* out, float* all_steps, int B, int H, int W,
-                   int unnormalize, int use_graph, void* stream) {
+                   const float* x_T, const float* noise, uint64_t seed, uint64_t sample_offset, const float* ctx,
+                   int ctx_tokens, const float* cond, int cond_channels, float* out, float* all_steps, int B, int H,
+                   int W, int unnormalize, int use_graph, void* stream) {
     DM_REQUIRE(cond && cond_channels > 0, "dm_sample_cond needs a condition image");
-    return sample_impl(u, kind, n_steps, times_host, coefs_host, x_T, noise, seed, ctx, ctx_tokens, cond, cond_channels,
-                       out, all_steps, B, H, W, unnormalize, use_graph, stream);
+    return sample_impl(u, kind, n_steps, times_host, coefs_host, x_T, noise, seed, sample_offset, ctx, ctx_tokens, cond,
+                       cond_channels, out, all_steps, B, H, W, unnormalize, use_graph, stream);
 }
 
-int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, void* stream) {
+int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, uint64_t element_offset, void* stream) {
     DM_REQUIRE(out && n >= 0, "bad argument");
-    return launch_randn(out, n, seed, draw, static_cast<hipStream_t>(stream));
+    return launch_randn(out, n, seed, draw, element_offset, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -149,8 +149,18 @@ int launch_norm_act(const float* x, int nsplit, int64_t split_stride, const floa
 // y[r][o] = act_out(bias[o] + sum_i act_in(x[r][i]) * W[o][i]);  act: 0 none, 1 silu, 2 gelu(erf)
 int launch_linear_rows(const float* x, int ldx, const float* W, const float* bias, float* y, int ldy, int R, int I,
                        int O, int act_in, int act_out, hipStream_t s);
-// e[r] = cat(sin(t[r]*f), cos(t[r]*f)); t int64; if step_times != nullptr t = step_times[*step]
-int launch_sinusoid(const int64_t* t, const int64_t* step_times, const int* step, const float* freqs, float* e,
+// Device-resident state of one sampling loop.  A captured denoise step reads everything that differs between two
+// sample() calls of the same shape from here, so the instantiated graph is reused across calls.
+struct SamplerState {
+    int step;            // index of the current denoise step (advanced on the device)
+    int n_steps;         // the step that also writes the final output is n_steps - 1
+    int unnormalize;     // (x + 1) / 2 on the final output
+    int pad_;
+    uint64_t seed;       // Philox key
+    uint64_t off4;       // Philox counter of this shard's first element = global element index / 4
+};
+// e[r] = cat(sin(t[r]*f), cos(t[r]*f)); t int64; if step_times != nullptr t = step_times[state->step]
+int launch_sinusoid(const int64_t* t, const int64_t* step_times, const SamplerState* state, const float* freqs, float* e,
                     int R, int half, hipStream_t s);
 // GroupNorm(32 groups) + optional swish, NHWC
 int launch_group_norm(const float* x, const float* w, const float* b, float* y, float* stats_ws, int B, int HW,
@@ -162,13 +172,15 @@ int launch_copy_channels(const float* src, float* dst, int B, int Cs, int Cd, in
 int launch_pointwise_small(const float* x, const float* w_oc, const float* bias, float* y_nchw, int64_t pixels, int C,
                            int Cout, int HW, hipStream_t s);
 
-struct StepState;  // device-resident sampler state (see dm_api.hip)
+// state_dev == nullptr: one stand-alone update (step 0 of 1, no Philox noise, no unnormalize)
 int launch_sampler_update(int kind, const float* x, const float* eps, const float* noise, const float* coefs_dev,
-                          const int* step_dev, int64_t noise_step_stride, uint64_t seed, float* out,
-                          float* all_steps, float* final_out, int unnormalize, int n_steps, int64_t n,
-                          hipStream_t s);
-int launch_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, hipStream_t s);
-int launch_step_advance(int* step_dev, hipStream_t s);
+                          const SamplerState* state_dev, int64_t noise_step_stride, float* out, float* all_steps,
+                          float* final_out, int64_t n, hipStream_t s);
+// element e of the tensor uses Philox counter ((element_offset + e) / 4, draw); element_offset % 4 == 0
+int launch_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, uint64_t element_offset, hipStream_t s);
+int launch_step_advance(SamplerState* state_dev, hipStream_t s);
+int launch_finalize(const float* x, float* out, int64_t n, int unnormalize, hipStream_t s);
+int launch_broadcast_rows(const float* src, float* dst, int rows, int n, int ld, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // Attention cores (attention.hip); qkv is NHWC (B, n, 3*heads*dh) = [q | k | v] per pixel

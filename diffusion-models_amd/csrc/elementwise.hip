@@ -240,17 +240,17 @@ int launch_linear_rows(const float* x, int ldx, const float* W, const float* bia
 // SinusoidalPosEmb.forward (DD/denoising_diffusion.py:77-84); freqs are computed on the host
 // exactly as the reference computes them (fp32) so only sin/cos run here.
 __global__ void sinusoid_kernel(const int64_t* __restrict__ t, const int64_t* __restrict__ step_times,
-                                const int* __restrict__ step, const float* __restrict__ freqs,
+                                const SamplerState* __restrict__ st, const float* __restrict__ freqs,
                                 float* __restrict__ e, int R, int half) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R * half) return;
     int r = i / half, k = i - r * half;
-    int64_t tv = step_times ? step_times[*step] : t[r];
+    int64_t tv = step_times ? step_times[st->step] : t[r];
     float a = (float)tv * freqs[k];
     e[(size_t)r * 2 * half + k] = sinf(a);
     e[(size_t)r * 2 * half + half + k] = cosf(a);
 }
-int launch_sinusoid(const int64_t* t, const int64_t* step_times, const int* step, const float* freqs, float* e,
+int launch_sinusoid(const int64_t* t, const int64_t* step_times, const SamplerState* step, const float* freqs, float* e,
                     int R, int half, hipStream_t s) {
     int n = R * half;
     hipLaunchKernelGGL(sinusoid_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, step_times, step, freqs, e, R,
@@ -339,6 +339,22 @@ int launch_copy_channels(const float* src, float* dst, int B, int Cs, int Cd, in
     const int64_t n = (int64_t)B * Cs * HW;
     hipLaunchKernelGGL(copy_channels_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, (int64_t)Cs * HW,
                        (int64_t)Cd * HW, (int64_t)c_off * HW, n);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// dst[r][0..n) = src[0..n) for r < rows (dst rows ld floats apart): the time embedding of a sampler step in front
+// of every row of the text-concat input (DD/denoising_diffusion_text_conditional.py:146-152), one launch
+__global__ void broadcast_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int ld, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t r = i / n;
+    const int c = (int)(i - r * n);
+    dst[r * ld + c] = src[c];
+}
+int launch_broadcast_rows(const float* src, float* dst, int rows, int n, int ld, hipStream_t s) {
+    const int64_t total = (int64_t)rows * n;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(broadcast_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, dst, n, ld, total);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -436,18 +452,20 @@ __device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t draw, uin
         z[2 * h + 1] = rad * sinf(ang);
     }
 }
-__global__ void randn_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t draw) {
+__global__ void randn_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t draw, uint64_t off4) {
     int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i4 * 4 >= n) return;
     float z[4];
-    philox_normal4(seed, draw, (uint64_t)i4, z);
+    philox_normal4(seed, draw, off4 + (uint64_t)i4, z);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (i4 * 4 + j < n) out[i4 * 4 + j] = z[j];
 }
-int launch_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, hipStream_t s) {
+int launch_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, uint64_t element_offset, hipStream_t s) {
+    DM_REQUIRE(element_offset % 4 == 0, "Philox element offset must be a multiple of 4 (one counter serves 4 elements)");
+    if (n == 0) return 0;
     int64_t n4 = (n + 3) / 4;
-    hipLaunchKernelGGL(randn_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, out, n, seed, draw);
+    hipLaunchKernelGGL(randn_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, out, n, seed, draw, element_offset / 4);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -461,10 +479,16 @@ int launch_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, hipStream_
 #pragma clang fp contract(off)
 __global__ void sampler_update_kernel(int kind, const float* __restrict__ x, const float* __restrict__ eps,
                                       const float* __restrict__ noise, const float* __restrict__ coefs,
-                                      const int* __restrict__ step_dev, int64_t noise_step_stride, uint64_t seed,
+                                      const SamplerState* __restrict__ st, int64_t noise_step_stride,
                                       float* __restrict__ out, float* __restrict__ all_steps,
-                                      float* __restrict__ final_out, int unnormalize, int n_steps, int64_t n) {
-    const int step = step_dev ? *step_dev : 0;
+                                      float* __restrict__ final_out, int64_t n) {
+    // everything that changes between two sample() calls of one shape is read from the device-side state, so a
+    // captured step graph stays valid across calls (seed, Philox offset, step count, unnormalize)
+    const int step = st ? st->step : 0;
+    const int n_steps = st ? st->n_steps : 1;
+    const int unnormalize = st ? st->unnormalize : 0;
+    const uint64_t seed = st ? st->seed : 0;
+    const uint64_t off4 = st ? st->off4 : 0;
     const float* c = coefs + (size_t)step * 8;
     const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4];
     const bool flag = c[5] != 0.0f;
@@ -478,7 +502,7 @@ __global__ void sampler_update_kernel(int kind, const float* __restrict__ x, con
             for (int j = 0; j < 4; ++j)
                 if (i4 * 4 + j < n) z[j] = np[i4 * 4 + j];
         } else if (c4 != 0.0f) {
-            philox_normal4(seed, (uint64_t)step + 1, (uint64_t)i4, z);
+            philox_normal4(seed, (uint64_t)step + 1, off4 + (uint64_t)i4, z);
         }
     }
 #pragma unroll
@@ -501,23 +525,34 @@ __global__ void sampler_update_kernel(int kind, const float* __restrict__ x, con
         if (final_out && step == n_steps - 1) final_out[i] = unnormalize ? (r + 1.0f) * 0.5f : r;
     }
 }
+// out = x or (x + 1) / 2: `unnormalize` at the end of a loop (DD/denoising_diffusion.py:663,:707)
+__global__ void finalize_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, int unnormalize) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float r = x[i];
+    out[i] = unnormalize ? (r + 1.0f) * 0.5f : r;
+}
 #pragma clang fp contract(fast)
 
-int launch_sampler_update(int kind, const float* x, const float* eps, const float* noise, const float* coefs_dev,
-                          const int* step_dev, int64_t noise_step_stride, uint64_t seed, float* out,
-                          float* all_steps, float* final_out, int unnormalize, int n_steps, int64_t n,
-                          hipStream_t s) {
-    int64_t n4 = (n + 3) / 4;
-    hipLaunchKernelGGL(sampler_update_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, kind, x, eps, noise,
-                       coefs_dev, step_dev, noise_step_stride, seed, out, all_steps, final_out, unnormalize,
-                       n_steps, n);
+int launch_finalize(const float* x, float* out, int64_t n, int unnormalize, hipStream_t s) {
+    hipLaunchKernelGGL(finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, out, n, unnormalize);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-__global__ void step_advance_kernel(int* step) { *step += 1; }
-int launch_step_advance(int* step_dev, hipStream_t s) {
-    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, step_dev);
+int launch_sampler_update(int kind, const float* x, const float* eps, const float* noise, const float* coefs_dev,
+                          const SamplerState* state_dev, int64_t noise_step_stride, float* out, float* all_steps,
+                          float* final_out, int64_t n, hipStream_t s) {
+    int64_t n4 = (n + 3) / 4;
+    hipLaunchKernelGGL(sampler_update_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, kind, x, eps, noise,
+                       coefs_dev, state_dev, noise_step_stride, out, all_steps, final_out, n);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void step_advance_kernel(SamplerState* st) { st->step += 1; }
+int launch_step_advance(SamplerState* state_dev, hipStream_t s) {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, state_dev);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -13,7 +13,13 @@ Reference surface mirrored (paths relative to the reference checkout):
 Extensions (keyword-only, default to the reference behaviour): ``noise`` injects
 the N(0,1) draws (a callable ``shape -> cpu tensor`` called in the reference's
 draw order, e.g. ``oracle.sampler_oracle.NoiseStream``) for parity tests;
-``seed`` selects the device Philox stream used otherwise.
+``seed`` selects the device Philox stream used otherwise (default: drawn from
+torch's global CPU generator, so ``torch.manual_seed`` makes ``sample()``
+reproducible as it does for the reference -- the noise VALUES differ from
+``torch.randn``'s, the control does not); ``sample_offset`` is the index of the
+call's first sample in a global batch sharded over ranks (``dist.sample_sharded``):
+Philox counters are global element indices, so the concatenated shards equal
+the unsharded batch bit for bit.
 """
 from __future__ import annotations
 
@@ -34,6 +40,11 @@ DDPM, DDIM = 0, 1
 
 def _identity(t, *a, **k):
     return t
+
+
+def _default_seed() -> int:
+    """A Philox key from torch's global CPU generator (reproducible under torch.manual_seed)."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
 class DenoisingDiffusion:
@@ -117,20 +128,23 @@ class DenoisingDiffusion:
         return ddim_step_table(self._sched, S, self.ddim_sampling_eta)
 
     # -- the loop --------------------------------------------------------------------------------------
-    def _randn(self, shape, seed: int, draw: int) -> torch.Tensor:
+    def _randn(self, shape, seed: int, draw: int, sample_offset: int = 0) -> torch.Tensor:
         out = torch.empty(tuple(shape), device=self.device, dtype=torch.float32)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self._lib.dm_randn(_lib.ptr(out), out.numel(), seed, draw, stream))
+        per_sample = out.numel() // max(int(shape[0]), 1)
+        _lib.check(self._lib.dm_randn(_lib.ptr(out), out.numel(), C.c_uint64(seed), C.c_uint64(draw),
+                                      C.c_uint64(int(sample_offset) * per_sample), stream))
         return out
 
     def _run(self, kind, shape, times, coefs, takes_noise: Sequence[bool], return_all_timesteps, noise, seed,
-             text_emb=None, max_steps=None, cond=None):
+             text_emb=None, max_steps=None, cond=None, sample_offset=0):
         shape = tuple(int(v) for v in shape)
         B, Cc, H, W = shape
         assert Cc == self.channels, f"shape has {Cc} channels, the model {self.channels}"
         n_steps = len(times)
         if seed is None:
-            seed = random.getrandbits(63)
+            seed = _default_seed()
+        sample_offset = int(sample_offset)
         if noise is not None:
             x_T = noise(shape).to(self.device, torch.float32).contiguous()
             rows = []
@@ -143,7 +157,7 @@ class DenoisingDiffusion:
                     rows.append(zero)
             noise_dev = torch.stack(rows, dim=0).to(self.device).contiguous()
         else:
-            x_T = self._randn(shape, seed, 0)
+            x_T = self._randn(shape, seed, 0, sample_offset)
             noise_dev = None
         if max_steps is not None:  # bounded run (bench / smoke): first `max_steps` iterations only
             n_steps = min(n_steps, int(max_steps))
@@ -162,12 +176,13 @@ class DenoisingDiffusion:
             assert cond.shape[0] == B and tuple(cond.shape[2:]) == (H, W), "batch / size mismatch between x and cond"
             _lib.check(self._lib.dm_sample_cond(
                 self.model._handle, kind, n_steps, times_arr, coefs_ptr, _lib.ptr(x_T), _lib.ptr(noise_dev),
-                C.c_uint64(seed), _lib.ptr(ctx), m, _lib.ptr(cond), int(cond.shape[1]), _lib.ptr(out),
+                C.c_uint64(seed), C.c_uint64(sample_offset), _lib.ptr(ctx), m, _lib.ptr(cond), int(cond.shape[1]),
+                _lib.ptr(out),
                 _lib.ptr(all_steps), B, H, W, self._unnormalize_flag, 1 if self.use_graph else 0, stream))
         else:
             _lib.check(self._lib.dm_sample(
                 self.model._handle, kind, n_steps, times_arr, coefs_ptr, _lib.ptr(x_T), _lib.ptr(noise_dev),
-                C.c_uint64(seed), _lib.ptr(ctx), m, _lib.ptr(out), _lib.ptr(all_steps), B, H, W,
+                C.c_uint64(seed), C.c_uint64(sample_offset), _lib.ptr(ctx), m, _lib.ptr(out), _lib.ptr(all_steps), B, H, W,
                 self._unnormalize_flag, 1 if self.use_graph else 0, stream))
         if not return_all_timesteps:
             return out
@@ -175,19 +190,22 @@ class DenoisingDiffusion:
         return self.unnormalize(ret)
 
     @torch.inference_mode()
-    def p_sample_loop(self, shape, return_all_timesteps=False, *, noise=None, seed=None, max_steps=None, text_emb=None):
+    def p_sample_loop(self, shape, return_all_timesteps=False, *, noise=None, seed=None, max_steps=None, text_emb=None,
+                      sample_offset=0):
         times, coefs = self._ddpm_tables()
         takes = [t > 0 for t in times]
-        return self._run(DDPM, shape, times, coefs, takes, return_all_timesteps, noise, seed, text_emb, max_steps)
+        return self._run(DDPM, shape, times, coefs, takes, return_all_timesteps, noise, seed, text_emb, max_steps,
+                         sample_offset=sample_offset)
 
     @torch.inference_mode()
     def ddim_sample(self, shape, sampling_timesteps=None, return_all_timesteps=False, *, noise=None, seed=None,
-                    max_steps=None, text_emb=None):
+                    max_steps=None, text_emb=None, sample_offset=0):
         if sampling_timesteps is None:
             sampling_timesteps = self.sampling_timesteps
         times, coefs = self._ddim_tables(sampling_timesteps)
         takes = [bool(c[5] != 0) for c in coefs]
-        return self._run(DDIM, shape, times, coefs, takes, return_all_timesteps, noise, seed, text_emb, max_steps)
+        return self._run(DDIM, shape, times, coefs, takes, return_all_timesteps, noise, seed, text_emb, max_steps,
+                         sample_offset=sample_offset)
 
     @torch.inference_mode()
     def sample(self, batch_size=16, return_all_timesteps=False, **kw):
@@ -195,15 +213,19 @@ class DenoisingDiffusion:
         sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
         return sample_fn((batch_size, channels, h, w), return_all_timesteps=return_all_timesteps, **kw)
 
-    @torch.inference_mode()
-    def p_sample(self, x, t: int, x_self_cond=None, *, noise=None, text_emb=None):
-        """One reverse step (denoising_diffusion.py:638-645): returns (pred_img, x_start)."""
+    def _eps(self, x, bt, **cond_kw):
+        """The U-Net call of ``model_predictions`` (:603-606); subclasses thread their condition through ``cond_kw``."""
+        return self.model(x, bt, **cond_kw)
+
+    def _p_sample(self, x, t: int, noise, cond_kw):
+        """One reverse step (denoising_diffusion.py:638-645): (pred_img, x_start); the update runs in sampler_update_kernel."""
         b = x.shape[0]
+        t = int(t)
+        x = x.to(self.device, torch.float32).contiguous()
         bt = torch.full((b,), t, device=self.device, dtype=torch.long)
-        eps = self.model(x, bt, text_emb=text_emb) if text_emb is not None else self.model(x, bt)
+        eps = self._eps(x, bt, **cond_kw)
         s = self._sched
         c0, c1 = s["sqrt_recip_alphas_cumprod"][t], s["sqrt_recipm1_alphas_cumprod"][t]
-        x = x.to(self.device, torch.float32).contiguous()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         # x_start through the DDIM form of the update kernel with the "last step" flag (returns clamp(x0))
         coef0 = (C.c_float * _lib.DM_COEFS)(float(c0), float(c1), 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
@@ -217,11 +239,17 @@ class DenoisingDiffusion:
         z = None
         if t > 0:
             z = (noise(x.shape).to(self.device, torch.float32).contiguous() if noise is not None
-                 else self._randn(x.shape, random.getrandbits(63), 1))
+                 else self._randn(x.shape, _default_seed(), 1))
         out = torch.empty_like(x)
         _lib.check(self._lib.dm_op_sampler_update(DDPM, _lib.ptr(x), _lib.ptr(eps), _lib.ptr(z), coef, _lib.ptr(out),
                                                   x.numel(), stream))
         return out, x_start
+
+    @torch.inference_mode()
+    def p_sample(self, x, t: int, x_self_cond=None, *, noise=None):
+        """:638-645.  Returns (pred_img, x_start)."""
+        assert x_self_cond is None, "self-conditioning is not on the accelerated sampling path"
+        return self._p_sample(x, t, noise, {})
 
 
 class TextConditionalDenoisingDiffusion(DenoisingDiffusion):
@@ -238,7 +266,9 @@ class TextConditionalDenoisingDiffusion(DenoisingDiffusion):
         """Random caption embeddings from the pickle the training pipeline wrote (:320-363)."""
         assert self.embedding_file is not None, "no embedding_file given; pass text_emb= to sample()"
         with open(self.embedding_file, "rb") as f:
-            table = pickle.load(f)  # the user's own precomputed file, as in the reference
+            # The caller's OWN file, written by their embedding-precompute step, exactly as the reference reads it
+            # (:331-332).  pickle executes what it loads: never point embedding_file at a file of unknown origin.
+            table = pickle.load(f)
         keys = list(table.keys())
         embs, texts = [], []
         for key in random.choices(keys, k=batch):
@@ -276,6 +306,12 @@ class TextConditionalDenoisingDiffusion(DenoisingDiffusion):
         return sample_fn((batch_size, channels, h, w), save_path_for_text, return_all_timesteps=return_all_timesteps,
                          **kw)
 
+    @torch.inference_mode()
+    def p_sample(self, x, t: int, text_emb=None, x_self_cond=None, *, noise=None):
+        """denoising_diffusion_text_conditional.py:310-317 (the reference's positional order: x, t, text_emb)."""
+        assert x_self_cond is None, "self-conditioning is not on the accelerated sampling path"
+        return self._p_sample(x, t, noise, {"text_emb": text_emb} if text_emb is not None else {})
+
 
 class ImageConditionalDenoisingDiffusion(DenoisingDiffusion):
     """``ImageConditionalDenoisingDiffusion`` (denoising_diffusion_image_conditional.py:62-229): the condition image
@@ -309,23 +345,23 @@ class ImageConditionalDenoisingDiffusion(DenoisingDiffusion):
 
     @torch.inference_mode()
     def p_sample_loop(self, shape, return_condition_image=False, return_all_timesteps=False, *, cond=None, noise=None,
-                      seed=None, max_steps=None):
+                      seed=None, max_steps=None, sample_offset=0):
         # the reference draws x_T first, then the condition (:159-163); the order only matters for its global RNG
         times, coefs = self._ddpm_tables()
         cond = self._cond(shape[0], cond)
         ret = self._run(DDPM, shape, times, coefs, [t > 0 for t in times], return_all_timesteps, noise, seed, None,
-                        max_steps, cond=cond)
+                        max_steps, cond=cond, sample_offset=sample_offset)
         return (cond, ret) if return_condition_image else ret
 
     @torch.inference_mode()
     def ddim_sample(self, shape, sampling_timesteps=None, cond=None, return_all_timesteps=False, *, noise=None,
-                    seed=None, max_steps=None):
+                    seed=None, max_steps=None, sample_offset=0):
         if sampling_timesteps is None:
             sampling_timesteps = self.sampling_timesteps
         times, coefs = self._ddim_tables(sampling_timesteps)
         cond = self._cond(shape[0], cond)
         return self._run(DDIM, shape, times, coefs, [bool(c[5] != 0) for c in coefs], return_all_timesteps, noise, seed,
-                         None, max_steps, cond=cond)
+                         None, max_steps, cond=cond, sample_offset=sample_offset)
 
     @torch.inference_mode()
     def sample(self, batch_size=16, return_condition_image=False, return_all_timesteps=False, *, cond=None, **kw):
@@ -339,18 +375,10 @@ class ImageConditionalDenoisingDiffusion(DenoisingDiffusion):
 
     @torch.inference_mode()
     def p_sample(self, x, t: int, cond=None, x_self_cond=None, *, noise=None):
-        """:114-120."""
-        inner = self.model
-
-        class _WithCond:  # the parent's p_sample calls self.model(x, bt)
-            def __call__(_, xx, tt, **kw):
-                return inner(xx, tt, cond=cond)
-
-        self.model = _WithCond()
-        try:
-            return super().p_sample(x, t, noise=noise)
-        finally:
-            self.model = inner
+        """denoising_diffusion_image_conditional.py:114-120: ``cond`` is what the U-Net sees behind x."""
+        assert x_self_cond is None, "self-conditioning is not on the accelerated sampling path"
+        assert cond is not None, "the image-conditional U-Net needs cond="
+        return self._p_sample(x, t, noise, {"cond": cond})
 
 
 class LatentDiffusion(DenoisingDiffusion):
@@ -377,6 +405,37 @@ class LatentDiffusion(DenoisingDiffusion):
         return self.decode(latents)
 
 
+class TextConditionalLatentDiffusion(TextConditionalDenoisingDiffusion):
+    """``TextConditionalLatentDiffusion`` (latent-diffusion/ldm/models/latent_diffusion_text_conditional.py:11-99): the
+    text-conditional loop on VAE latents (normalize / unnormalize are the identity, :36-37), then ``vae.decode``
+    (:78-99)."""
+
+    def __init__(self, model, vae, latent_shape, text_emb_dim=512, **kwargs):
+        super().__init__(model=model, image_size=latent_shape[1], **kwargs)
+        self.vae = vae
+        self.latent_channels = latent_shape[0]
+        self.model.channels = self.latent_channels
+        self.text_emb_dim = text_emb_dim
+        self.normalize = _identity
+        self.unnormalize = _identity
+        self._unnormalize_flag = 0
+
+    def encode(self, images):
+        latents = self.vae.encode(images)
+        return latents[0] if isinstance(latents, tuple) else latents
+
+    def decode(self, latents):
+        return self.vae.decode(latents)
+
+    @torch.inference_mode()
+    def sample(self, batch_size=16, save_path_for_text=None, return_all_timesteps=False, **kw):
+        (h, w), channels = self.image_size, self.channels
+        sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
+        latents = sample_fn((batch_size, channels, h, w), save_path_for_text,
+                            return_all_timesteps=return_all_timesteps, **kw)
+        return self.decode(latents)
+
+
 class ImageConditionalLatentDiffusion(ImageConditionalDenoisingDiffusion):
     """``ImageConditionalLatentDiffusion`` (latent-diffusion/ldm/models/latent_diffusion_image_conditional.py:16-166):
     the image-conditional loop on VAE latents.  The condition image is encoded by the (condition) VQ model and rides
@@ -385,8 +444,11 @@ class ImageConditionalLatentDiffusion(ImageConditionalDenoisingDiffusion):
     normalize / unnormalize are the identity (:43-44)."""
 
     def __init__(self, model, vae, latent_shape, init_image_size, cond_vae=None, **kwargs):
-        kwargs.setdefault("auto_normalize", False)
         super().__init__(model, image_size=tuple(latent_shape[1:]), **kwargs)
+        # latents are not images: the reference forces the identity whatever auto_normalize says (:43-44)
+        self.normalize = _identity
+        self.unnormalize = _identity
+        self._unnormalize_flag = 0
         self.vae = vae
         self.cond_vae = cond_vae if cond_vae is not None else vae
         self.init_image_size = init_image_size

@@ -47,9 +47,31 @@ def gather_shards(local: torch.Tensor, batch_size: int, group=None) -> torch.Ten
 
 def sample_sharded(sample_fn: Callable[[int, int], torch.Tensor], batch_size: int, group=None) -> torch.Tensor:
     """`sample_fn(lo, hi)` produces samples [lo, hi) of the global batch on this rank's GPU
-    (key any randomness by the GLOBAL sample index so the result does not depend on the world size)."""
+    (key any randomness by the GLOBAL sample index so the result does not depend on the world size:
+    ``diffusion.sample(batch_size=hi - lo, seed=seed, sample_offset=lo)`` does, see :func:`sample_global`)."""
     if not (dist.is_available() and dist.is_initialized()):
         return sample_fn(0, batch_size)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_bounds(batch_size, world, rank)
     return gather_shards(sample_fn(lo, hi), batch_size, group)
+
+
+def shared_seed(seed=None, group=None) -> int:
+    """One Philox key for every rank: `seed`, or a draw from rank 0's torch generator broadcast to the group."""
+    if seed is not None:
+        return int(seed)
+    t = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
+    if dist.is_available() and dist.is_initialized():
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else t.device
+        t = t.to(dev)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return int(t.item())
+
+
+def sample_global(diffusion, batch_size: int, seed=None, group=None, **sample_kw) -> torch.Tensor:
+    """``diffusion.sample(batch_size)`` with the batch sharded over the ranks of `group` and ONE all-gather at the
+    end.  Every rank draws the noise of ITS global sample indices (Philox counter = global element index), so the
+    result is the same tensor for any world size, including 1."""
+    seed = shared_seed(seed, group)
+    return sample_sharded(lambda lo, hi: diffusion.sample(batch_size=hi - lo, seed=seed, sample_offset=lo, **sample_kw),
+                          batch_size, group)

@@ -114,10 +114,14 @@ class Unet:
         return unet_param_spec(self.cfg)
 
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
-        """Accepts ``Unet.state_dict()`` of the reference (same names, OIHW / [out,in] layouts)."""
-        if self._loaded:
-            raise RuntimeError("weights were already loaded into this handle; build a new Unet")
+        """Accepts ``Unet.state_dict()`` of the reference (same names, OIHW / [out,in] layouts).
+
+        The first call packs and uploads the weights (``dm_unet_finalize``).  Later calls REFRESH them in place
+        (``dm_unet_update_param`` + ``dm_unet_refresh``): only layers whose values changed are re-packed, into the same
+        device buffers, so the workspace and the captured step graph survive -- what ``Trainer.train`` needs when it
+        samples from the EMA model after every update (denoising_diffusion.py:1190-1198)."""
         spec = dict(self.param_spec())
+        set_param = self._lib.dm_unet_update_param if self._loaded else self._lib.dm_unet_set_param
         unexpected = [k for k in state_dict if k not in spec]
         missing = [k for k in spec if k not in state_dict]
         if strict and (unexpected or missing):
@@ -129,10 +133,18 @@ class Unet:
             if tuple(t.shape) != tuple(shape):
                 raise RuntimeError(f"size mismatch for {name}: {tuple(t.shape)} vs {tuple(shape)}")
             shp = (C.c_int64 * t.dim())(*t.shape)
-            _lib.check(self._lib.dm_unet_set_param(self._handle, name.encode(), t.data_ptr(), shp, t.dim()))
-        _lib.check(self._lib.dm_unet_finalize(self._handle))
+            _lib.check(set_param(self._handle, name.encode(), t.data_ptr(), shp, t.dim()))
+        if self._loaded:
+            _lib.check(self._lib.dm_unet_refresh(self._handle))
+        else:
+            _lib.check(self._lib.dm_unet_finalize(self._handle))
         self._loaded = True
         return self
+
+    @property
+    def graph_captures(self) -> int:
+        """How many times a denoise-step graph was captured on this handle (one per sampled shape)."""
+        return int(self._lib.dm_unet_graph_captures(self._handle))
 
     # -- forward ---------------------------------------------------------------------------
     def _ctx(self, text_emb: Optional[torch.Tensor], batch: int):

@@ -74,6 +74,17 @@ int dm_unet_missing_params(dm_unet* u);
 /* repack weights into kernel layouts and upload; must follow the last set_param */
 int dm_unet_finalize(dm_unet* u);
 
+/* In-place weight refresh for the caller of record: Trainer.train samples from `self.ema.ema_model` after every EMA
+ * update (DD/denoising_diffusion.py:1190,1198,1216), i.e. the same architecture with new values each time.
+ * dm_unet_update_param replaces the host copy of one parameter of a FINALIZED handle (same name / shape rules as
+ * dm_unet_set_param; unchanged values are detected and cost nothing); dm_unet_refresh then re-packs the layers whose
+ * parameters changed into the SAME device buffers (no reallocation: workspace, captured step graph and every device
+ * pointer stay valid).  The call synchronises the device. */
+int dm_unet_update_param(dm_unet* u, const char* name, const float* data_host, const int64_t* shape, int ndim);
+int dm_unet_refresh(dm_unet* u);
+/* how many times a denoise-step graph has been captured on this handle (diagnostics / tests: one per shape) */
+int dm_unet_graph_captures(dm_unet* u);
+
 /* Unet.forward(x, time, x_self_cond=None) DD/denoising_diffusion.py:349-390 and the
  * text variant forward(x, time, text_emb) DD/denoising_diffusion_text_conditional.py:131-214.
  *   x      (B, input_channels, H, W)   time (B,) int64 device   ctx (B, ctx_tokens, text_emb_dim) or NULL
@@ -97,31 +108,39 @@ int dm_unet_forward(dm_unet* u, const float* x, const int64_t* time, const float
  *   x_T        (B,C,H,W) start noise (draw #0 of the reference)
  *   noise      NULL -> device Philox noise from `seed`; else (n_steps, B,C,H,W) injected noise,
  *              row i used by step i (rows of steps that take no noise are ignored)
+ *   sample_offset  index of this call's first sample in the GLOBAL batch (0 for an unsharded call).  Philox
+ *              counters are the global element index, (sample_offset*C*H*W + e) / 4, so a batch sharded over ranks
+ *               draws exactly the noise the unsharded batch draws: cat(shards) == whole, bit for bit.
+ *              Generate x_T with dm_randn(..., draw 0, element_offset = sample_offset*C*H*W) for the same property.
  *   out        (B,C,H,W); (x+1)/2 applied when unnormalize != 0 (:663,:707)
  *   all_steps  NULL, or (n_steps+1, B,C,H,W) receiving x_T and every iterate
  *              (return_all_timesteps; the caller permutes to (B, n_steps+1, ...))
- *   use_graph  capture one denoise step into a hipGraph and replay it n_steps times
+ *   use_graph  replay one denoise step as a hipGraph n_steps times.  The instantiated graph is cached on the handle
+ *              and reused by later calls of the same (kind, B, H, W, ctx_tokens, cond_channels); seed, offset, step
+ *              tables, x_T, ctx and cond are device data or copied into handle-owned buffers, not captured arguments.
  */
 #define DM_COEFS 8
 #define DM_SAMPLER_DDPM 0
 #define DM_SAMPLER_DDIM 1
 
 int dm_sample(dm_unet* u, int kind, int n_steps, const int64_t* times_host, const float* coefs_host,
-              const float* x_T, const float* noise, uint64_t seed, const float* ctx, int ctx_tokens,
-              float* out, float* all_steps, int B, int H, int W, int unnormalize, int use_graph, void* stream);
+              const float* x_T, const float* noise, uint64_t seed, uint64_t sample_offset, const float* ctx,
+              int ctx_tokens, float* out, float* all_steps, int B, int H, int W, int unnormalize, int use_graph,
+              void* stream);
 
 /* The same loop for the image-conditional variant (replaces ImageConditionalDenoisingDiffusion.p_sample_loop /
  * ddim_sample, DD/denoising_diffusion_image_conditional.py:156-224; its Unet.forward concatenates `cond` behind x in
  * front of init_conv, :51-55).  cond is (B, cond_channels, H, W) fp32 on the device, constant over the loop; the
  * handle must have input_channels == channels + cond_channels. */
 int dm_sample_cond(dm_unet* u, int kind, int n_steps, const int64_t* times_host, const float* coefs_host,
-                   const float* x_T, const float* noise, uint64_t seed, const float* ctx, int ctx_tokens,
-                   const float* cond, int cond_channels, float* out, float* all_steps, int B, int H, int W,
-                   int unnormalize, int use_graph, void* stream);
+                   const float* x_T, const float* noise, uint64_t seed, uint64_t sample_offset, const float* ctx,
+                   int ctx_tokens, const float* cond, int cond_channels, float* out, float* all_steps, int B, int H,
+                   int W, int unnormalize, int use_graph, void* stream);
 
 /* N(0,1) noise from the library's Philox4x32-10 stream (what dm_sample uses when noise == NULL);
- * element e of the tensor of draw `draw` uses counter (e/4, draw) under key `seed`. */
-int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, void* stream);
+ * element e of the tensor of draw `draw` uses counter ((element_offset + e)/4, draw) under key `seed`
+ * (element_offset % 4 == 0; draw 0 = x_T, draw i+1 = the noise of loop step i). */
+int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, uint64_t element_offset, void* stream);
 
 /* ---- VAE decode (replaces VQModel.decode, LD/models/autoencoder.py:113-116 ->
  *      Decoder.forward LD/modules/diffusionmodules/model.py:552-585) ----------------------- */

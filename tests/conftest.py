@@ -66,3 +66,9 @@ def golden_encoder():
     """VAE Encoder outputs of the reference (tests/golden/make_golden_encoder.py)."""
     return load_golden("encoder.pt")
 
+
+
+@pytest.fixture(scope="session")
+def golden_configs():
+    """BASELINE configs 3 / 4 / 5 as workloads, from the reference (tests/golden/make_golden_configs.py)."""
+    return load_golden("configs.pt")

@@ -233,11 +233,18 @@ def test_philox_noise_statistics_and_determinism():
     n = 1 << 22
     a = torch.empty(n, device=DEV)
     b = torch.empty(n, device=DEV)
-    _lib.check(lib.dm_randn(_lib.ptr(a), n, 1234, 0, None))
-    _lib.check(lib.dm_randn(_lib.ptr(b), n, 1234, 0, None))
+    _lib.check(lib.dm_randn(_lib.ptr(a), n, 1234, 0, 0, None))
+    _lib.check(lib.dm_randn(_lib.ptr(b), n, 1234, 0, 0, None))
     torch.cuda.synchronize()
     assert torch.equal(a, b)
-    _lib.check(lib.dm_randn(_lib.ptr(b), n, 1234, 1, None))
+    # element offset: the tail of the stream generated on its own equals the tail of the whole stream
+    off = 12 * 1024 + 4
+    _lib.check(lib.dm_randn(_lib.ptr(b), n - off, 1234, 0, off, None))
+    torch.cuda.synchronize()
+    assert torch.equal(b[: n - off], a[off:])
+    with pytest.raises(RuntimeError):
+        _lib.check(lib.dm_randn(_lib.ptr(b), 16, 1234, 0, 3, None))  # offsets are multiples of 4
+    _lib.check(lib.dm_randn(_lib.ptr(b), n, 1234, 1, 0, None))
     torch.cuda.synchronize()
     a, b = a.cpu().double(), b.cpu().double()
     assert abs(a.mean()) < 3e-3 and abs(a.std() - 1) < 3e-3

@@ -244,3 +244,51 @@ def test_vae_encoder(golden_encoder):
         assert torch.allclose(d.gather(1, idx[:, None]).squeeze(1), d.min(dim=1).values, rtol=1e-5, atol=1e-6)
         assert rel_l2(zq.permute(0, 2, 3, 1).reshape(-1, cfg.embed_dim), e[idx]) < 1e-6
 
+
+
+CFG4_DEC = DecoderConfig(ch=64, ch_mult=(1, 2), num_res_blocks=2, attn_resolutions=(), resolution=64, z_channels=4,
+                         embed_dim=4)
+CFG4_ENC = EncoderConfig(ch=64, ch_mult=(1, 2), num_res_blocks=2, attn_resolutions=(), resolution=64, z_channels=4,
+                         embed_dim=4, n_embed=256)
+
+
+def test_config3_64x64_loop(golden_configs):
+    """BASELINE config 3: the full U-Net at 64x64 through the reference's p_sample_loop (50-step schedule)."""
+    cfg = UnetConfig()
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=0)
+    b = golden_configs["unet_full_64_b2"]
+    assert rel_l2(uo.unet_forward(sd, cfg, b["x"], b["t"]), b["y"]) < TOL
+    b = golden_configs["full64_ddpm50"]
+    y = so.p_sample_loop(lambda x, t: uo.unet_forward(sd, cfg, x, t), dm.make_schedule(b["T"], "linear"), b["shape"],
+                         so.NoiseStream(b["seed"]))
+    assert rel_l2(y, b["y"]) < 1e-4
+
+
+def test_config4_latent_loop_and_decode(golden_configs):
+    """BASELINE config 4: Unet(channels=4) DDIM on 4x32x32 latents + VQModel.decode at resolution 64, against the
+    reference's LatentDiffusion.sample (identity unnormalize, latent_diffusion.py:25-26,59-66)."""
+    vsd = dm.synth_state_dict(encoder_param_spec(CFG4_ENC) + dm.decoder_param_spec(CFG4_DEC), salt=14)
+    b = golden_configs["decode_cfg4"]
+    assert rel_l2(vo.vq_decode(vsd, CFG4_DEC, b["z"]), b["y"]) < TOL
+    cfg = UnetConfig(channels=4)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=0)
+    model = lambda x, t: uo.unet_forward(sd, cfg, x, t)  # noqa: E731
+    sched = dm.make_schedule(1000, "linear")
+    b = golden_configs["latent4_ddim6"]
+    lat = so.ddim_sample(model, sched, b["shape"], so.NoiseStream(b["seed"]), b["S"], unnormalize=False)
+    assert rel_l2(lat, b["y"]) < 1e-4
+    b = golden_configs["ldm_cfg4_ddim6"]
+    lat = so.ddim_sample(model, sched, (b["B"], 4, 32, 32), so.NoiseStream(b["seed"]), b["S"], unnormalize=False)
+    assert rel_l2(vo.vq_decode(vsd, CFG4_DEC, lat), b["y"]) < 1e-4
+
+
+def test_config5_text_64x64(golden_configs):
+    """BASELINE config 5: full-width text / cross-attention U-Net at 64x64, forward and the reference's DDIM loop."""
+    cfg = UnetConfig(text_condition=True, use_cross_attn=True)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=0)
+    b = golden_configs["unet_text_full_64"]
+    assert rel_l2(uo.unet_forward(sd, cfg, b["x"], b["t"], text_emb=b["ctx"]), b["y"]) < TOL
+    b = golden_configs["text64_ddim4"]
+    model = lambda x, t: uo.unet_forward(sd, cfg, x, t, text_emb=b["ctx"])  # noqa: E731
+    y = so.ddim_sample(model, dm.make_schedule(1000, "linear"), b["shape"], so.NoiseStream(b["seed"]), b["S"])
+    assert rel_l2(y, b["y"]) < 1e-4

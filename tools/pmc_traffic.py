@@ -10,9 +10,12 @@ coalesced reads, so it is doubled (the guide's correction); WRITE_SIZE is exact 
 import csv
 import glob
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(directory, counter):
@@ -35,7 +38,9 @@ def main():
     fdir, wdir = sys.argv[1], sys.argv[2]
     ft, fc = per_kernel(fdir, "FETCH_SIZE")
     wt, wc = per_kernel(wdir, "WRITE_SIZE")
-    out = {}
+    from bench import csrc_sha  # the kernel sources these counters were collected on (bench.py refuses another hash)
+
+    out = {"_csrc_sha": csrc_sha()}
     for k in sorted(ft):
         raw_kb = ft[k] / fc[k]
         out[k] = {
