@@ -233,16 +233,17 @@ def test_sharded_seeded_sampling_equals_unsharded_bitwise(full):
     """Philox counters are GLOBAL element indices: shards [0,4) and [4,8) of one seed concatenate to the unsharded batch,
     bit for bit, in production mode (no injected noise) -- SURVEY.md 8(e)."""
     u, _ = full
-    for d in (dm.DenoisingDiffusion(u, image_size=32, timesteps=1000, sampling_timesteps=5, ddim_sampling_eta=0.7),
-              dm.DenoisingDiffusion(u, image_size=32, timesteps=6)):
-        whole = d.sample(batch_size=8, seed=1234)
-        lo = d.sample(batch_size=4, seed=1234, sample_offset=0)
-        hi = d.sample(batch_size=4, seed=1234, sample_offset=4)
+    for d, kw in ((dm.DenoisingDiffusion(u, image_size=32, timesteps=1000, sampling_timesteps=5, ddim_sampling_eta=0.7), {}),
+                  (dm.DenoisingDiffusion(u, image_size=32, timesteps=1000), dict(max_steps=5))):
+        whole = d.sample(batch_size=8, seed=1234, **kw)
+        assert torch.isfinite(whole).all()
+        lo = d.sample(batch_size=4, seed=1234, sample_offset=0, **kw)
+        hi = d.sample(batch_size=4, seed=1234, sample_offset=4, **kw)
         assert torch.equal(torch.cat((lo, hi)), whole)
         assert not torch.equal(lo, hi)
-        r0 = d.sample(batch_size=3, seed=1234, sample_offset=0)
-        r1 = d.sample(batch_size=3, seed=1234, sample_offset=3)
-        r2 = d.sample(batch_size=2, seed=1234, sample_offset=6)  # ragged 3-way split
+        r0 = d.sample(batch_size=3, seed=1234, sample_offset=0, **kw)
+        r1 = d.sample(batch_size=3, seed=1234, sample_offset=3, **kw)
+        r2 = d.sample(batch_size=2, seed=1234, sample_offset=6, **kw)  # ragged 3-way split
         assert torch.equal(torch.cat((r0, r1, r2)), whole)
 
 
