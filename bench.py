@@ -265,9 +265,9 @@ def main():
         kern = []
         for r in rows:
             avg_ms = r["total_ms"] / r["launches"]
-            # the Winograd F(2x2,3x3) kernel multiplies 16 instead of 36 times per (2x2 outputs, cin, cout): its own
-            # matrix work is 16/36 of the direct convolution's FLOP count that the rows are priced in
-            executed = 16.0 / 36.0 if r["kernel"].startswith("wino") else 1.0
+            # the rows are priced as the reference's direct convolution; a Winograd kernel's own matrix work is a fraction
+            # of that count: F(4x4,3x3) multiplies 36 times per 4x4 outputs (36/144), F(2x2,3x3) 16 times per 2x2 (16/36)
+            executed = 0.25 if r["kernel"].startswith("wino4") else (16.0 / 36.0 if r["kernel"].startswith("wino") else 1.0)
             tf_direct = r["total_flops"] / (r["total_ms"] * 1e-3) / 1e12
             kern.append({"kernel": r["kernel"], "launches_per_unet_fwd": r["launches"] // 4,
                          "avg_ms": avg_ms, "mfma_tflops": tf_direct * executed,
@@ -293,8 +293,8 @@ def main():
             "timing": "HIP events on the launch stream around every launch of an eager run behind a parked GPU, minus the "
                       "calibrated interval of an empty-kernel bracket (dispatch + event packets, ~9 us): kernel "
                       "execution time, comparable with rocprofv3 --kernel-trace",
-            "note": "achieved = f32-MFMA FLOPs the kernel executes per launch (Winograd F(2x2,3x3): 2*16*Cin*Cout per 2x2 "
-                    "output pixels) / its average launch time; frac = achieved / f32 MFMA peak.  algorithmic_equiv prices "
+            "note": "achieved = f32-MFMA FLOPs the kernel executes per launch (Winograd F(4x4,3x3): 2*36*Cin*Cout per 4x4 "
+                    "output pixels; F(2x2,3x3): 2*16 per 2x2) / its average launch time; frac = achieved / f32 MFMA peak.  algorithmic_equiv prices "
                     "the same launches as the reference's direct 3x3 convolution (2*9*Cin*Cout per pixel, SURVEY 8(d)) "
                     "and can exceed the peak; it is not a roofline fraction",
         }

@@ -221,12 +221,14 @@ __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpi
                 ssv[j] = t;
             }
         }
-        // 1 / max(||v||, 1e-12) as one v_rsq_f32 (1 ulp)
+        // 1 / max(||v||, 1e-12) as one v_rsq_f32 (1 ulp).  The consumer of a transcendental's result is plain C++,
+        // never inline asm: gfx950 needs a wait state between v_rsq / v_exp / v_rcp and the VALU instruction that reads
+        // the result, which the compiler inserts for its own instructions but not for asm operands (stale high halves).
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const float rn = fast_rsq(fmaxf(ssv[j], 1e-24f));
-            const f32x2 rn2 = {rn, rn};
-            v[j] = join4(pk_mul(pk_mul(v[j].xy, rn2), g4.xy), pk_mul(pk_mul(v[j].zw, rn2), g4.zw));
+            const f32x4 gr = g4 * rn;
+            v[j] = join4(pk_mul(v[j].xy, gr.xy), pk_mul(v[j].zw, gr.zw));
         }
     }
     if (epi & EPI_SCALE_SHIFT) {
@@ -247,17 +249,16 @@ __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpi
     }
     if (epi & EPI_SILU) {
         // x * 1 / (1 + 2^(-x log2 e)): the same instructions __expf / the reciprocal lower to, packed where possible
-        const f32x2 nl2e = {-1.4426950408889634f, -1.4426950408889634f}, one2 = {1.0f, 1.0f};
+        // (the additions and the final multiply read transcendental results: plain C++, see the note at the norm)
+        const f32x2 nl2e = {-1.4426950408889634f, -1.4426950408889634f};
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            f32x2 t0 = pk_mul(v[j].xy, nl2e), t1 = pk_mul(v[j].zw, nl2e);
-            t0 = f32x2{__builtin_amdgcn_exp2f(t0.x), __builtin_amdgcn_exp2f(t0.y)};
-            t1 = f32x2{__builtin_amdgcn_exp2f(t1.x), __builtin_amdgcn_exp2f(t1.y)};
-            t0 = pk_add(t0, one2);
-            t1 = pk_add(t1, one2);
-            t0 = f32x2{fast_rcp(t0.x), fast_rcp(t0.y)};
-            t1 = f32x2{fast_rcp(t1.x), fast_rcp(t1.y)};
-            v[j] = join4(pk_mul(v[j].xy, t0), pk_mul(v[j].zw, t1));
+            const f32x2 t0 = pk_mul(v[j].xy, nl2e), t1 = pk_mul(v[j].zw, nl2e);
+            f32x4 e4 = make_f32x4(__builtin_amdgcn_exp2f(t0.x), __builtin_amdgcn_exp2f(t0.y),
+                                  __builtin_amdgcn_exp2f(t1.x), __builtin_amdgcn_exp2f(t1.y));
+            e4 = e4 + 1.0f;
+            const f32x4 r4 = make_f32x4(fast_rcp(e4.x), fast_rcp(e4.y), fast_rcp(e4.z), fast_rcp(e4.w));
+            v[j] = v[j] * r4;
         }
     }
     const gfloat_mptr op = (gfloat_mptr)p.out;

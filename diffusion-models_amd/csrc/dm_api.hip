@@ -129,6 +129,7 @@ struct ConvLayer {
     int fold_w_stride = 0;
     float* w = nullptr;
     float* ww = nullptr;  // Winograd-transformed weights (winograd_mfma.hip) when the layer is eligible
+    float* ww4 = nullptr;  // F(4x4,3x3) transformed weights (wino4_mfma.hip)
     float* wraw = nullptr;  // (Cout, Cin) weights of a 1x1 conv with Cout <= 4 (pointwise_small_kernel)
     float* bias = nullptr;
 };
@@ -318,6 +319,12 @@ static int make_conv(DeviceOwner& own, ConvLayer& L, const float* oihw, const fl
         std::vector<float> wp(wino_packed_floats(Cout, C0, C1));
         wino_pack_weights(oihw, wp.data(), Cout, C0, C1);
         if (own.upload(wp.data(), wp.size(), &L.ww)) return 1;
+    }
+    L.ww4 = nullptr;
+    if (wino4_eligible(Cout, C0, C1, KH, KW, stride, pad, up)) {
+        std::vector<float> wp(wino4_packed_floats(Cout, C0, C1));
+        wino4_pack_weights(oihw, wp.data(), Cout, C0, C1);
+        if (own.upload(wp.data(), wp.size(), &L.ww4)) return 1;
     }
     L.wraw = nullptr;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && !up && Cout <= 4 && C1 == 0 && C0 % 4 == 0 &&
@@ -638,27 +645,36 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
         return launch_pointwise_small(in0, L.wraw, L.bias, out, (int64_t)c.B * p.Ho * p.Wo, L.C0, L.Cout, p.Ho * p.Wo,
                                       c.s);
     }
-    // 3x3 / stride 1 convolutions run as Winograd F(2x2,3x3) when the layer has transformed weights
-    const bool wino = L.ww && !L.fold && !in_nchw && !out_nchw && wino_use(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
-    if (wino) {
+    // 3x3 / stride 1 convolutions run as Winograd F(4x4,3x3) on power-of-two images, else as F(2x2,3x3), when the layer
+    // has transformed weights
+    const bool wino4 = L.ww4 && !L.fold && !in_nchw && !out_nchw && wino4_shape_ok(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
+    const bool wino = !wino4 && L.ww && !L.fold && !in_nchw && !out_nchw &&
+                      wino_use(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
+    if (wino4) {
+        p.w = L.ww4;
+        p.chunks0 = L.C0 / 8;
+        p.n_chunks = (L.C0 + L.C1) / 8;
+        p.geo = wino4_plan(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1, true);
+    } else if (wino) {
         p.w = L.ww;
         p.chunks0 = L.C0 / 8;
         p.n_chunks = (L.C0 + L.C1) / 8;
         p.geo = wino_plan(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1, true);
     }
+    auto launch = [&](const ConvParams& q) { return wino4 ? wino4_launch(q, c.s) : (wino ? wino_launch(q, c.s) : conv_launch(q, c.s)); };
     const int full_epi = epi | (L.bias ? EPI_BIAS : 0);
     const bool in_kernel = p.geo.splits == 1 && (!want_norm || p.geo.fused_norm);
     if (in_kernel) {
         if (c.dry()) return 0;
         p.out = out; p.partial = 0; p.epi = full_epi;
-        return wino ? wino_launch(p, c.s) : conv_launch(p, c.s);
+        return launch(p);
     }
     DM_REQUIRE(!out_nchw, "split / unfused epilogue writes NHWC");
     const size_t M = (size_t)c.B * out_h * out_w;
     float* part = c.A->alloc((size_t)p.geo.splits * M * L.Cout);
     if (c.dry()) return 0;
     p.out = part; p.partial = 1; p.epi = 0;
-    if (wino ? wino_launch(p, c.s) : conv_launch(p, c.s)) return 1;
+    if (launch(p)) return 1;
     return launch_norm_act(part, p.geo.splits, (int64_t)(M * L.Cout), L.bias, g, scale, c.ss_stride, out_h * out_w,
                            residual, out, (int64_t)M, L.Cout, full_epi, c.s);
 }

@@ -125,6 +125,18 @@ bool wino_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1);
 int wino_launch(const ConvParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
+// Winograd F(4x4, 3x3) convolution (wino4_mfma.hip): same contract as wino_launch, 2.25 instead of 4 multiplies per
+// output; images of 4x4, 8x8, 16x16 or (16k x 32m) pixels.  ConvGeom TW/TH/NB count 4x4-pixel tiles (32 per workgroup).
+// ---------------------------------------------------------------------------------------
+bool wino4_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up);
+size_t wino4_packed_floats(int Cout, int C0, int C1);
+// OIHW (Cout, C0+C1, 3, 3) -> U = G g G^T (6x6) in kernel layout [chunk of 8 cin][wave 4][slot 9][Cout][8]
+void wino4_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1);
+ConvGeom wino4_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_split);
+bool wino4_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1);
+int wino4_launch(const ConvParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
 // Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
 // Off by default; never enabled while a graph is being captured.
 // ---------------------------------------------------------------------------------------
