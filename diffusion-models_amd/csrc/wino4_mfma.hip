@@ -252,21 +252,9 @@ __global__ __launch_bounds__(256, 1) void wino4_mfma_kernel(const ConvParams p) 
     const int cb = split * g.chunks_per_split;
     const int ce = min(cb + g.chunks_per_split, p.n_chunks);
     float* raw[2] = {smem, smem + BUF};
+    DM_STAMP_DECL
+    DM_STAMP(0);
     constexpr int SCRATCH = 2 * BUF;  // floats from the buffer base: items outside the image land here (either buffer)
-
-    // ---- zero both window buffers once (padding pixels stay zero), build the output-pixel table
-    {
-        const f32x4 z4 = make_f32x4(0.f, 0.f, 0.f, 0.f);
-        for (int i = tid; i < 2 * BUF / 4; i += 256) *reinterpret_cast<f32x4*>(smem + 4 * i) = z4;
-        int* ptab = reinterpret_cast<int*>(smem + g.ptab_off);
-        {
-            const int i = tid;  // 16 tiles x 16 pixels
-            const int t = i >> 4, beta = (i >> 2) & 3, alpha = i & 3;
-            const int tx = t & (TW - 1), ty = (t >> LTW) & (TH - 1), nb = t >> (2 * LTW);
-            const int b = b0 + nb, y = 4 * (ty0 + ty) + alpha, x = 4 * (tx0 + tx) + beta;
-            ptab[i] = (b < p.B && y < p.Ho && x < p.Wo) ? (b * p.Ho + y) * p.Wo + x : -1;
-        }
-    }
 
     // ---- window staging: item = (pixel of the load region, channel quad)
     int hpix[HR], hoff[HR];
@@ -376,11 +364,10 @@ __global__ __launch_bounds__(256, 1) void wino4_mfma_kernel(const ConvParams p) 
     using I3 = std::integral_constant<int, 3>;
     using I4 = std::integral_constant<int, 4>;
 
-    __syncthreads();  // zero fill done
-    // ---- prologue: chunks cb and cb + 1 -> LDS, weights of chunk cb -> registers, operands of chunk cb -> registers
+    // ---- prologue: request chunks cb and cb + 1 and the weights of chunk cb first, do the LDS housekeeping while they fly
+    f32x4 h2[HR];
     {
         const bool two = cb + 1 < ce;
-        f32x4 h2[HR];
         window_offsets(cb >= p.chunks0 ? p.C1 : p.C0);
 #pragma unroll
         for (int i = 0; i < HR; ++i) hreg[i] = window_value(cb, i);
@@ -390,12 +377,29 @@ __global__ __launch_bounds__(256, 1) void wino4_mfma_kernel(const ConvParams p) 
         for (int i = 0; i < HR; ++i) h2[i] = window_value(c1, i);
 #pragma unroll
         for (int k = 0; k < 9; ++k) load_u(cb, k);
-#pragma unroll
-        for (int i = 0; i < HR; ++i) *reinterpret_cast<f32x4*>(raw[0] + hoff[i]) = hreg[i];
-#pragma unroll
-        for (int i = 0; i < HR; ++i) *reinterpret_cast<f32x4*>(raw[1] + hoff[i]) = h2[i];
     }
+    // zero both window buffers once (padding pixels stay zero), build the output-pixel table
+    {
+        const f32x4 z4 = make_f32x4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < 2 * BUF / 4; i += 256) *reinterpret_cast<f32x4*>(smem + 4 * i) = z4;
+        int* ptab = reinterpret_cast<int*>(smem + g.ptab_off);
+        {
+            const int i = tid;  // 16 tiles x 16 pixels
+            const int t = i >> 4, beta = (i >> 2) & 3, alpha = i & 3;
+            const int tx = t & (TW - 1), ty = (t >> LTW) & (TH - 1), nb = t >> (2 * LTW);
+            const int b = b0 + nb, y = 4 * (ty0 + ty) + alpha, x = 4 * (tx0 + tx) + beta;
+            ptab[i] = (b < p.B && y < p.Ho && x < p.Wo) ? (b * p.Ho + y) * p.Wo + x : -1;
+        }
+    }
+
+    __syncthreads();  // zero fill done
+    DM_STAMP_ADD(0)
+#pragma unroll
+    for (int i = 0; i < HR; ++i) *reinterpret_cast<f32x4*>(raw[0] + hoff[i]) = hreg[i];
+#pragma unroll
+    for (int i = 0; i < HR; ++i) *reinterpret_cast<f32x4*>(raw[1] + hoff[i]) = h2[i];
     __syncthreads();
+    DM_STAMP_ADD(1)
     {
         f32x2 d[5];
         row_stage_read(I0{}, I0{}, d); row_stage_math(0, d);
@@ -407,6 +411,7 @@ __global__ __launch_bounds__(256, 1) void wino4_mfma_kernel(const ConvParams p) 
         for (int a = 0; a < 3; ++a) col_stage(a);
     }
     __syncthreads();  // buffer 0 is overwritten with chunk cb + 2 by the first iteration
+    DM_STAMP_ADD(2)
 
     // ---- main loop: 72 MFMAs per chunk and wave; everything else rides in the hooks between them
     const f32x4 zero4 = make_f32x4(0.f, 0.f, 0.f, 0.f);
@@ -468,6 +473,7 @@ __global__ __launch_bounds__(256, 1) void wino4_mfma_kernel(const ConvParams p) 
         if (c < ce) chunk_body(c, std::false_type{}, P1{});
     }
 
+    DM_STAMP_ADD(3)
     // ---- epilogue.  Per wave and row type a: p = M[a][plus] + M[a][minus], m = M[a][plus] - M[a][minus] (in place), then
     // for every output column beta:  R_a[beta] = c1[beta] * (beta even ? p : m) + cP[beta] * M[a][P]   (column half CT)
     //   low half (columns 0,1,2):  c1 = 1, 1, 1, 1   cP = 1, 0, 0, 0      high half (columns 5,3,4):  c1 = 1, 2, 4, 8   cP = 0, 0, 0, 1
@@ -540,6 +546,7 @@ __global__ __launch_bounds__(256, 1) void wino4_mfma_kernel(const ConvParams p) 
                 }
         }
         __syncthreads();
+        DM_STAMP_ADD(4)
         // X_i = sum over the two column halves; i = 0 (lo, P), 1 (lo, +), 2 (lo, -), 3 (hi, +), 4 (hi, -), 5 (hi, P)
         f32x4 v[8];
 #pragma unroll
@@ -557,11 +564,15 @@ __global__ __launch_bounds__(256, 1) void wino4_mfma_kernel(const ConvParams p) 
             v[4 * bb + 2] = fma4(s34, four, s12);
             v[4 * bb + 3] = add4(fma4(d34, eight, d12), x5);
         }
+        DM_STAMP_ADD(5)
         rows_epilogue<1, 8, true>(p, re, v, pixv[h], cg, cvalid, pf[h]);
+        DM_STAMP_ADD(6)
     };
     beta_pair(I0{});
     __syncthreads();
+    DM_STAMP_ADD(7)
     beta_pair(I1{});
+    DM_STAMP_FLUSH
 }
 
 template <int LTW>
@@ -572,6 +583,30 @@ static int wino4_launch_t(const ConvParams& p, int blocks, hipStream_t s) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+#ifdef DM_STAMPS
+    // diagnostic build: run the launch synchronously with a stamp buffer and print the phase averages
+    {
+        const size_t nblk = (size_t)blocks * p.geo.splits;
+        unsigned long long* dbuf = nullptr;
+        DM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), nblk * 8 * sizeof(unsigned long long)));
+        DM_CHECK_HIP(hipMemsetAsync(dbuf, 0, nblk * 8 * sizeof(unsigned long long), s));
+        ConvParams ps = p;
+        ps.stamps = dbuf;
+        hipLaunchKernelGGL(wino4_mfma_kernel<LTW>, dim3(blocks, p.geo.splits, 1), dim3(256), p.geo.lds_bytes, s, ps);
+        DM_CHECK_HIP(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h(nblk * 8);
+        DM_CHECK_HIP(hipMemcpy(h.data(), dbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        (void)hipFree(dbuf);
+        double avg[8] = {0};
+        for (size_t b = 0; b < nblk; ++b)
+            for (int k = 0; k < 8; ++k) avg[k] += (double)h[b * 8 + k] / nblk;
+        fprintf(stderr, "STAMPS wino4<%d> %d+%d->%d @%dx%d e%d k%d chunks %d: wgs=%zu | setup %.0f loads->lds %.0f "
+                        "transform0 %.0f loop %.0f (%.0f/chunk) stage1+bar %.0f final %.0f rows_epi %.0f midbar %.0f\n",
+                LTW, p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.epi, p.geo.splits, p.geo.chunks_per_split, nblk, avg[0], avg[1],
+                avg[2], avg[3], avg[3] / p.geo.chunks_per_split, avg[4], avg[5], avg[6], avg[7]);
+        return 0;
+    }
+#endif
     hipLaunchKernelGGL(wino4_mfma_kernel<LTW>, dim3(blocks, p.geo.splits, 1), dim3(256), p.geo.lds_bytes, s, p);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
