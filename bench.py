@@ -247,6 +247,7 @@ def main():
             "global_batch": B_global,
             "hip_graph": not args.no_graph,
             "graph_captures": unet.graph_captures,
+            "workspace_MB": round(unet.workspace_bytes / 2 ** 20, 1),
             "parallelism": f"batch-shard x{world}, one all-gather per sample()",
         },
         "denoise_image_steps_per_s": value * S,

@@ -20,7 +20,7 @@ ABI_VERSION = 2
 EXPORTS = (
     "dm_last_error", "dm_abi_version",
     "dm_unet_create", "dm_unet_destroy", "dm_unet_set_param", "dm_unet_missing_params", "dm_unet_finalize",
-    "dm_unet_update_param", "dm_unet_refresh", "dm_unet_graph_captures",
+    "dm_unet_update_param", "dm_unet_refresh", "dm_unet_graph_captures", "dm_unet_workspace_bytes",
     "dm_unet_forward", "dm_sample", "dm_sample_cond", "dm_randn",
     "dm_decoder_create", "dm_decoder_destroy", "dm_decoder_set_param", "dm_decoder_missing_params",
     "dm_decoder_finalize", "dm_decoder_forward",
@@ -82,6 +82,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_unet_update_param.argtypes = [vp, C.c_char_p, fp, C.POINTER(i64), i32]
     lib.dm_unet_refresh.argtypes = [vp]
     lib.dm_unet_graph_captures.argtypes = [vp]
+    lib.dm_unet_workspace_bytes.argtypes = [vp]
+    lib.dm_unet_workspace_bytes.restype = i64
     lib.dm_sample.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, u64, u64, fp, i32, fp, fp,
                               i32, i32, i32, i32, i32, vp]
     lib.dm_sample_cond.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, u64, u64, fp, i32, fp,

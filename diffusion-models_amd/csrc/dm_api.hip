@@ -108,16 +108,67 @@ struct DeviceOwner {
     }
 };
 
-// bump allocator over one device buffer; `dry` only measures
+// Workspace allocator over one device buffer.  Activations are released as soon as their last consumer has been
+// ENQUEUED (the launch stream is in order, and so is a captured step graph), so a denoise step works in a few hundred
+// megabytes that it keeps re-using instead of a fresh line of HBM per tensor: at the benchmark batch the blocks a
+// layer reads were written a few launches earlier and are still in the 256 MB Infinity Cache.
+// `dry` replays the same allocation sequence on fake addresses to measure the capacity (`peak`) a run needs; the
+// sequence, hence every pointer, is a function of the shapes only -- which is what makes the step capturable.
 struct Arena {
     char* base = nullptr;
-    size_t cap = 0, off = 0;
+    size_t cap = 0;
     bool dry = false;
+    size_t off = 0;  // capacity required so far (high-water mark)
+    struct Blk {
+        size_t off, size;
+        bool free;
+    };
+    std::vector<Blk> blks;  // sorted by offset, adjacent, covering [0, end of the last block)
+    char* origin() const { return dry ? reinterpret_cast<char*>(uintptr_t(1) << 44) : base; }
     float* alloc(size_t nfloats) {
-        size_t bytes = (nfloats * sizeof(float) + 255) & ~size_t(255);
-        float* p = dry ? nullptr : reinterpret_cast<float*>(base + off);
-        off += bytes;
-        return p;
+        const size_t bytes = std::max<size_t>((nfloats * sizeof(float) + 255) & ~size_t(255), 256);
+        int best = -1;
+        for (size_t i = 0; i < blks.size(); ++i)  // best fit
+            if (blks[i].free && blks[i].size >= bytes && (best < 0 || blks[i].size < blks[best].size)) best = (int)i;
+        size_t at;
+        if (best >= 0) {
+            Blk& b = blks[best];
+            at = b.off;
+            if (b.size > bytes) {
+                const Blk rest{b.off + bytes, b.size - bytes, true};
+                b.size = bytes;
+                b.free = false;
+                blks.insert(blks.begin() + best + 1, rest);
+            } else {
+                b.free = false;
+            }
+        } else if (!blks.empty() && blks.back().free) {  // grow the free tail
+            at = blks.back().off;
+            blks.back().size = bytes;
+            blks.back().free = false;
+        } else {
+            at = blks.empty() ? 0 : blks.back().off + blks.back().size;
+            blks.push_back(Blk{at, bytes, false});
+        }
+        off = std::max(off, blks.back().off + blks.back().size);
+        return reinterpret_cast<float*>(origin() + at);
+    }
+    void release(const void* p) {
+        if (!p) return;
+        const size_t at = (size_t)(static_cast<const char*>(p) - origin());
+        for (size_t i = 0; i < blks.size(); ++i) {
+            if (blks[i].off != at || blks[i].free) continue;
+            blks[i].free = true;
+            if (i + 1 < blks.size() && blks[i + 1].free) {
+                blks[i].size += blks[i + 1].size;
+                blks.erase(blks.begin() + i + 1);
+            }
+            if (i > 0 && blks[i - 1].free) {
+                blks[i - 1].size += blks[i].size;
+                blks.erase(blks.begin() + i);
+            }
+            return;
+        }
     }
 };
 
@@ -672,11 +723,16 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
     DM_REQUIRE(!out_nchw, "split / unfused epilogue writes NHWC");
     const size_t M = (size_t)c.B * out_h * out_w;
     float* part = c.A->alloc((size_t)p.geo.splits * M * L.Cout);
-    if (c.dry()) return 0;
+    if (c.dry()) {
+        c.A->release(part);
+        return 0;
+    }
     p.out = part; p.partial = 1; p.epi = 0;
     if (launch(p)) return 1;
-    return launch_norm_act(part, p.geo.splits, (int64_t)(M * L.Cout), L.bias, g, scale, c.ss_stride, out_h * out_w,
-                           residual, out, (int64_t)M, L.Cout, full_epi, c.s);
+    const int rc = launch_norm_act(part, p.geo.splits, (int64_t)(M * L.Cout), L.bias, g, scale, c.ss_stride, out_h * out_w,
+                                   residual, out, (int64_t)M, L.Cout, full_epi, c.s);
+    c.A->release(part);
+    return rc;
 }
 
 // Block.forward: conv3x3 -> RMSNorm -> (scale+1, shift) -> SiLU [-> + residual]
@@ -695,12 +751,15 @@ static int run_resnet(Ctx& c, const ResBlock& R, const float* x0, const float* x
     if (run_block(c, R.c1, x0, x1, H, W, R.g1, scale, nullptr, h1)) return 1;
     if (!R.has_res) {
         if (run_block(c, R.c2, h1, nullptr, H, W, R.g2, nullptr, x0, h2)) return 1;
+        c.A->release(h1);
         *out = h2;
         return 0;
     }
     if (run_block(c, R.c2, h1, nullptr, H, W, R.g2, nullptr, nullptr, h2)) return 1;
+    c.A->release(h1);
     float* o = c.A->alloc(n);
     if (run_conv(c, R.res, x0, x1, H, W, o, EPI_RESIDUAL, nullptr, nullptr, h2)) return 1;
+    c.A->release(h2);
     *out = o;
     return 0;
 }
@@ -716,6 +775,7 @@ static int run_attn(Ctx& c, const AttnLayer& At, const float* x, int H, int W, f
         float* ws = c.A->alloc(linattn_fused_ws_floats(c.B, n));
         float* yf = c.A->alloc(rows * At.dim);
         if (!c.dry() && launch_linattn_fused(At.fused, x, ws, yf, c.B, n, add_x, c.s)) return 1;
+        c.A->release(ws);
         *out = yf;
         return 0;
     }
@@ -740,7 +800,11 @@ static int run_attn(Ctx& c, const AttnLayer& At, const float* x, int H, int W, f
         float* ctxws = c.A->alloc((size_t)c.B * u->heads * u->dh * u->dh);
         if (!c.dry() && launch_linear_attention_core(qkv, At.mem_kv, ctxws, o, c.B, n, u->heads, u->dh, c.s)) return 1;
         if (run_conv(c, At.out, o, nullptr, H, W, y, EPI_NORM | res_flag, At.out_g, nullptr, xres)) return 1;
+        c.A->release(ctxws);
     }
+    c.A->release(xn);
+    c.A->release(qkv);
+    c.A->release(o);
     *out = y;
     return 0;
 }
@@ -765,6 +829,10 @@ static int run_cross(Ctx& c, const CrossLayer& Cr, const float* x, int H, int W,
             return 1;
     }
     if (run_conv(c, Cr.out, o, nullptr, H, W, y, EPI_NORM, Cr.g, nullptr, nullptr)) return 1;
+    c.A->release(q);
+    c.A->release(k);
+    c.A->release(v);
+    c.A->release(o);
     *out = y;
     return 0;
 }
@@ -811,61 +879,81 @@ static int unet_forward_impl(dm_unet* u, Arena& A, const float* x_nchw, const in
             if (launch_linear_rows(cat, 2 * td, u->tc_w, u->tc_b, t2, td, B, 2 * td, td, 0, 0, s)) return 1;
         }
         tfinal = t2;
+        A.release(cat);
+        A.release(tf0);
     }
     if (!A.dry) {
         // every ResnetBlock.mlp (SiLU -> Linear) in one launch
         if (launch_linear_rows(tfinal, td, u->ss_w, u->ss_b, ss, u->ss_total, Bt, td, u->ss_total, 1, 0, s)) return 1;
     }
+    if (tfinal != temb) A.release(tfinal);
+    A.release(e0);
+    A.release(e1);
+    A.release(temb);
     c.ss = A.dry ? reinterpret_cast<const float*>(16) : ss;  // non-null marker in dry mode
     c.ss_stride = Bt == 1 ? 0 : u->ss_total;
 
     const int n_st = cfg.n_stages;
     float* x = A.alloc((size_t)B * H * W * u->init_dim);
     if (run_conv(c, u->init_conv, x_nchw, nullptr, H, W, x, 0, nullptr, nullptr, nullptr, /*in_nchw=*/true)) return 1;
-    const float* r = x;
+    const float* r = x;  // Unet.forward's `r = x.clone()`: read again by final_res_block, never released before
+    auto rel = [&](const float* t) {
+        if (t != r) A.release(t);
+    };
     std::vector<const float*> skips;
-    std::vector<int> skipC;
     int h = H, w = W;
     float* cur = x;
     for (int i = 0; i < n_st; ++i) {
         Stage& S = u->downs[i];
         float *a, *b2, *at;
         if (run_resnet(c, S.b1, cur, nullptr, h, w, &a)) return 1;
-        skips.push_back(a); skipC.push_back(S.b1.dout);
+        rel(cur);
+        skips.push_back(a);
         if (run_resnet(c, S.b2, a, nullptr, h, w, &b2)) return 1;
         if (run_attn(c, S.attn, b2, h, w, &at)) return 1;
-        skips.push_back(at); skipC.push_back(S.b2.dout);
+        rel(b2);
+        skips.push_back(at);
         int ho = (i < n_st - 1) ? h / 2 : h, wo = (i < n_st - 1) ? w / 2 : w;
         float* d = A.alloc((size_t)B * ho * wo * S.resample.Cout);
         if (run_conv(c, S.resample, at, nullptr, h, w, d, 0, nullptr, nullptr, nullptr)) return 1;
         cur = d; h = ho; w = wo;
     }
     float* t0;
-    if (text_cross) { if (run_cross(c, u->cross_down, cur, h, w, ctx, ctx_tokens, &t0)) return 1; cur = t0; }
-    if (run_resnet(c, u->mid1, cur, nullptr, h, w, &t0)) return 1; cur = t0;
-    if (text_cross) { if (run_cross(c, u->cross_mid, cur, h, w, ctx, ctx_tokens, &t0)) return 1; cur = t0; }
-    if (run_attn(c, u->mid_attn, cur, h, w, &t0)) return 1; cur = t0;
-    if (run_resnet(c, u->mid2, cur, nullptr, h, w, &t0)) return 1; cur = t0;
-    if (text_cross) { if (run_cross(c, u->cross_up, cur, h, w, ctx, ctx_tokens, &t0)) return 1; cur = t0; }
+    if (text_cross) { if (run_cross(c, u->cross_down, cur, h, w, ctx, ctx_tokens, &t0)) return 1; rel(cur); cur = t0; }
+    if (run_resnet(c, u->mid1, cur, nullptr, h, w, &t0)) return 1; rel(cur); cur = t0;
+    if (text_cross) { if (run_cross(c, u->cross_mid, cur, h, w, ctx, ctx_tokens, &t0)) return 1; rel(cur); cur = t0; }
+    if (run_attn(c, u->mid_attn, cur, h, w, &t0)) return 1; rel(cur); cur = t0;
+    if (run_resnet(c, u->mid2, cur, nullptr, h, w, &t0)) return 1; rel(cur); cur = t0;
+    if (text_cross) { if (run_cross(c, u->cross_up, cur, h, w, ctx, ctx_tokens, &t0)) return 1; rel(cur); cur = t0; }
     for (int j = 0; j < n_st; ++j) {
         Stage& S = u->ups[j];
         float *a, *b2, *at;
-        const float* sk = skips.back(); skips.pop_back(); skipC.pop_back();
+        const float* sk = skips.back(); skips.pop_back();
         if (run_resnet(c, S.b1, cur, sk, h, w, &a)) return 1;
-        sk = skips.back(); skips.pop_back(); skipC.pop_back();
+        rel(cur);
+        rel(sk);
+        sk = skips.back(); skips.pop_back();
         if (run_resnet(c, S.b2, a, sk, h, w, &b2)) return 1;
+        rel(a);
+        rel(sk);
         if (run_attn(c, S.attn, b2, h, w, &at)) return 1;
+        rel(b2);
         bool last = j == n_st - 1;
         int ho = last ? h : h * 2, wo = last ? w : w * 2;
         float* d = A.alloc((size_t)B * ho * wo * S.resample.Cout);
         // the conv sees the (virtually) upsampled tensor
         if (run_conv(c, S.resample, at, nullptr, ho, wo, d, 0, nullptr, nullptr, nullptr)) return 1;
+        rel(at);
         cur = d; h = ho; w = wo;
     }
     float* fr;
     if (run_resnet(c, u->final_res, cur, r, h, w, &fr)) return 1;
+    rel(cur);
+    A.release(r);
     if (run_conv(c, u->final_conv, fr, nullptr, h, w, out_nchw, 0, nullptr, nullptr, nullptr, false, /*out_nchw=*/true))
         return 1;
+    A.release(fr);
+    A.release(ss);
     return 0;
 }
 
@@ -1080,6 +1168,7 @@ int dm_unet_refresh(dm_unet* u) {
 }
 
 int dm_unet_graph_captures(dm_unet* u) { return u ? u->graph_captures : -1; }
+int64_t dm_unet_workspace_bytes(dm_unet* u) { return u ? (int64_t)u->ws_cap : -1; }
 
 int dm_unet_forward(dm_unet* u, const float* x, const int64_t* time, const float* ctx, int ctx_tokens, float* out,
                     int B, int H, int W, void* stream) {
@@ -1185,14 +1274,14 @@ static int sample_impl(dm_unet* u, int kind, int n_steps, const int64_t* times_h
     float* eps = A.alloc(n);
     float* xin = cond ? A.alloc(n_in) : nullptr;  // [x | cond] per image, what init_conv reads
     float* ctxbuf = ctx ? A.alloc(n_ctx) : nullptr;
-    const size_t arena_mark = A.off;
+    const std::vector<Arena::Blk> arena_mark = A.blks;  // allocator state in front of a denoise step
     DM_CHECK_HIP(hipMemcpyAsync(xbuf, x_T, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (ctx) DM_CHECK_HIP(hipMemcpyAsync(ctxbuf, ctx, n_ctx * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (cond && launch_copy_channels(cond, xin, B, cond_channels, C + cond_channels, C, H * W, s)) return 1;
     if (all_steps) DM_CHECK_HIP(hipMemcpyAsync(all_steps, x_T, n * sizeof(float), hipMemcpyDeviceToDevice, s));
 
     auto one_step = [&](hipStream_t st) -> int {
-        A.off = arena_mark;
+        A.blks = arena_mark;
         if (cond && launch_copy_channels(xbuf, xin, B, C, C + cond_channels, 0, H * W, st)) return 1;
         if (unet_forward_impl(u, A, cond ? xin : xbuf, nullptr, u->times_dev, u->state_dev, ctxbuf, ctx_tokens, eps, B, H,
                               W, st))

@@ -142,6 +142,11 @@ class Unet:
         return self
 
     @property
+    def workspace_bytes(self) -> int:
+        """Bytes of activation workspace the handle owns (tensors are recycled inside a forward)."""
+        return int(self._lib.dm_unet_workspace_bytes(self._handle))
+
+    @property
     def graph_captures(self) -> int:
         """How many times a denoise-step graph was captured on this handle (one per sampled shape)."""
         return int(self._lib.dm_unet_graph_captures(self._handle))

@@ -84,6 +84,9 @@ int dm_unet_update_param(dm_unet* u, const char* name, const float* data_host, c
 int dm_unet_refresh(dm_unet* u);
 /* how many times a denoise-step graph has been captured on this handle (diagnostics / tests: one per shape) */
 int dm_unet_graph_captures(dm_unet* u);
+/* bytes of the activation workspace the handle currently owns (grown by the largest call so far; activations are
+ * released to it as soon as their last consumer is enqueued, so a B=256 step works in a few hundred MB) */
+int64_t dm_unet_workspace_bytes(dm_unet* u);
 
 /* Unet.forward(x, time, x_self_cond=None) DD/denoising_diffusion.py:349-390 and the
  * text variant forward(x, time, text_emb) DD/denoising_diffusion_text_conditional.py:131-214.
