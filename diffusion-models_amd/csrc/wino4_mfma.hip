@@ -167,10 +167,15 @@ ConvGeom wino4_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_
 bool wino4_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1) {
     if (w4_class(Ho, Wo) < 0) return false;
     const ConvGeom g = wino4_plan(B, Ho, Wo, Cout, C0, C1, true);
-    static const int min_wgs = w4_env_int("DM_WINO4_MIN_WGS", 96);  // too few 256-pixel workgroups: F(2x2) fills the chip better
+    // One 512-register workgroup per CU cannot hide its own prologue (first windows and weights from L2 / HBM) and
+    // epilogue behind another workgroup, as the two-per-CU F(2x2) kernel does: this kernel wins where those fixed costs
+    // are amortised over a long reduction (measured at B = 256, 32x32: 16 chunks 1.10-1.18x, 32-48 chunks 1.19-1.23x,
+    // 8 chunks 1.0x) and the chip is filled.
+    static const int min_wgs = w4_env_int("DM_WINO4_MIN_WGS", 200);
+    static const int min_k = w4_env_int("DM_WINO4_MIN_K", 12);  // chunks of 8 input channels per workgroup
     const int wgs = g.tiles_x * g.tiles_y * g.groups * g.n_tiles_n * g.splits;
-    return wgs >= min_wgs && g.lds_bytes <= 160 * 1024 && (size_t)B * Ho * Wo < (1u << 24) &&
-           (size_t)B * Ho * Wo * std::max(C0, C1) < (1ull << 30);
+    return wgs >= min_wgs && g.chunks_per_split >= min_k && g.lds_bytes <= 160 * 1024 &&
+           (size_t)B * Ho * Wo < (1u << 24) && (size_t)B * Ho * Wo * std::max(C0, C1) < (1ull << 30);
 }
 
 // packed math whose first factor is a wave-uniform coefficient pair held in SGPRs (one constant-bus operand)
@@ -233,13 +238,10 @@ __global__ __launch_bounds__(256, 1) void wino4_mfma_kernel(const ConvParams p) 
     const int l15 = lane & 15;  // MFMA row (tile) of the A operand / column (cout) of the B operand
     const int kq = lane >> 4;   // channel pair (2 kq, 2 kq + 1) of the chunk
 
-    // XCD-aware block order: blocks b and b + 8 share an XCD (and its L2), so consecutive LOGICAL ids -- the cout tiles of
-    // one pixel block, then its neighbours -- are given to the blocks of one XCD
+    // Block order: the cout tile is the fastest index and blocks are dealt round-robin over the 8 XCDs, so with 2, 4 or 8
+    // cout tiles an XCD always works on the same tile(s): its L2 holds that tile's weights for all pixel blocks (the
+    // deep layers are weight-streaming: 37.7 MB of transformed weights against 4 MB of activations at 512 channels).
     int bid = blockIdx.x;
-    {
-        const int nblk = gridDim.x;
-        if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
-    }
     const int n_tile = bid % g.n_tiles_n;
     bid /= g.n_tiles_n;
     const int tile_x = bid % g.tiles_x;
