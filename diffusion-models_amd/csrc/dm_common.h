@@ -174,7 +174,13 @@ struct SamplerState {
 // e[r] = cat(sin(t[r]*f), cos(t[r]*f)); t int64; if step_times != nullptr t = step_times[state->step]
 int launch_sinusoid(const int64_t* t, const int64_t* step_times, const SamplerState* state, const float* freqs, float* e,
                     int R, int half, hipStream_t s);
-// GroupNorm(32 groups) + optional swish, NHWC
+// VAE kernels (vae_kernels.hip): MFMA flash attention of AttnBlock, coalesced GroupNorm statistics
+bool vae_attn_mfma_ok(int n, int C);
+int launch_vae_attn_mfma(const float* q, const float* k, const float* v, float* out, int B, int n, int C, hipStream_t s);
+bool group_sums_ok(int C, int groups);
+int launch_group_stats_fast(const float* x, float* stats, double* acc, int B, int HW, int C, int groups, float eps,
+                            hipStream_t s);
+// GroupNorm(32 groups) + optional swish, NHWC; stats_ws holds B*groups*2 floats + B*groups*2 doubles
 int launch_group_norm(const float* x, const float* w, const float* b, float* y, float* stats_ws, int B, int HW,
                       int C, int groups, float eps, int swish, hipStream_t s);
 int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s);

@@ -314,8 +314,13 @@ __global__ void group_apply_kernel(const float* __restrict__ x, const float* __r
 }
 int launch_group_norm(const float* x, const float* w, const float* b, float* y, float* stats_ws, int B, int HW,
                       int C, int groups, float eps, int swish, hipStream_t s) {
-    // stats_ws: B*groups*2 floats of scratch (mean, rstd)
-    hipLaunchKernelGGL(group_stats_kernel, dim3(groups, B), dim3(256), 0, s, x, stats_ws, HW, C, groups, eps);
+    // stats_ws: B*groups*2 floats (mean, rstd) followed by B*groups*2 doubles of accumulator scratch
+    if (group_sums_ok(C, groups)) {
+        double* acc = reinterpret_cast<double*>(stats_ws + (size_t)B * groups * 2);
+        if (launch_group_stats_fast(x, stats_ws, acc, B, HW, C, groups, eps, s)) return 1;
+    } else {
+        hipLaunchKernelGGL(group_stats_kernel, dim3(groups, B), dim3(256), 0, s, x, stats_ws, HW, C, groups, eps);
+    }
     int64_t n = (int64_t)B * HW * C;
     hipLaunchKernelGGL(group_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, stats_ws, w, b, y, HW, C,
                        groups, swish, n);
