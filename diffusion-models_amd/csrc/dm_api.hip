@@ -154,7 +154,8 @@ struct Arena {
         return reinterpret_cast<float*>(origin() + at);
     }
     void release(const void* p) {
-        if (!p) return;
+        static const bool off = std::getenv("DM_NO_WS_REUSE") != nullptr;  // measurement switch: one fresh block per tensor
+        if (!p || off) return;
         const size_t at = (size_t)(static_cast<const char*>(p) - origin());
         for (size_t i = 0; i < blks.size(); ++i) {
             if (blks[i].off != at || blks[i].free) continue;

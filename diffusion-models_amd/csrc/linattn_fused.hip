@@ -212,6 +212,9 @@ __global__ __launch_bounds__(256) void linattn_ctx_reduce_kernel(const float* __
     for (int i = 0; i < 4; ++i) {
         const int d = 8 * e4 + 4 * lh + i;  // every (d, e = l31) once
         float c = 0.f, k = 0.f;
+        // the partial sums of the token blocks are independent loads: keep 8 of them in flight (at 64x64 there are 16-32
+        // blocks per image and only heads x images workgroups, so this loop is a latency chain otherwise)
+#pragma unroll 8
         for (int kb = 0; kb < nblk; ++kb) {
             const float* cp = ws + (((size_t)b * nblk + kb) * LA_HEADS + h) * LA_CTX;
             c += cp[d * LA_DH + l31];
