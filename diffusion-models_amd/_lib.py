@@ -28,6 +28,8 @@ EXPORTS = (
     "dm_encoder_finalize", "dm_encoder_forward",
     "dm_op_conv2d", "dm_op_downsample", "dm_op_rmsnorm", "dm_op_block", "dm_op_linear_attention",
     "dm_op_attention", "dm_op_sampler_update",
+    "dm_conv_create", "dm_conv_destroy", "dm_conv_forward", "dm_op_pool2d", "dm_op_resize_bilinear",
+    "dm_op_copy_channels_nhwc", "dm_op_global_avgpool", "dm_op_linear",
     "dm_profile_enable", "dm_profile_read",
 )
 
@@ -110,6 +112,15 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_op_linear_attention.argtypes = [fp, fp, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, vp]
     lib.dm_op_attention.argtypes = [fp, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, vp]
     lib.dm_op_sampler_update.argtypes = [i32, fp, fp, fp, C.POINTER(C.c_float), fp, i64, vp]
+    lib.dm_conv_create.argtypes = [fp, fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]
+    lib.dm_conv_destroy.argtypes = [vp]
+    lib.dm_conv_destroy.restype = None
+    lib.dm_conv_forward.argtypes = [vp, fp, i32, i32, i32, i32, fp, vp]
+    lib.dm_op_pool2d.argtypes = [fp, fp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.dm_op_resize_bilinear.argtypes = [fp, fp, i32, i32, i32, i32, i32, i32, fp, fp, vp]
+    lib.dm_op_copy_channels_nhwc.argtypes = [fp, i32, fp, i32, i32, i64, vp]
+    lib.dm_op_global_avgpool.argtypes = [fp, fp, i32, i32, i32, vp]
+    lib.dm_op_linear.argtypes = [fp, fp, fp, fp, i32, i32, i32, vp]
     lib.dm_profile_enable.argtypes = [i32]
     lib.dm_profile_read.argtypes = [C.POINTER(ProfileRow), i32, C.POINTER(i32)]
 

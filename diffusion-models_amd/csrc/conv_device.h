@@ -261,6 +261,11 @@ __device__ __forceinline__ void rows_epilogue(const ConvParams& p, const RowsEpi
             v[j] = v[j] * r4;
         }
     }
+    if (epi & EPI_RELU) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+            v[j] = make_f32x4(fmaxf(v[j].x, 0.f), fmaxf(v[j].y, 0.f), fmaxf(v[j].z, 0.f), fmaxf(v[j].w, 0.f));
+    }
     const gfloat_mptr op = (gfloat_mptr)p.out;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     // folded upsample conv: blockIdx.z picks the output parity, which fixes the (asymmetric) padding
     const int par = p.fold ? blockIdx.z : 0;
     const int par_y = par >> 1, par_x = par & 1;
-    const int pad_y = p.fold ? 1 - par_y : p.pad, pad_x = p.fold ? 1 - par_x : p.pad;
+    const int pad_y = p.fold ? 1 - par_y : p.pad, pad_x = p.fold ? 1 - par_x : p.pad_w;
     const int ix0 = x0 * p.stride - pad_x, iy0 = y0 * p.stride - pad_y;
     DM_STAMP_DECL
     DM_STAMP(0);
@@ -822,6 +822,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                     }
                 }
                 if (epi & EPI_SILU) v = v * fast_rcp(1.0f + __expf(-v));
+                if (epi & EPI_RELU) v = fmaxf(v, 0.0f);
                 if (epi & EPI_RESIDUAL) v += p.residual[pix * p.Cout + co[q]];
                 if (p.out_nchw) {
                     const int b = pixi / HoWo;

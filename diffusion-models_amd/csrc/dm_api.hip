@@ -175,6 +175,7 @@ struct Arena {
 
 struct ConvLayer {
     int C0 = 0, C1 = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0;
+    int pad_w = -1;     // zero columns left / right when they differ from `pad` rows (1x7 / 7x1 convs of InceptionV3); -1: pad
     int pad_hi = 0;     // extra zero rows / columns at the bottom / right only (VAE Encoder Downsample, model.py:89-93)
     bool up = false;    // nearest x2 in front of the conv (Upsample, DD/denoising_diffusion.py:48-52)
     bool fold = false;  // ... executed as four 2x2 parity convs on the source grid (ConvParams::fold)
@@ -656,6 +657,8 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
     p.in_nchw = in_nchw ? 1 : 0;
     p.w = L.w; p.bias = L.bias;
     p.Cout = L.Cout; p.stride = L.stride; p.pad = L.pad;
+    const int padw = L.pad_w >= 0 ? L.pad_w : L.pad;
+    p.pad_w = padw;
     p.B = c.B;
     p.out_nchw = out_nchw ? 1 : 0;
     p.residual = residual; p.g = g; p.scale = scale; p.ss_stride = c.ss_stride;
@@ -665,7 +668,7 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
         // (Hin, Win) is the upsampled size the caller sees; the four parity convs run on the source grid
         DM_REQUIRE(!out_nchw && !in_nchw, "folded upsample conv is NHWC");
         p.fold = 1; p.fold_w_stride = L.fold_w_stride; p.up = 0;
-        p.KH = 2; p.KW = 2;
+        p.KH = 2; p.KW = 2; p.pad_w = 1;
         p.Hin = Hin / 2; p.Win = Win / 2;
         p.Ho = p.Hin; p.Wo = p.Win;
         out_h = Hin; out_w = Win;
@@ -674,7 +677,7 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
                !in_nchw && Hin % 2 == 0 && Win % 2 == 0) {
         // Downsample: space-to-depth, then a 1x1 convolution over 4*C0 channels (ConvParams::s2d)
         p.fold = 0; p.fold_w_stride = 0; p.up = 0; p.s2d = 1;
-        p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+        p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.pad_w = 0;
         p.Ho = Hin / 2; p.Wo = Win / 2;
         p.Hin = p.Ho; p.Win = p.Wo;
         p.chunks0 = p.n_chunks = 4 * (L.C0 / 16);
@@ -686,7 +689,7 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
         p.Hin = Hin; p.Win = Win;
         // the kernel zero-fills every window pixel outside the image, so bottom / right padding is only an output size
         p.Ho = (Hin + 2 * L.pad + L.pad_hi - L.KH) / L.stride + 1;
-        p.Wo = (Win + 2 * L.pad + L.pad_hi - L.KW) / L.stride + 1;
+        p.Wo = (Win + 2 * padw + L.pad_hi - L.KW) / L.stride + 1;
         out_h = p.Ho; out_w = p.Wo;
         p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, L.KH, L.KW, L.stride, L.C0, L.C1, want_norm && !out_nchw,
                           !out_nchw);
@@ -699,8 +702,9 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
     }
     // 3x3 / stride 1 convolutions run as Winograd F(4x4,3x3) on power-of-two images, else as F(2x2,3x3), when the layer
     // has transformed weights
-    const bool wino4 = L.ww4 && !L.fold && !in_nchw && !out_nchw && wino4_shape_ok(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
-    const bool wino = !wino4 && L.ww && !L.fold && !in_nchw && !out_nchw &&
+    const bool wino4 = L.ww4 && !L.fold && !in_nchw && !out_nchw && padw == L.pad &&
+                       wino4_shape_ok(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
+    const bool wino = !wino4 && L.ww && !L.fold && !in_nchw && !out_nchw && padw == L.pad &&
                       wino_use(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
     if (wino4) {
         p.w = L.ww4;
@@ -1363,3 +1367,4 @@ int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, uint64_t eleme
 // single-operator entry points (dm_op_*) and the VAE decoder share the helpers above
 #include "dm_ops.inc"
 #include "dm_vae.inc"
+#include "dm_consumer.inc"

@@ -42,6 +42,7 @@ enum ConvEpilogue : int {
     EPI_SCALE_SHIFT = 4, // v * (scale[b][cout] + 1) + shift[b][cout]
     EPI_SILU = 8,        // v * sigmoid(v)
     EPI_RESIDUAL = 16,   // + residual[pixel][cout]
+    EPI_RELU = 32,       // max(v, 0)  (BasicConv2d of the Inception evaluators; after bias, before the residual)
 };
 
 struct ConvGeom {
@@ -76,6 +77,7 @@ struct ConvParams {
     const float* w;      // packed [chunk][ky][kx][Cout padded to 64][CK]
     const float* bias;
     int Cout, KH, KW, stride, pad;
+    int pad_w;           // zero columns left of the image (pad = rows above it); equal to pad for every U-Net / VAE conv
     int B, Ho, Wo;
     float* out;
     int out_nchw;
@@ -184,6 +186,14 @@ int launch_group_stats_fast(const float* x, float* stats, double* acc, int B, in
 int launch_group_norm(const float* x, const float* w, const float* b, float* y, float* stats_ws, int B, int HW,
                       int C, int groups, float eps, int swish, hipStream_t s);
 int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s);
+// consumer-side ops (consumer_ops.hip): NHWC pooling (mode 0 max, 1 avg counting the padding, 2 avg over valid pixels),
+// bilinear resize (align_corners = False) NCHW -> NHWC with a per-channel affine map, channel-slice copy, global mean
+int launch_pool2d_nhwc(const float* in, float* out, int B, int H, int W, int C, int k, int stride, int pad, int mode,
+                       hipStream_t s);
+int launch_resize_bilinear(const float* in_nchw, float* out_nhwc, int B, int C, int H, int W, int Ho, int Wo,
+                           const float* scale, const float* shift, hipStream_t s);
+int launch_copy_channels_nhwc(const float* src, int Cs, float* dst, int Cd, int c_off, int64_t rows, hipStream_t s);
+int launch_global_avgpool_nhwc(const float* in, float* out, int B, int HW, int C, hipStream_t s);
 int launch_spin(double milliseconds, hipStream_t s);
 int launch_copy_channels(const float* src, float* dst, int B, int Cs, int Cd, int c_off, int HW, hipStream_t s);
 // y_nchw[b][o][sp] = bias[o] + sum_c x[pixel][c] * w[o][c]  for Cout <= 4 (NHWC in, NCHW out)

@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const float* __restrict__
         if (flags & EPI_NORM) v = v * rn * g[c];
         if (flags & EPI_SCALE_SHIFT) v = v * (sp[c] + 1.0f) + sp[C + c];
         if (flags & EPI_SILU) v = silu_f(v);
+        if (flags & EPI_RELU) v = fmaxf(v, 0.0f);
         if (flags & EPI_RESIDUAL) v += residual[row * C + c];
         yr[c] = v;
     };
@@ -159,6 +160,12 @@ __global__ __launch_bounds__(256) void norm_act_vec_kernel(const float* __restri
             t.y = silu_f(t.y);
             t.z = silu_f(t.z);
             t.w = silu_f(t.w);
+        }
+        if (flags & EPI_RELU) {
+            t.x = fmaxf(t.x, 0.f);
+            t.y = fmaxf(t.y, 0.f);
+            t.z = fmaxf(t.z, 0.f);
+            t.w = fmaxf(t.w, 0.f);
         }
         if (flags & EPI_RESIDUAL) t += *reinterpret_cast<const f32x4v*>(residual + row * C + c);
         *reinterpret_cast<f32x4v*>(y + row * C + c) = t;

@@ -38,6 +38,18 @@ def synth_tensor(name: str, shape: Tuple[int, ...], salt: int = 0) -> torch.Tens
         if leaf == "weight":
             return 1.0 + 0.25 * torch.randn(shape, generator=g)
         return 0.1 * torch.randn(shape, generator=g)
+    if ".bn." in name:  # BatchNorm of InceptionV3's BasicConv2d (eval mode: affine + running statistics)
+        if leaf == "weight":
+            return 1.0 + 0.2 * (torch.rand(shape, generator=g) * 2 - 1)
+        if leaf == "running_var":
+            return 0.5 + torch.rand(shape, generator=g)
+        return 0.1 * torch.randn(shape, generator=g)  # bias, running_mean
+    if name.endswith(".conv.weight") and name.startswith(("Conv2d_", "Mixed_")):
+        # InceptionV3 conv in front of a ReLU: He-uniform keeps activations O(1) through 90 layers
+        fan_in = 1
+        for d in shape[1:]:
+            fan_in *= d
+        return (torch.rand(shape, generator=g) * 2 - 1) * math.sqrt(6.0 / fan_in)
     if leaf == "weight":
         fan_in = 1
         for d in shape[1:]:

@@ -229,6 +229,34 @@ int dm_op_attention(const float* x, const float* norm_g, const float* mem_kv, co
 int dm_op_sampler_update(int kind, const float* x, const float* eps, const float* noise, const float* c_host,
                          float* out, int64_t n, void* stream);
 
+/* ---- sample consumer: the InceptionV3 feature extractor behind the reference's FID and
+ *      Inception-score evaluators (DD/fid_evaluation.py:41-51 -> pytorch_fid.inception.InceptionV3;
+ *      DD/inception_score_evaluation.py:70-92 -> torchvision.models.inception_v3).  The layer graph is host code
+ *      (diffusion-models_amd/inception.py); these are its operators.  Activations are NHWC fp32 DEVICE pointers.
+ *      Both libraries and their pretrained weights are absent here: parity unpinned, checked against the oracle's
+ *      restatement of the published architectures. -------------------------------------------------------------- */
+typedef struct dm_conv dm_conv;
+/* nn.Conv2d(Cin, Cout, (KH, KW), stride, (pad_h, pad_w)) with an optional ReLU; weight_host OIHW, bias_host or NULL
+ * (BasicConv2d = conv + BatchNorm(eval) + ReLU is passed with the BatchNorm folded into weight and bias) */
+int dm_conv_create(const float* weight_host, const float* bias_host, int Cout, int Cin, int KH, int KW, int stride,
+                   int pad_h, int pad_w, int relu, int device, dm_conv** out);
+void dm_conv_destroy(dm_conv* c);
+/* in: (B, H, W, Cin) NHWC, or (B, Cin, H, W) when in_nchw != 0; out: (B, Ho, Wo, Cout) NHWC */
+int dm_conv_forward(dm_conv* c, const float* in, int in_nchw, int B, int H, int W, float* out_nhwc, void* stream);
+/* F.max_pool2d / F.avg_pool2d on NHWC: mode 0 max, 1 avg with count_include_pad=True, 2 avg with count_include_pad=False */
+int dm_op_pool2d(const float* in, float* out, int B, int H, int W, int C, int k, int stride, int pad, int mode,
+                 void* stream);
+/* F.interpolate(x, (Ho, Wo), mode="bilinear", align_corners=False) of an NCHW batch, written NHWC, then
+ * scale[c] * v + shift[c] (scale / shift: C floats on the device) */
+int dm_op_resize_bilinear(const float* in_nchw, float* out_nhwc, int B, int C, int H, int W, int Ho, int Wo,
+                          const float* scale_dev, const float* shift_dev, void* stream);
+/* torch.cat along channels, one source at a time: dst[row][c_off + c] = src[row][c] */
+int dm_op_copy_channels_nhwc(const float* src, int Cs, float* dst, int Cd, int c_off, int64_t rows, void* stream);
+/* adaptive_avg_pool2d(x, (1, 1)) on NHWC: out (B, C) */
+int dm_op_global_avgpool(const float* in_nhwc, float* out, int B, int HW, int C, void* stream);
+/* nn.Linear: y (R, O) = x (R, I) W^T + b; weight (O, I) and bias on the device */
+int dm_op_linear(const float* x, const float* weight, const float* bias, float* y, int R, int I, int O, void* stream);
+
 /* ---- measurement (bench.py's roofline leg; not part of the reference surface) -------------
  * While enabled, every convolution / fused-attention launch is bracketed by two HIP events recorded on
  * the stream the kernel is launched on.  Do not combine with use_graph.  dm_profile_enable(1) first

@@ -1,0 +1,143 @@
+"""Sample consumer: InceptionV3 features for the FID / Inception-score evaluators.
+
+pytorch_fid and torchvision are absent from the reference tree and from this image and their weights cannot be
+fetched, so this row is **parity unpinned**: the HIP path is checked against the oracle's independent restatement of
+the published architecture (oracle/inception_oracle.py) on name-seeded synthetic weights, and the operators against
+torch's own CPU ops."""
+import ctypes as C
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import diffusion_models_amd as dm
+from diffusion_models_amd import _lib
+from diffusion_models_amd.inception_spec import all_convs, inception_param_spec
+from oracle import inception_oracle as io
+
+from conftest import rel_l2
+
+DEV = "cuda:0"
+
+
+def test_spec_matches_published_parameter_count():
+    # torchvision's inception_v3 has 27,161,264 parameters, 3,326,696 of them in AuxLogits (not on the eval path)
+    spec = inception_param_spec()
+    n = sum(int(np.prod(s)) for k, s in spec if not k.endswith(("running_mean", "running_var")))
+    assert n == 27161264 - 3326696
+    assert len(all_convs()) == 94  # 96 BasicConv2d in torchvision, two of them in AuxLogits
+
+
+def test_frechet_distance_known_answers():
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=(500, 8))
+    m, s = a.mean(0), np.cov(a, rowvar=False)
+    assert abs(dm.calculate_frechet_distance(m, s, m, s)) < 1e-6
+    # two isotropic Gaussians: |dm|^2 + d (s1 - s2)^2
+    d = 5
+    got = dm.calculate_frechet_distance(np.zeros(d), 4.0 * np.eye(d), np.ones(d), 1.0 * np.eye(d))
+    assert abs(got - (d + d * (2.0 - 1.0) ** 2)) < 1e-6
+    assert abs(got - io.frechet_distance(np.zeros(d), 4.0 * np.eye(d), np.ones(d), np.eye(d))) < 1e-9
+
+
+@pytest.mark.gpu
+def test_consumer_operators_vs_torch():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 12, 9, 11, generator=g)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    for k, stride, pad, mode, ref in (
+        (3, 2, 0, 0, F.max_pool2d(x, 3, 2)),
+        (3, 1, 1, 0, F.max_pool2d(x, 3, 1, 1)),
+        (3, 1, 1, 1, F.avg_pool2d(x, 3, 1, 1)),
+        (3, 1, 1, 2, F.avg_pool2d(x, 3, 1, 1, count_include_pad=False)),
+    ):
+        y = torch.empty((2, ref.shape[2], ref.shape[3], 12), device=DEV)
+        _lib.check(lib.dm_op_pool2d(_lib.ptr(xh), _lib.ptr(y), 2, 9, 11, 12, k, stride, pad, mode, None))
+        assert torch.allclose(y.cpu().permute(0, 3, 1, 2), ref, atol=1e-6), (k, stride, pad, mode)
+    # bilinear resize + affine
+    img = torch.rand(2, 3, 32, 32, generator=g)
+    ref = 2 * F.interpolate(img, size=(299, 299), mode="bilinear", align_corners=False) - 1
+    y = torch.empty((2, 299, 299, 3), device=DEV)
+    sc, sh = torch.full((3,), 2.0, device=DEV), torch.full((3,), -1.0, device=DEV)
+    a = img.to(DEV)
+    _lib.check(lib.dm_op_resize_bilinear(_lib.ptr(a), _lib.ptr(y), 2, 3, 32, 32, 299, 299, _lib.ptr(sc), _lib.ptr(sh), None))
+    assert torch.allclose(y.cpu().permute(0, 3, 1, 2), ref, atol=2e-6)
+    # convolution handle: 1x7 / 7x1 / strided / ReLU, odd sizes and channel counts of the Inception graph
+    for cin, cout, k, stride, pad, hw in ((80, 192, (3, 3), 1, (0, 0), (17, 17)), (128, 128, (1, 7), 1, (0, 3), (17, 17)),
+                                         (128, 192, (7, 1), 1, (3, 0), (17, 17)), (288, 384, (3, 3), 2, (0, 0), (35, 35)),
+                                         (48, 64, (5, 5), 1, (2, 2), (35, 35)), (384, 384, (1, 3), 1, (0, 1), (8, 8)),
+                                         (448, 384, (3, 3), 1, (1, 1), (8, 8)), (3, 32, (3, 3), 2, (0, 0), (39, 39))):
+        w = torch.randn(cout, cin, *k, generator=g) * (2.0 / (cin * k[0] * k[1])) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        xi = torch.randn(2, cin, *hw, generator=g)
+        ref = F.relu(F.conv2d(xi, w, b, stride=stride, padding=pad))
+        h = C.c_void_p()
+        _lib.check(lib.dm_conv_create(w.data_ptr(), b.data_ptr(), cout, cin, k[0], k[1], stride, pad[0], pad[1], 1, 0, C.byref(h)))
+        xin = xi.permute(0, 2, 3, 1).contiguous().to(DEV)
+        y = torch.empty((2, ref.shape[2], ref.shape[3], cout), device=DEV)
+        _lib.check(lib.dm_conv_forward(h, _lib.ptr(xin), 0, 2, hw[0], hw[1], _lib.ptr(y), None))
+        torch.cuda.synchronize()
+        lib.dm_conv_destroy(h)
+        err = rel_l2(y.cpu().permute(0, 3, 1, 2), ref)
+        print("conv", cin, cout, k, stride, pad, err)
+        assert err < 2e-5
+
+
+@pytest.mark.gpu
+def test_inception_features_and_logits_vs_oracle():
+    sd = dm.synth_state_dict(inception_param_spec(), salt=0)
+    x = torch.rand(3, 3, 32, 32, generator=torch.Generator().manual_seed(7))
+    net = dm.InceptionV3([3], state_dict=sd, device=DEV)
+    got = net(x)[0].cpu()
+    want = io.fid_features(sd, x)
+    assert got.shape == want.shape == (3, 2048, 1, 1)
+    err = rel_l2(got, want)
+    print("FID pool3 features vs oracle", err)
+    assert err < 2e-4
+    # earlier blocks (64 / 192 / 768-channel feature maps of pytorch_fid)
+    maps = dm.InceptionV3([0, 1, 2], state_dict=sd, device=DEV)(x)
+    assert [tuple(m.shape[1:]) for m in maps] == [(64, 73, 73), (192, 35, 35), (768, 17, 17)]
+    tv = dm.InceptionV3(variant="torchvision", state_dict=sd, device=DEV)
+    xs = x * 2 - 1  # the evaluator accepts [-1, 1]
+    xn = (F.interpolate((xs + 1) / 2, size=(299, 299), mode="bilinear", align_corners=False)
+          - torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    err = rel_l2(tv.logits(xn).cpu(), io.is_logits(sd, xs))
+    print("torchvision logits vs oracle", err)
+    assert err < 2e-4
+
+
+@pytest.mark.gpu
+def test_evaluators_end_to_end(tmp_path):
+    """FIDEvaluation / InceptionScoreEvaluation with the reference's call pattern (fid_evaluation.py:106-133,
+    inception_score_evaluation.py:52-104) against the same statistics computed from the oracle's features."""
+    sd = dm.synth_state_dict(inception_param_spec(), salt=0)
+
+    class Sampler:
+        def eval(self):
+            return self
+
+    g = torch.Generator().manual_seed(11)
+    real = [torch.rand(4, 3, 32, 32, generator=g) for _ in range(3)]
+    fake = torch.rand(12, 3, 32, 32, generator=g) * 0.8
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # explicit weights: no synthetic-weight warning
+        fid = dm.FIDEvaluation(4, iter(real), Sampler(), stats_dir=str(tmp_path), device=DEV, num_fid_samples=12,
+                               inception_state_dict=sd)
+        ise = dm.InceptionScoreEvaluation(4, Sampler(), stats_dir=str(tmp_path), device=DEV, num_samples=12,
+                                          inception_state_dict=sd)
+    got = fid.fid_score(fake)
+    fr = torch.cat([io.fid_features(sd, r)[:, :, 0, 0] for r in real]).numpy()
+    ff = io.fid_features(sd, fake)[:, :, 0, 0].numpy()
+    want = io.frechet_distance(ff.mean(0), np.cov(ff, rowvar=False), fr.mean(0), np.cov(fr, rowvar=False))
+    print("FID", got, want)
+    assert abs(got - want) <= 2e-3 * abs(want) + 1e-3
+    assert (tmp_path / "dataset_stats.npz").exists()
+    got_is = ise.calculate_inception_score(fake * 2 - 1)
+    want_is = io.inception_score(torch.softmax(io.is_logits(sd, fake * 2 - 1), dim=1))
+    print("IS", got_is, want_is)
+    assert abs(got_is - want_is) <= 1e-3 * want_is
+    with pytest.warns(UserWarning):
+        dm.InceptionV3([0], device=DEV)  # no weights given: synthetic, loudly
