@@ -678,6 +678,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
             re.row_in_wg0 = wm * 64;
             re.wn = wn;
             re.all_valid = (p.Cout % NT) == 0;
+            // everything the epilogue reads from global memory -- the residual rows included (res_conv and the
+            // attention projections add one: 64 KB per workgroup whose latency was exposed row by row, 16 k of the
+            // 85 k cycles of a 128->64 res_conv workgroup) -- is requested before the accumulators go through LDS
+            RowsPrefetch<16, true> pf;
+            rows_prefetch<16, true>(p, re, pixv, cg, cvalid, pf);
             float* T = smem + wave * (64 * TS);
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -690,10 +695,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
             f32x4 v[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const f32x4*>(T + (4 * j + rsub) * TS + c4);
-            // the per-cout operands of the epilogue are requested together, ahead of their use
-            RowsPrefetch<16, false> pf;
-            rows_prefetch<16, false>(p, re, pixv, cg, cvalid, pf);
-            rows_epilogue<WN, 16, false>(p, re, v, pixv, cg, cvalid, pf);
+            rows_epilogue<WN, 16, true>(p, re, v, pixv, cg, cvalid, pf);
             DM_STAMP_ADD(6)
             DM_STAMP_FLUSH
             return;
