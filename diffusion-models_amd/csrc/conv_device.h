@@ -6,6 +6,22 @@
 namespace dm {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// Workgroup -> (cout tile, pixel block).  The dispatcher deals workgroups to the 8 XCDs round-robin by linear id and
+// each XCD has its own L2.  With the cout tile as the fastest index an XCD always works on the same cout tile (its L2
+// keeps that tile's weights), but in raw order the pixel blocks of an XCD are 8 / n_tiles_n apart, so the halo a block
+// shares with its neighbours is fetched from HBM by each of them (F(2x2) at 32x32: the 8 blocks of an image sit on 8
+// XCDs, 1.41x the input bytes).  With xcd_groups = 8 / n_tiles_n > 0 the XCDs that share a cout tile split the pixel
+// blocks into contiguous ranges instead: neighbours run on the same XCD at about the same time.  The host sets
+// xcd_groups only when gridDim.x % 8 == 0 (K splits in blockIdx.y then keep the XCD assignment) and n_tiles_n | 8.
+__device__ __forceinline__ void block_to_tile(const ConvGeom& g, int bid, int nblk, int& n_tile, int& pblock) {
+    n_tile = bid % g.n_tiles_n;
+    pblock = bid / g.n_tiles_n;
+    if (g.xcd_groups > 0) {
+        const int per = (nblk / g.n_tiles_n) / g.xcd_groups;  // pixel blocks per XCD group
+        pblock = (pblock % g.xcd_groups) * per + pblock / g.xcd_groups;
+    }
+}
 // 16-byte staging values are NATIVE vectors, not HIP's float4 struct: arrays of the struct are copied with
 // llvm.memcpy between address spaces, which keeps them in scratch memory (one synchronous round trip per
 // global load) instead of registers.

@@ -63,6 +63,7 @@ struct ConvGeom {
     int row_stride;      // winograd: LDS floats per window row
     int magic_win, magic_row;  // winograd: ceil(2^24 / (IH*IW)), ceil(2^24 / IW): divisions of the window setup
     int lds_bytes;
+    int xcd_groups;      // 3x3 kernels: XCDs that share a cout tile (8 / n_tiles_n), 0 = blocks in raw order
 };
 
 struct ConvParams {

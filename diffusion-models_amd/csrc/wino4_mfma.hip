@@ -241,9 +241,8 @@ __global__ __launch_bounds__(256, 1) void wino4_mfma_kernel(const ConvParams p) 
     // Block order: the cout tile is the fastest index and blocks are dealt round-robin over the 8 XCDs, so with 2, 4 or 8
     // cout tiles an XCD always works on the same tile(s): its L2 holds that tile's weights for all pixel blocks (the
     // deep layers are weight-streaming: 37.7 MB of transformed weights against 4 MB of activations at 512 channels).
-    int bid = blockIdx.x;
-    const int n_tile = bid % g.n_tiles_n;
-    bid /= g.n_tiles_n;
+    int n_tile, bid;
+    block_to_tile(g, blockIdx.x, gridDim.x, n_tile, bid);
     const int tile_x = bid % g.tiles_x;
     bid /= g.tiles_x;
     const int tile_y = bid % g.tiles_y;
@@ -634,6 +633,9 @@ int wino4_launch(const ConvParams& pin, hipStream_t s) {
     DM_REQUIRE(g.lds_bytes <= 160 * 1024, "winograd4: tile does not fit LDS");
     DM_REQUIRE(p.chunks0 == p.C0 / W4CK && p.n_chunks == (p.C0 + p.C1) / W4CK, "winograd4: chunk counts");
     const int blocks = g.n_tiles_n * g.tiles_x * g.tiles_y * g.groups;
+    // XCD-aware block order (conv_device.h: block_to_tile); DM_NO_XCD_ORDER=1 keeps the raw order for A/B runs
+    static const bool xcd_order = w4_env_int("DM_NO_XCD_ORDER", 0) == 0;
+    p.geo.xcd_groups = (xcd_order && blocks % 8 == 0 && 8 % g.n_tiles_n == 0) ? 8 / g.n_tiles_n : 0;
     const bool timed = prof::enabled();
     if (timed) {
         // priced as the reference's op: 2*9*Cin*Cout*pixels FLOP; the kernel executes 36/144 of the

@@ -156,9 +156,8 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
     const int l31 = lane & 31;
     const int lh = lane >> 5;
 
-    int bid = blockIdx.x;
-    const int n_tile = bid % g.n_tiles_n;
-    bid /= g.n_tiles_n;
+    int n_tile, bid;
+    block_to_tile(g, blockIdx.x, gridDim.x, n_tile, bid);
     const int tile_x = bid % g.tiles_x;
     bid /= g.tiles_x;
     const int tile_y = bid % g.tiles_y;
@@ -565,6 +564,9 @@ int wino_launch(const ConvParams& pin, hipStream_t s) {
     DM_REQUIRE(g.lds_bytes <= 160 * 1024, "winograd: tile does not fit LDS");
     DM_REQUIRE(p.chunks0 == p.C0 / WCK && p.n_chunks == (p.C0 + p.C1) / WCK, "winograd: chunk counts");
     const int blocks = g.n_tiles_n * g.tiles_x * g.tiles_y * g.groups;
+    // XCD-aware block order (conv_device.h: block_to_tile); DM_NO_XCD_ORDER=1 keeps the raw order for A/B runs
+    static const bool xcd_order = w_env_int("DM_NO_XCD_ORDER", 0) == 0;
+    p.geo.xcd_groups = (xcd_order && blocks % 8 == 0 && 8 % g.n_tiles_n == 0) ? 8 / g.n_tiles_n : 0;
     const bool timed = prof::enabled();
     if (timed) {
         // priced as the reference's op: 2*9*Cin*Cout*pixels FLOP; the kernel executes 16/36 of
