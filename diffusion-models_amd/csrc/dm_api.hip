@@ -183,6 +183,7 @@ struct ConvLayer {
     float* w = nullptr;
     float* ww = nullptr;  // Winograd-transformed weights (winograd_mfma.hip) when the layer is eligible
     float* ww4 = nullptr;  // F(4x4,3x3) transformed weights (wino4_mfma.hip)
+    float* wwu = nullptr;  // transformed weights of the upsample + 3x3 algorithm (upwino_mfma.hip)
     float* wraw = nullptr;  // (Cout, Cin) weights of a 1x1 conv with Cout <= 4 (pointwise_small_kernel)
     float* bias = nullptr;
 };
@@ -378,6 +379,12 @@ static int make_conv(DeviceOwner& own, ConvLayer& L, const float* oihw, const fl
         std::vector<float> wp(wino4_packed_floats(Cout, C0, C1));
         wino4_pack_weights(oihw, wp.data(), Cout, C0, C1);
         if (own.upload(wp.data(), wp.size(), &L.ww4)) return 1;
+    }
+    L.wwu = nullptr;
+    if (upwino_eligible(Cout, C0, C1, KH, KW, stride, pad, up)) {
+        std::vector<float> wp(upwino_packed_floats(Cout, C0, C1));
+        upwino_pack_weights(oihw, wp.data(), Cout, C0, C1);
+        if (own.upload(wp.data(), wp.size(), &L.wwu)) return 1;
     }
     L.wraw = nullptr;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && !up && Cout <= 4 && C1 == 0 && C0 % 4 == 0 &&
@@ -664,7 +671,19 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
     p.residual = residual; p.g = g; p.scale = scale; p.ss_stride = c.ss_stride;
     const bool want_norm = (epi & EPI_NORM) != 0;
     int out_h, out_w;  // dims of the output tensor
-    if (L.fold) {
+    const bool upwino = L.up && L.wwu && !in_nchw && !out_nchw && in1 == nullptr && Hin % 2 == 0 && Win % 2 == 0 &&
+                        upwino_shape_ok(c.B, Hin / 2, Win / 2, L.Cout, L.C0, L.C1);
+    if (upwino) {
+        // (Hin, Win) is the upsampled size the caller sees; the kernel works on the source grid (upwino_mfma.hip)
+        p.fold = 0; p.fold_w_stride = 0; p.up = 1;
+        p.KH = 3; p.KW = 3;
+        p.Hin = Hin / 2; p.Win = Win / 2;
+        p.Ho = Hin; p.Wo = Win;
+        out_h = Hin; out_w = Win;
+        p.w = L.wwu;
+        p.chunks0 = p.n_chunks = L.C0 / 8;
+        p.geo = upwino_plan(c.B, p.Hin, p.Win, L.Cout, L.C0, L.C1, true);
+    } else if (L.fold) {
         // (Hin, Win) is the upsampled size the caller sees; the four parity convs run on the source grid
         DM_REQUIRE(!out_nchw && !in_nchw, "folded upsample conv is NHWC");
         p.fold = 1; p.fold_w_stride = L.fold_w_stride; p.up = 0;
@@ -702,9 +721,9 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
     }
     // 3x3 / stride 1 convolutions run as Winograd F(4x4,3x3) on power-of-two images, else as F(2x2,3x3), when the layer
     // has transformed weights
-    const bool wino4 = L.ww4 && !L.fold && !in_nchw && !out_nchw && padw == L.pad &&
+    const bool wino4 = !upwino && L.ww4 && !L.fold && !in_nchw && !out_nchw && padw == L.pad &&
                        wino4_shape_ok(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
-    const bool wino = !wino4 && L.ww && !L.fold && !in_nchw && !out_nchw && padw == L.pad &&
+    const bool wino = !upwino && !wino4 && L.ww && !L.fold && !in_nchw && !out_nchw && padw == L.pad &&
                       wino_use(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
     if (wino4) {
         p.w = L.ww4;
@@ -717,7 +736,10 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
         p.n_chunks = (L.C0 + L.C1) / 8;
         p.geo = wino_plan(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1, true);
     }
-    auto launch = [&](const ConvParams& q) { return wino4 ? wino4_launch(q, c.s) : (wino ? wino_launch(q, c.s) : conv_launch(q, c.s)); };
+    auto launch = [&](const ConvParams& q) {
+        return upwino ? upwino_launch(q, c.s)
+                      : (wino4 ? wino4_launch(q, c.s) : (wino ? wino_launch(q, c.s) : conv_launch(q, c.s)));
+    };
     const int full_epi = epi | (L.bias ? EPI_BIAS : 0);
     const bool in_kernel = p.geo.splits == 1 && (!want_norm || p.geo.fused_norm);
     if (in_kernel) {

@@ -68,6 +68,15 @@ CONV_CASES = [
     (2, 8, 0, 6, 2, 64, 3, 1, False, True, False),        # single K chunk, image narrower than a tile row
     (2, 1024, 0, 4, 4, 64, 3, 1, False, True, False),     # Winograd with K split 8 ways (partial sums + finalize)
     (1, 1024, 0, 2, 2, 64, 3, 1, False, True, False),     # 2x2 image: window too large for Winograd -> direct kernel
+    # nearest x2 + 3x3 on the source grid (upwino_mfma.hip; C % 8 == 0, Cout % 64 == 0, source 4x4 or multiples of 8).
+    # Small shapes reach it only with DM_UPWINO_MIN_WGS=1 DM_UPWINO_MIN_K=1 (tests/test_hip_forced_dispatch.py),
+    # otherwise they check the folded direct kernel
+    (2, 64, 0, 8, 8, 64, 3, 1, True, True, False),        # one 8x8 block per image
+    (3, 128, 0, 16, 16, 128, 3, 1, True, True, True),     # 2x2 blocks, two cout tiles, residual
+    (5, 64, 0, 4, 4, 128, 3, 1, True, True, False),       # four 4x4 images per workgroup, ragged batch
+    (2, 512, 0, 4, 4, 64, 3, 1, True, True, False),       # K split (partial sums + finalize)
+    (1, 16, 0, 8, 24, 64, 3, 1, True, False, False),      # non-square source, two chunks, no bias
+    (40, 128, 0, 16, 16, 64, 3, 1, True, True, False),    # 160 workgroups of 16 chunks: production dispatch
     # the direct 3x3 kernel behind it (odd sizes are not Winograd-eligible)
     (2, 64, 64, 7, 9, 64, 3, 1, False, True, True),
     (3, 256, 0, 5, 5, 256, 3, 1, False, True, False),
