@@ -650,14 +650,27 @@ static bool wino_use(int B, int Ho, int Wo, int Cout, int C0, int C1) {
     return mode != 0 && wino_shape_ok(B, Ho, Wo, Cout, C0, C1);
 }
 
-static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* in1, int Hin, int Win, float* out,
-                    int epi, const float* g, const float* scale, const float* residual, bool in_nchw = false,
-                    bool out_nchw = false) {
-    // One convolution with its epilogue (epi = EPI_* requested by the caller; bias is implied by the layer).
-    // The plan decides whether the epilogue runs inside the conv kernel (one workgroup owns all couts of a
-    // pixel and K is not split) or in norm_act_kernel on the raw / K-split partial sums.
-    ConvParams p{};
-    p.in0 = in0; p.in1 = in1; p.C0 = L.C0; p.C1 = L.C1;
+// residual operand of a landing pass given as the K-split partial sums of another convolution (+ its bias)
+struct ResParts {
+    const float* part;
+    int nsplit;
+    int64_t stride;
+    const float* bias;
+};
+
+struct PlannedConv {
+    ConvParams p;      // everything but the tensor pointers
+    int out_h, out_w;  // dims of the output tensor
+    int kind;          // 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3), 3 upsample algorithm, 4 one thread per pixel
+    bool in_kernel;    // the epilogue runs inside the conv kernel (else: partial sums + landing kernel)
+};
+
+// Which kernel and tiling a convolution takes; a function of the layer, the batch and the image size only.
+static int plan_conv(const Ctx& c, const ConvLayer& L, bool has_in1, int Hin, int Win, int epi, bool in_nchw, bool out_nchw,
+                     PlannedConv& P) {
+    ConvParams& p = P.p;
+    p = ConvParams{};
+    p.C0 = L.C0; p.C1 = L.C1;
     const int CK = conv_ck_for(L.C0, L.C1);
     p.chunks0 = (L.C0 + CK - 1) / CK;
     p.n_chunks = p.chunks0 + (L.C1 ? (L.C1 + CK - 1) / CK : 0);
@@ -668,10 +681,10 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
     p.pad_w = padw;
     p.B = c.B;
     p.out_nchw = out_nchw ? 1 : 0;
-    p.residual = residual; p.g = g; p.scale = scale; p.ss_stride = c.ss_stride;
+    p.ss_stride = c.ss_stride;
     const bool want_norm = (epi & EPI_NORM) != 0;
-    int out_h, out_w;  // dims of the output tensor
-    const bool upwino = L.up && L.wwu && !in_nchw && !out_nchw && in1 == nullptr && Hin % 2 == 0 && Win % 2 == 0 &&
+    P.kind = 0;
+    const bool upwino = L.up && L.wwu && !in_nchw && !out_nchw && !has_in1 && Hin % 2 == 0 && Win % 2 == 0 &&
                         upwino_shape_ok(c.B, Hin / 2, Win / 2, L.Cout, L.C0, L.C1);
     if (upwino) {
         // (Hin, Win) is the upsampled size the caller sees; the kernel works on the source grid (upwino_mfma.hip)
@@ -679,10 +692,11 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
         p.KH = 3; p.KW = 3;
         p.Hin = Hin / 2; p.Win = Win / 2;
         p.Ho = Hin; p.Wo = Win;
-        out_h = Hin; out_w = Win;
+        P.out_h = Hin; P.out_w = Win;
         p.w = L.wwu;
         p.chunks0 = p.n_chunks = L.C0 / 8;
         p.geo = upwino_plan(c.B, p.Hin, p.Win, L.Cout, L.C0, L.C1, true);
+        P.kind = 3;
     } else if (L.fold) {
         // (Hin, Win) is the upsampled size the caller sees; the four parity convs run on the source grid
         DM_REQUIRE(!out_nchw && !in_nchw, "folded upsample conv is NHWC");
@@ -690,7 +704,7 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
         p.KH = 2; p.KW = 2; p.pad_w = 1;
         p.Hin = Hin / 2; p.Win = Win / 2;
         p.Ho = p.Hin; p.Wo = p.Win;
-        out_h = Hin; out_w = Win;
+        P.out_h = Hin; P.out_w = Win;
         p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, 2, 2, 1, L.C0, L.C1, want_norm, true, 4);
     } else if (L.KH == 2 && L.KW == 2 && L.stride == 2 && L.pad == 0 && !L.up && L.C1 == 0 && L.C0 % 16 == 0 &&
                !in_nchw && Hin % 2 == 0 && Win % 2 == 0) {
@@ -700,7 +714,7 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
         p.Ho = Hin / 2; p.Wo = Win / 2;
         p.Hin = p.Ho; p.Win = p.Wo;
         p.chunks0 = p.n_chunks = 4 * (L.C0 / 16);
-        out_h = p.Ho; out_w = p.Wo;
+        P.out_h = p.Ho; P.out_w = p.Wo;
         p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, 1, 1, 1, 4 * L.C0, 0, want_norm && !out_nchw, !out_nchw);
     } else {
         p.fold = 0; p.fold_w_stride = 0; p.up = L.up ? 1 : 0;
@@ -709,64 +723,115 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
         // the kernel zero-fills every window pixel outside the image, so bottom / right padding is only an output size
         p.Ho = (Hin + 2 * L.pad + L.pad_hi - L.KH) / L.stride + 1;
         p.Wo = (Win + 2 * padw + L.pad_hi - L.KW) / L.stride + 1;
-        out_h = p.Ho; out_w = p.Wo;
+        P.out_h = p.Ho; P.out_w = p.Wo;
         p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, L.KH, L.KW, L.stride, L.C0, L.C1, want_norm && !out_nchw,
                           !out_nchw);
     }
-    if (L.wraw && out_nchw && !in_nchw && in1 == nullptr && epi == 0) {
+    if (L.wraw && out_nchw && !in_nchw && !has_in1 && epi == 0) {
         // a handful of output channels (final_conv): one pixel per thread instead of a 64-column MFMA tile
-        if (c.dry()) return 0;
-        return launch_pointwise_small(in0, L.wraw, L.bias, out, (int64_t)c.B * p.Ho * p.Wo, L.C0, L.Cout, p.Ho * p.Wo,
-                                      c.s);
+        P.kind = 4;
+        P.in_kernel = true;
+        return 0;
     }
     // 3x3 / stride 1 convolutions run as Winograd F(4x4,3x3) on power-of-two images, else as F(2x2,3x3), when the layer
     // has transformed weights
-    const bool wino4 = !upwino && L.ww4 && !L.fold && !in_nchw && !out_nchw && padw == L.pad &&
+    const bool wino4 = P.kind == 0 && L.ww4 && !L.fold && !in_nchw && !out_nchw && padw == L.pad &&
                        wino4_shape_ok(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
-    const bool wino = !upwino && !wino4 && L.ww && !L.fold && !in_nchw && !out_nchw && padw == L.pad &&
+    const bool wino = P.kind == 0 && !wino4 && L.ww && !L.fold && !in_nchw && !out_nchw && padw == L.pad &&
                       wino_use(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
     if (wino4) {
         p.w = L.ww4;
         p.chunks0 = L.C0 / 8;
         p.n_chunks = (L.C0 + L.C1) / 8;
         p.geo = wino4_plan(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1, true);
+        P.kind = 2;
     } else if (wino) {
         p.w = L.ww;
         p.chunks0 = L.C0 / 8;
         p.n_chunks = (L.C0 + L.C1) / 8;
         p.geo = wino_plan(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1, true);
+        P.kind = 1;
     }
-    auto launch = [&](const ConvParams& q) {
-        return upwino ? upwino_launch(q, c.s)
-                      : (wino4 ? wino4_launch(q, c.s) : (wino ? wino_launch(q, c.s) : conv_launch(q, c.s)));
-    };
+    P.in_kernel = p.geo.splits == 1 && (!want_norm || p.geo.fused_norm);
+    return 0;
+}
+
+static int launch_planned(const PlannedConv& P, const ConvParams& q, hipStream_t s) {
+    switch (P.kind) {
+        case 3: return upwino_launch(q, s);
+        case 2: return wino4_launch(q, s);
+        case 1: return wino_launch(q, s);
+        default: return conv_launch(q, s);
+    }
+}
+
+static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* in1, int Hin, int Win, float* out,
+                    int epi, const float* g, const float* scale, const float* residual, bool in_nchw = false,
+                    bool out_nchw = false, const ResParts* res_parts = nullptr) {
+    // One convolution with its epilogue (epi = EPI_* requested by the caller; bias is implied by the layer).
+    // The plan decides whether the epilogue runs inside the conv kernel (one workgroup owns all couts of a
+    // pixel and K is not split) or in norm_act_kernel on the raw / K-split partial sums.  res_parts: the residual
+    // is the sum of another convolution's partial tiles (only on the landing path; the caller asks plan_conv first).
+    PlannedConv P;
+    if (plan_conv(c, L, in1 != nullptr, Hin, Win, epi, in_nchw, out_nchw, P)) return 1;
+    ConvParams& p = P.p;
+    p.in0 = in0; p.in1 = in1;
+    p.residual = residual; p.g = g; p.scale = scale;
+    if (P.kind == 4) {
+        if (c.dry()) return 0;
+        return launch_pointwise_small(in0, L.wraw, L.bias, out, (int64_t)c.B * p.Ho * p.Wo, L.C0, L.Cout, p.Ho * p.Wo,
+                                      c.s);
+    }
     const int full_epi = epi | (L.bias ? EPI_BIAS : 0);
-    const bool in_kernel = p.geo.splits == 1 && (!want_norm || p.geo.fused_norm);
-    if (in_kernel) {
+    if (P.in_kernel) {
+        DM_REQUIRE(!res_parts, "residual partial sums need the landing pass");
         if (c.dry()) return 0;
         p.out = out; p.partial = 0; p.epi = full_epi;
-        return launch(p);
+        return launch_planned(P, p, c.s);
     }
     DM_REQUIRE(!out_nchw, "split / unfused epilogue writes NHWC");
-    const size_t M = (size_t)c.B * out_h * out_w;
+    const size_t M = (size_t)c.B * P.out_h * P.out_w;
     float* part = c.A->alloc((size_t)p.geo.splits * M * L.Cout);
     if (c.dry()) {
         c.A->release(part);
         return 0;
     }
     p.out = part; p.partial = 1; p.epi = 0;
-    if (launch(p)) return 1;
-    const int rc = launch_norm_act(part, p.geo.splits, (int64_t)(M * L.Cout), L.bias, g, scale, c.ss_stride, out_h * out_w,
-                                   residual, out, (int64_t)M, L.Cout, full_epi, c.s);
+    if (launch_planned(P, p, c.s)) return 1;
+    int rc;
+    if (res_parts)
+        rc = launch_norm_act(part, p.geo.splits, (int64_t)(M * L.Cout), L.bias, g, scale, c.ss_stride, P.out_h * P.out_w,
+                             res_parts->part, out, (int64_t)M, L.Cout, full_epi | EPI_RESIDUAL, c.s, res_parts->nsplit,
+                             res_parts->stride, res_parts->bias);
+    else
+        rc = launch_norm_act(part, p.geo.splits, (int64_t)(M * L.Cout), L.bias, g, scale, c.ss_stride, P.out_h * P.out_w,
+                             residual, out, (int64_t)M, L.Cout, full_epi, c.s);
     c.A->release(part);
     return rc;
 }
 
+// The raw K-split partial sums of a convolution (no bias, no epilogue) for a consumer that lands them itself:
+// *part = [nsplit][B*Ho*Wo][Cout], allocated here, released by the caller.
+static int run_conv_partial(Ctx& c, const ConvLayer& L, const float* in0, const float* in1, int Hin, int Win, float** part,
+                            int* nsplit) {
+    PlannedConv P;
+    if (plan_conv(c, L, in1 != nullptr, Hin, Win, 0, false, false, P)) return 1;
+    DM_REQUIRE(P.kind != 4, "partial sums of a pointwise-small layer");
+    ConvParams& p = P.p;
+    p.in0 = in0; p.in1 = in1;
+    const size_t M = (size_t)c.B * P.out_h * P.out_w;
+    *part = c.A->alloc((size_t)p.geo.splits * M * L.Cout);
+    *nsplit = p.geo.splits;
+    if (c.dry()) return 0;
+    p.out = *part; p.partial = 1; p.epi = 0;
+    return launch_planned(P, p, c.s);
+}
+
 // Block.forward: conv3x3 -> RMSNorm -> (scale+1, shift) -> SiLU [-> + residual]
 static int run_block(Ctx& c, const ConvLayer& L, const float* in0, const float* in1, int H, int W, const float* g,
-                     const float* scale, const float* residual, float* out) {
+                     const float* scale, const float* residual, float* out, const ResParts* res_parts = nullptr) {
     int flags = EPI_NORM | EPI_SILU | (scale ? EPI_SCALE_SHIFT : 0) | (residual ? EPI_RESIDUAL : 0);
-    return run_conv(c, L, in0, in1, H, W, out, flags, g, scale, residual);
+    return run_conv(c, L, in0, in1, H, W, out, flags, g, scale, residual, false, false, res_parts);
 }
 
 // ResnetBlock.forward (DD/denoising_diffusion.py:136-148); x = cat(x0, x1)
@@ -778,6 +843,25 @@ static int run_resnet(Ctx& c, const ResBlock& R, const float* x0, const float* x
     if (run_block(c, R.c1, x0, x1, H, W, R.g1, scale, nullptr, h1)) return 1;
     if (!R.has_res) {
         if (run_block(c, R.c2, h1, nullptr, H, W, R.g2, nullptr, x0, h2)) return 1;
+        c.A->release(h1);
+        *out = h2;
+        return 0;
+    }
+    // block2(h1) + res_conv(x).  When both convolutions leave partial sums for a landing pass anyway (several cout
+    // tiles under one RMSNorm, or K splits), one landing serves both: it finishes block2 and adds the res_conv partials.
+    static const bool merge = std::getenv("DM_NO_RES_MERGE") == nullptr;
+    PlannedConv P2, Pr;
+    if (plan_conv(c, R.c2, false, H, W, EPI_NORM | EPI_SILU, false, false, P2)) return 1;
+    if (plan_conv(c, R.res, x1 != nullptr, H, W, EPI_RESIDUAL, false, false, Pr)) return 1;
+    if (merge && !P2.in_kernel && !Pr.in_kernel && Pr.kind != 4) {
+        ResParts rp{};
+        float* rpart = nullptr;
+        if (run_conv_partial(c, R.res, x0, x1, H, W, &rpart, &rp.nsplit)) return 1;
+        rp.part = rpart;
+        rp.stride = (int64_t)n;
+        rp.bias = R.res.bias;
+        if (run_block(c, R.c2, h1, nullptr, H, W, R.g2, nullptr, nullptr, h2, &rp)) return 1;
+        c.A->release(rpart);
         c.A->release(h1);
         *out = h2;
         return 0;

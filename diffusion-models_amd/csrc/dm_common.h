@@ -168,9 +168,11 @@ int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipSt
 int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t s);
 // v = sum_{s<nsplit} x[s*split_stride + row*C + c] [+ bias[c]];
 // y = [silu]( rmsnorm(v)*g*sqrt(C) [*(scale+1)+shift] ) [+ residual]; rows = pixels; flags = EPI_*
+// the residual may itself be K-split partial sums of a convolution: sum_{s<res_nsplit} residual[s*res_stride + ...] + res_bias[c]
 int launch_norm_act(const float* x, int nsplit, int64_t split_stride, const float* bias, const float* g,
                     const float* scale, int ss_stride, int pix_per_image, const float* residual, float* y,
-                    int64_t rows, int C, int flags, hipStream_t s);
+                    int64_t rows, int C, int flags, hipStream_t s, int res_nsplit = 1, int64_t res_stride = 0,
+                    const float* res_bias = nullptr);
 // y[r][o] = act_out(bias[o] + sum_i act_in(x[r][i]) * W[o][i]);  act: 0 none, 1 silu, 2 gelu(erf)
 int launch_linear_rows(const float* x, int ldx, const float* W, const float* bias, float* y, int ldy, int R, int I,
                        int O, int act_in, int act_out, hipStream_t s);

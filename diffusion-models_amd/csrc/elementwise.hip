@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const float* __restrict__
                                                        const float* __restrict__ bias, const float* __restrict__ g,
                                                        const float* __restrict__ scale, int ss_stride,
                                                        int pix_per_image, const float* __restrict__ residual,
-                                                       float* __restrict__ y, int64_t rows, int C, int flags) {
+                                                       float* __restrict__ y, int64_t rows, int C, int flags,
+                                                       int res_nsplit, int64_t res_stride,
+                                                       const float* __restrict__ res_bias) {
     const int lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -98,7 +100,12 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const float* __restrict__
         if (flags & EPI_SCALE_SHIFT) v = v * (sp[c] + 1.0f) + sp[C + c];
         if (flags & EPI_SILU) v = silu_f(v);
         if (flags & EPI_RELU) v = fmaxf(v, 0.0f);
-        if (flags & EPI_RESIDUAL) v += residual[row * C + c];
+        if (flags & EPI_RESIDUAL) {
+            float r = residual[row * C + c];
+            for (int sp2 = 1; sp2 < res_nsplit; ++sp2) r += residual[(size_t)sp2 * res_stride + row * C + c];
+            if (res_bias) r += res_bias[c];
+            v += r;
+        }
         yr[c] = v;
     };
     if constexpr (MAXV > 0) {
@@ -120,7 +127,9 @@ __global__ __launch_bounds__(256) void norm_act_vec_kernel(const float* __restri
                                                            const float* __restrict__ g,
                                                            const float* __restrict__ scale, int ss_stride,
                                                            int pix_per_image, const float* __restrict__ residual,
-                                                           float* __restrict__ y, int64_t rows, int flags) {
+                                                           float* __restrict__ y, int64_t rows, int flags,
+                                                           int res_nsplit, int64_t res_stride,
+                                                           const float* __restrict__ res_bias) {
     constexpr int C = 4 * L * NV;
     constexpr int RPW = 64 / L;  // rows per wavefront
     const int lane = threadIdx.x & 63;
@@ -167,23 +176,31 @@ __global__ __launch_bounds__(256) void norm_act_vec_kernel(const float* __restri
             t.z = fmaxf(t.z, 0.f);
             t.w = fmaxf(t.w, 0.f);
         }
-        if (flags & EPI_RESIDUAL) t += *reinterpret_cast<const f32x4v*>(residual + row * C + c);
+        if (flags & EPI_RESIDUAL) {
+            const float* rp = residual + row * C + c;
+            f32x4v r = *reinterpret_cast<const f32x4v*>(rp);
+            for (int sp2 = 1; sp2 < res_nsplit; ++sp2) r += *reinterpret_cast<const f32x4v*>(rp + (size_t)sp2 * res_stride);
+            if (res_bias) r += *reinterpret_cast<const f32x4v*>(res_bias + c);
+            t += r;
+        }
         *reinterpret_cast<f32x4v*>(y + row * C + c) = t;
     }
 }
 
 int launch_norm_act(const float* x, int nsplit, int64_t split_stride, const float* bias, const float* g,
                     const float* scale, int ss_stride, int pix_per_image, const float* residual, float* y,
-                    int64_t rows, int C, int flags, hipStream_t s) {
+                    int64_t rows, int C, int flags, hipStream_t s, int res_nsplit, int64_t res_stride,
+                    const float* res_bias) {
 #define DM_NORM_VEC(L_, NV_)                                                                                       \
     {                                                                                                              \
         const int64_t rpb = 4 * (64 / L_);                                                                         \
         hipLaunchKernelGGL((norm_act_vec_kernel<L_, NV_>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, s, x, nsplit, \
-                           split_stride, bias, g, scale, ss_stride, pix_per_image, residual, y, rows, flags);     \
+                           split_stride, bias, g, scale, ss_stride, pix_per_image, residual, y, rows, flags,      \
+                           res_nsplit, res_stride, res_bias);                                                      \
         DM_CHECK_HIP(hipGetLastError());                                                                           \
         return 0;                                                                                                  \
     }
-    const bool aligned = (split_stride % 4 == 0) && (ss_stride % 4 == 0);
+    const bool aligned = (split_stride % 4 == 0) && (ss_stride % 4 == 0) && (res_stride % 4 == 0);
     if (aligned) {
         if (C == 64) DM_NORM_VEC(16, 1)
         if (C == 128) DM_NORM_VEC(32, 1)
@@ -195,13 +212,13 @@ int launch_norm_act(const float* x, int nsplit, int64_t split_stride, const floa
     dim3 grid((rows + 3) / 4), block(256);
     if (C <= 128)
         hipLaunchKernelGGL(norm_act_kernel<2>, grid, block, 0, s, x, nsplit, split_stride, bias, g, scale, ss_stride,
-                           pix_per_image, residual, y, rows, C, flags);
+                           pix_per_image, residual, y, rows, C, flags, res_nsplit, res_stride, res_bias);
     else if (C <= 512)
         hipLaunchKernelGGL(norm_act_kernel<8>, grid, block, 0, s, x, nsplit, split_stride, bias, g, scale, ss_stride,
-                           pix_per_image, residual, y, rows, C, flags);
+                           pix_per_image, residual, y, rows, C, flags, res_nsplit, res_stride, res_bias);
     else
         hipLaunchKernelGGL(norm_act_kernel<0>, grid, block, 0, s, x, nsplit, split_stride, bias, g, scale, ss_stride,
-                           pix_per_image, residual, y, rows, C, flags);
+                           pix_per_image, residual, y, rows, C, flags, res_nsplit, res_stride, res_bias);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
