@@ -266,9 +266,11 @@ def main():
         kern = []
         for r in rows:
             avg_ms = r["total_ms"] / r["launches"]
-            # the rows are priced as the reference's direct convolution; a Winograd kernel's own matrix work is a fraction
-            # of that count: F(4x4,3x3) multiplies 36 times per 4x4 outputs (36/144), F(2x2,3x3) 16 times per 2x2 (16/36)
-            executed = 0.25 if r["kernel"].startswith("wino4") else (16.0 / 36.0 if r["kernel"].startswith("wino") else 1.0)
+            # the rows are priced as the reference's direct convolution; a Winograd-type kernel's own matrix work is a
+            # fraction of that count.  Multiply-adds the kernel executes per multiply-add of the direct 3x3 convolution it is priced as:
+            # F(4x4,3x3) 36/144, upsample algorithm 9/36 (per output pixel), F(2x2,3x3) 16/36
+            k = r["kernel"]
+            executed = 0.25 if k.startswith(("wino4", "upwino")) else (16.0 / 36.0 if k.startswith("wino") else 1.0)
             tf_direct = r["total_flops"] / (r["total_ms"] * 1e-3) / 1e12
             kern.append({"kernel": r["kernel"], "launches_per_unet_fwd": r["launches"] // 4,
                          "avg_ms": avg_ms, "mfma_tflops": tf_direct * executed,
