@@ -184,6 +184,7 @@ struct ConvLayer {
     float* ww = nullptr;  // Winograd-transformed weights (winograd_mfma.hip) when the layer is eligible
     float* ww4 = nullptr;  // F(4x4,3x3) transformed weights (wino4_mfma.hip)
     float* wwu = nullptr;  // transformed weights of the upsample + 3x3 algorithm (upwino_mfma.hip)
+    float* wpw = nullptr;  // lane-ordered weights of the 1x1 GEMM kernel (pw_mfma.hip)
     float* wraw = nullptr;  // (Cout, Cin) weights of a 1x1 conv with Cout <= 4 (pointwise_small_kernel)
     float* bias = nullptr;
 };
@@ -385,6 +386,12 @@ static int make_conv(DeviceOwner& own, ConvLayer& L, const float* oihw, const fl
         std::vector<float> wp(upwino_packed_floats(Cout, C0, C1));
         upwino_pack_weights(oihw, wp.data(), Cout, C0, C1);
         if (own.upload(wp.data(), wp.size(), &L.wwu)) return 1;
+    }
+    L.wpw = nullptr;
+    if (pw_eligible(Cout, C0, C1, KH, KW, stride, pad, up)) {
+        std::vector<float> wp(pw_packed_floats(Cout, C0, C1));
+        pw_pack_weights(oihw, wp.data(), Cout, C0, C1);
+        if (own.upload(wp.data(), wp.size(), &L.wpw)) return 1;
     }
     L.wraw = nullptr;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && !up && Cout <= 4 && C1 == 0 && C0 % 4 == 0 &&
@@ -661,7 +668,7 @@ struct ResParts {
 struct PlannedConv {
     ConvParams p;      // everything but the tensor pointers
     int out_h, out_w;  // dims of the output tensor
-    int kind;          // 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3), 3 upsample algorithm, 4 one thread per pixel
+    int kind;          // 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3), 3 upsample algorithm, 4 one thread per pixel, 5 1x1 GEMM
     bool in_kernel;    // the epilogue runs inside the conv kernel (else: partial sums + landing kernel)
 };
 
@@ -739,7 +746,15 @@ static int plan_conv(const Ctx& c, const ConvLayer& L, bool has_in1, int Hin, in
                        wino4_shape_ok(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
     const bool wino = P.kind == 0 && !wino4 && L.ww && !L.fold && !in_nchw && !out_nchw && padw == L.pad &&
                       wino_use(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
-    if (wino4) {
+    const bool pw = P.kind == 0 && L.wpw && !L.fold && !p.s2d && !in_nchw && !out_nchw && L.pad_hi == 0 && padw == 0 &&
+                    pw_shape_ok(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
+    if (pw) {
+        p.w = L.wpw;
+        p.chunks0 = L.C0 / 8;
+        p.n_chunks = (L.C0 + L.C1) / 8;
+        p.geo = pw_plan(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1, true);
+        P.kind = 5;
+    } else if (wino4) {
         p.w = L.ww4;
         p.chunks0 = L.C0 / 8;
         p.n_chunks = (L.C0 + L.C1) / 8;
@@ -758,6 +773,7 @@ static int plan_conv(const Ctx& c, const ConvLayer& L, bool has_in1, int Hin, in
 
 static int launch_planned(const PlannedConv& P, const ConvParams& q, hipStream_t s) {
     switch (P.kind) {
+        case 5: return pw_launch(q, s);
         case 3: return upwino_launch(q, s);
         case 2: return wino4_launch(q, s);
         case 1: return wino_launch(q, s);

@@ -139,6 +139,15 @@ ConvGeom wino4_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_
 bool wino4_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1);
 int wino4_launch(const ConvParams& p, hipStream_t s);
 
+// 1x1 convolution as a register-direct GEMM (pw_mfma.hip): NHWC, one or two sources, C % 8 == 0, Cout % 64 == 0;
+// w = pw_pack_weights, chunks of 8 input channels.
+bool pw_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up);
+size_t pw_packed_floats(int Cout, int C0, int C1);
+void pw_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1);
+ConvGeom pw_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_split);
+bool pw_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1);
+int pw_launch(const ConvParams& p, hipStream_t s);
+
 // Nearest x2 upsampling + 3x3 convolution as a 9-multiply bilinear algorithm per source pixel (upwino_mfma.hip):
 // (B, Hl, Wl) is the SOURCE tensor, the output is (B, 2 Hl, 2 Wl).  ConvParams: up = 1, Hin / Win = source size,
 // Ho / Wo = output size, w = upwino_pack_weights, chunks of 8 input channels, single source (C1 == 0).

@@ -1,0 +1,255 @@
+// 1x1 convolutions (res_conv DD/denoising_diffusion.py:134, the to_qkv / to_out projections of the attention layers
+// :163-170 / :209-213, the VAE's nin_shortcut and q / k / v / proj_out) as a register-direct GEMM on
+// v_mfma_f32_32x32x2_f32:  out[pixel][cout] = sum_c in[pixel][c] W[cout][c]   over one or two NHWC sources.
+//
+// A 1x1 convolution has no window, so neither MFMA operand needs LDS: lane (row l31, half lh) of a wave loads the 16
+// bytes in[pixel l31][8 chunk + 4 lh .. + 3] (A) and W'[chunk][cout tile][lane][0..3] (B, packed on the host in exactly
+// that order) and feeds component j of both to MFMA step j -- the K index of a step is the channel 8 chunk + 4 lh + j,
+// a fixed permutation of the reduction.  No staging loads, no barriers, no LDS traffic in the loop; four chunks are in
+// flight per wave and several workgroups share a CU.  (The generic kernel conv_mfma.hip stages a pixel window and the
+// weights through LDS for every 16 channels: at these shapes less than half of its time is MFMA issue.)
+// One wave = 64 pixels x 64 couts (2 x 2 MFMA tiles, 64 accumulators); one workgroup = 4 waves as 256 px x 64 couts
+// (WGN = 1) or 128 px x 128 couts (WGN = 2).  Epilogue: the shared row epilogue (conv_device.h) after a per-wave
+// transposition through LDS, 32 pixel rows at a time.
+#include "conv_device.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace dm {
+
+static constexpr int PWCK = 8;   // input channels per K chunk
+static constexpr int PWTS = 68;  // row stride (floats) of the epilogue staging tile
+static constexpr int PWD = 4;    // chunks in flight per wave (2 waves per SIMD; measured: 3, 4 and 6 in flight equal, 3 waves per SIMD with spills slower)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pw_rsrc(const float* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)min(bytes, (size_t)0xFFFFFFFFu),
+                                             0x00020000);
+}
+__device__ __forceinline__ f32x4 pw_bufload4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, (int)soff_bytes, 0));
+}
+
+static inline int pw_env_int(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
+}
+
+bool pw_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up) {
+    static const bool off = std::getenv("DM_NO_PW") != nullptr;
+    return !off && KH == 1 && KW == 1 && stride == 1 && pad == 0 && !up && C0 > 0 && C0 % PWCK == 0 && C1 % PWCK == 0 &&
+           Cout % 64 == 0;
+}
+
+size_t pw_packed_floats(int Cout, int C0, int C1) { return (size_t)(C0 + C1) * Cout; }
+
+// oihw = (Cout, C0 + C1) -> [chunk of 8 channels][cout tile of 32][lane = 32 lh + l31][j 4] = W[32 t + l31][8 chunk + 4 lh + j]
+void pw_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1) {
+    const int Cin = C0 + C1;
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci) {
+            const int chunk = ci / PWCK, cc = ci % PWCK, lh = cc / 4, j = cc % 4;
+            const int t = co / 32, l31 = co % 32;
+            packed[(((size_t)chunk * (Cout / 32) + t) * 64 + lh * 32 + l31) * 4 + j] = oihw[(size_t)co * Cin + ci];
+        }
+}
+
+// M = output pixels (B * Ho * Wo)
+ConvGeom pw_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_split) {
+    ConvGeom g{};
+    const size_t M = (size_t)B * Ho * Wo;
+    g.WN = Cout % 128 == 0 ? 2 : 1;
+    g.WM = 4 / g.WN;
+    g.CK = PWCK;
+    g.TW = g.TH = g.NB = 1;
+    g.tiles_x = (int)((M + 64 * g.WM - 1) / (64 * g.WM));  // pixel blocks
+    g.tiles_y = 1;
+    g.groups = 1;
+    g.n_tiles_n = Cout / (64 * g.WN);
+    g.TPS = 1;
+    const int n_chunks = (C0 + C1) / PWCK;
+    const int wgs = g.tiles_x * g.n_tiles_n;
+    int splits = 1;
+    if (allow_split) {
+        static const int target = pw_env_int("DM_PW_TARGET_WGS", 256);
+        static const int min_chunks = pw_env_int("DM_PW_MIN_CHUNKS", 16);
+        while (wgs * splits < target && splits < 8 && n_chunks / (splits * 2) >= min_chunks) splits *= 2;
+    }
+    g.chunks_per_split = (n_chunks + splits - 1) / splits;
+    g.splits = (n_chunks + g.chunks_per_split - 1) / g.chunks_per_split;
+    g.fused_norm = Cout == 64 && g.splits == 1;
+    g.lds_bytes = 4 * 32 * PWTS * 4;
+    return g;
+}
+
+bool pw_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1) {
+    const size_t M = (size_t)B * Ho * Wo;
+    return M > 0 && M < (1u << 24) && M * (size_t)std::max(Cout, std::max(C0, C1)) < (1ull << 30);
+}
+
+template <int WGN>
+__global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
+    constexpr int WGM = 4 / WGN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const ConvGeom& g = p.geo;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+    const int wn = wave % WGN, wm = wave / WGN;
+
+    int n_blk, m_blk;
+    block_to_tile(g, blockIdx.x, gridDim.x, n_blk, m_blk);
+    const int ct = n_blk * WGN + wn;  // 64-cout tile of this wave
+    const unsigned M = (unsigned)((size_t)p.B * p.Ho * p.Wo);
+    const unsigned px0 = ((unsigned)m_blk * WGM + wm) * 64u;
+    const int split = blockIdx.y;
+    const int cb = split * g.chunks_per_split;
+    const int ce = min(cb + g.chunks_per_split, p.n_chunks);
+
+    // ---- operand addressing: A rows of this lane (clamped: rows past the tensor load row M - 1 and are never stored)
+    const __amdgpu_buffer_rsrc_t rs_in0 = pw_rsrc(p.in0, (size_t)M * p.C0 * 4);
+    const __amdgpu_buffer_rsrc_t rs_in1 = pw_rsrc(p.C1 ? p.in1 : p.in0, (size_t)M * (p.C1 ? p.C1 : p.C0) * 4);
+    unsigned avo0[2], avo1[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const unsigned px = min(px0 + 32u * r + (unsigned)l31, M - 1u);
+        avo0[r] = (__umul24(px, (unsigned)p.C0) + 4u * lh) * 4u;
+        avo1[r] = (__umul24(px, (unsigned)p.C1) + 4u * lh) * 4u;
+    }
+    const size_t w_chunk = (size_t)p.Cout * PWCK;  // floats per chunk
+    const __amdgpu_buffer_rsrc_t rs_w = pw_rsrc(p.w, (size_t)p.n_chunks * w_chunk * 4);
+    const unsigned wvo = (unsigned)(((2 * ct) * 64 + lane) * 4 * 4);  // cout tile 2 ct; tile 2 ct + 1 is 1024 bytes on
+
+    f32x4 a[PWD][2], b[PWD][2];
+    auto load = [&](int c, int d) {
+        const bool s1 = c >= p.chunks0;
+        const unsigned so = (unsigned)(s1 ? c - p.chunks0 : c) * (PWCK * 4);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) a[d][r] = pw_bufload4(s1 ? rs_in1 : rs_in0, s1 ? avo1[r] : avo0[r], so);
+        const unsigned wo = (unsigned)c * (unsigned)(w_chunk * 4);
+        b[d][0] = pw_bufload4(rs_w, wvo, wo);
+        b[d][1] = pw_bufload4(rs_w, wvo + 1024u, wo);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][q][e] = 0.f;
+
+#pragma unroll
+    for (int d = 0; d < PWD; ++d) load(min(cb + d, ce - 1), d);
+    for (int c = cb; c < ce; c += PWD) {
+#pragma unroll
+        for (int d = 0; d < PWD; ++d) {
+            if (c + d < ce) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+                            acc[r][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][r][j], b[d][q][j], acc[r][q], 0, 0, 0);
+                if (c + d + PWD < ce) load(c + d + PWD, d);
+            }
+        }
+    }
+
+    // ---- epilogue: 32 pixel rows (one MFMA row tile) at a time through this wave's staging tile
+    const int rsub = lane >> 4;
+    const int c4 = (lane & 15) * 4;
+    const int cg = ct * 64 + c4;
+    const bool cvalid = cg < p.Cout;
+    RowsEpilogue re;
+    re.split = split;
+    re.M = (size_t)M;
+    re.b0 = 0;
+    re.uni = p.ss_stride == 0;
+    re.HoWo = p.Ho * p.Wo;
+    re.red = nullptr;
+    re.rows_per_wg = 0;
+    re.row_in_wg0 = 0;
+    re.wn = 0;
+    re.all_valid = true;
+    float* T = smem + (size_t)wave * 32 * PWTS;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        int pixv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned px = px0 + 32u * r + 4u * j + (unsigned)rsub;
+            pixv[j] = px < M ? (int)px : -1;
+        }
+        RowsPrefetch<8, true> pf;
+        rows_prefetch<8, true>(p, re, pixv, cg, cvalid, pf);
+        // accumulator register e of lane (l31, lh): row (e & 3) + 8 (e >> 2) + 4 lh, column l31
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) T[((e & 3) + 8 * (e >> 2) + 4 * lh) * PWTS + q * 32 + l31] = acc[r][q][e];
+        __builtin_amdgcn_wave_barrier();
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(T + (4 * j + rsub) * PWTS + c4);
+        __builtin_amdgcn_wave_barrier();
+        rows_epilogue<1, 8, true>(p, re, v, pixv, cg, cvalid, pf);
+    }
+}
+
+template <int WGN>
+static int pw_launch_t(const ConvParams& p, int blocks, hipStream_t s) {
+    hipLaunchKernelGGL(pw_mfma_kernel<WGN>, dim3(blocks, p.geo.splits, 1), dim3(256), p.geo.lds_bytes, s, p);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int pw_launch(const ConvParams& pin, hipStream_t s) {
+    ConvParams p = pin;
+    p.stamps = nullptr;
+    const ConvGeom& g = p.geo;
+    DM_REQUIRE(p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && !p.up && !p.fold && !p.s2d, "pointwise: plain 1x1 only");
+    DM_REQUIRE(!p.in_nchw && !p.out_nchw, "pointwise: NHWC only");
+    DM_REQUIRE(p.C0 % PWCK == 0 && p.C1 % PWCK == 0 && p.Cout % 64 == 0, "pointwise: channel counts");
+    DM_REQUIRE(p.Hin == p.Ho && p.Win == p.Wo, "pointwise: same-size convolution");
+    const size_t M = (size_t)p.B * p.Ho * p.Wo;
+    DM_REQUIRE(M > 0 && M < (1u << 24) && M * (size_t)std::max(p.Cout, std::max(p.C0, p.C1)) < (1ull << 30),
+               "pointwise: tensor too large for 24-bit pixel indices");
+    DM_REQUIRE((g.WN == 1 || g.WN == 2) && g.WM * g.WN == 4 && p.Cout % (64 * g.WN) == 0 &&
+                   g.n_tiles_n == p.Cout / (64 * g.WN) && (size_t)g.tiles_x * 64 * g.WM >= M &&
+                   (size_t)(g.tiles_x - 1) * 64 * g.WM < M,
+               "pointwise: plan does not match the tensor");
+    DM_REQUIRE(!(p.epi & EPI_NORM) || (p.Cout == 64 && g.splits == 1), "pointwise: fused RMSNorm needs all couts in one wave");
+    DM_REQUIRE(g.splits == 1 || p.partial, "pointwise: split-K writes partial sums");
+    DM_REQUIRE(p.chunks0 == p.C0 / PWCK && p.n_chunks == (p.C0 + p.C1) / PWCK, "pointwise: chunk counts");
+    DM_REQUIRE(g.splits * g.chunks_per_split >= p.n_chunks && (g.splits - 1) * g.chunks_per_split < p.n_chunks,
+               "pointwise: K split does not cover the chunks");
+    DM_REQUIRE(g.lds_bytes >= 4 * 32 * PWTS * 4, "pointwise: LDS size");
+    const int blocks = g.n_tiles_n * g.tiles_x;
+    static const bool xcd_order = pw_env_int("DM_NO_XCD_ORDER", 0) == 0;
+    p.geo.xcd_groups = (xcd_order && blocks % 8 == 0 && 8 % g.n_tiles_n == 0) ? 8 / g.n_tiles_n : 0;
+    const bool timed = prof::enabled();
+    if (timed) {
+        const double pix = (double)M, cin = p.C0 + p.C1;
+        const double flops = 2.0 * cin * p.Cout * pix;
+        const double bytes = 4.0 * (cin * pix + p.Cout * pix + cin * p.Cout);
+        char name[64];
+        if (prof::detail())
+            snprintf(name, sizeof(name), "pw<%d> 1x1 %d+%d->%d @%dx%d e%d k%d", g.WN, p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.epi,
+                     g.splits);
+        else
+            snprintf(name, sizeof(name), "pw_mfma_kernel<%d>", g.WN);
+        if (prof::begin(name, flops, bytes, s)) return 1;
+    }
+    const int rc = g.WN == 2 ? pw_launch_t<2>(p, blocks, s) : pw_launch_t<1>(p, blocks, s);
+    if (rc) return 1;
+    if (timed && prof::end(s)) return 1;
+    return 0;
+}
+
+}  // namespace dm

@@ -77,6 +77,13 @@ CONV_CASES = [
     (2, 512, 0, 4, 4, 64, 3, 1, True, True, False),       # K split (partial sums + finalize)
     (1, 16, 0, 8, 24, 64, 3, 1, True, False, False),      # non-square source, two chunks, no bias
     (40, 128, 0, 16, 16, 64, 3, 1, True, True, False),    # 160 workgroups of 16 chunks: production dispatch
+    # 1x1 GEMM kernel (pw_mfma.hip; C % 8 == 0, Cout % 64 == 0): res_conv / attention projections
+    (3, 64, 64, 10, 6, 64, 1, 0, False, True, True),      # two sources + residual, 180 pixels (ragged last rows)
+    (2, 512, 256, 4, 4, 512, 1, 0, False, True, True),    # res_conv of the deepest stage: 96 chunks, K split, 4 cout blocks
+    (5, 256, 0, 8, 8, 384, 1, 0, False, False, False),    # to_qkv: three 128-cout blocks, no bias
+    (1, 8, 0, 2, 2, 64, 1, 0, False, True, False),        # one chunk, four pixels
+    (7, 72, 8, 16, 16, 128, 1, 0, False, True, False),    # chunk boundary of the concat inside the prefetch ring
+    (2, 64, 0, 8, 8, 192, 1, 0, False, True, False),      # 192 couts: three 64-cout blocks (InceptionV3 branches)
     # the direct 3x3 kernel behind it (odd sizes are not Winograd-eligible)
     (2, 64, 64, 7, 9, 64, 3, 1, False, True, True),
     (3, 256, 0, 5, 5, 256, 3, 1, False, True, False),
