@@ -202,6 +202,8 @@ struct AttnLayer {
     float *norm_g = nullptr, *mem_kv = nullptr, *out_g = nullptr;
     ConvLayer qkv, out;
     bool has_fused = false;  // LinearAttention as two fused kernels (linattn_fused.hip)
+    bool has16 = false;      // full attention over 16 tokens as one kernel (attn16_fused.hip)
+    Attn16 a16{};
     LinAttnFused fused{};
 };
 
@@ -490,6 +492,16 @@ static int build_attn_body(dm_unet* u, AttnLayer& A, const std::string& p, int d
     if (full) {
         if (make_conv(u->own, A.out, P(u, p + ".to_out.weight").data.data(), P(u, p + ".to_out.bias").data.data(), dim,
                       hidden, 0, 1, 1, 1, 0, false)) return 1;
+        A.has16 = false;
+        if (attn16_eligible(dim, u->heads, u->dh)) {
+            std::vector<float> wp, wo;
+            attn16_pack(P(u, p + ".to_qkv.weight").data.data(), P(u, p + ".norm.g").data.data(),
+                        P(u, p + ".to_out.weight").data.data(), dim, wp, wo);
+            float *dwp, *dwo;
+            if (u->own.upload(wp.data(), wp.size(), &dwp) || u->own.upload(wo.data(), wo.size(), &dwo)) return 1;
+            A.a16 = Attn16{dim, dwp, dwo, A.out.bias, A.mem_kv};
+            A.has16 = true;
+        }
     } else {
         if (make_conv(u->own, A.out, P(u, p + ".to_out.0.weight").data.data(), P(u, p + ".to_out.0.bias").data.data(),
                       dim, hidden, 0, 1, 1, 1, 0, false)) return 1;
@@ -903,6 +915,12 @@ static int run_attn(Ctx& c, const AttnLayer& At, const float* x, int H, int W, f
         float* yf = c.A->alloc(rows * At.dim);
         if (!c.dry() && launch_linattn_fused(At.fused, x, ws, yf, c.B, n, add_x, c.s)) return 1;
         c.A->release(ws);
+        *out = yf;
+        return 0;
+    }
+    if (At.full && At.has16 && n == 16) {
+        float* yf = c.A->alloc(rows * At.dim);
+        if (!c.dry() && launch_attn16_fused(At.a16, x, yf, c.B, add_x, c.s)) return 1;
         *out = yf;
         return 0;
     }

@@ -148,6 +148,20 @@ ConvGeom pw_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_spl
 bool pw_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1);
 int pw_launch(const ConvParams& p, hipStream_t s);
 
+// Full self-attention over 16 tokens (a 4x4 feature map) as one kernel (attn16_fused.hip): RMSNorm, to_qkv, memory
+// key/values, softmax, to_out + bias [+ x].  x, y: (B, 16, C) NHWC.
+struct Attn16 {
+    int C;
+    const float* wp;      // attn16_pack: projection weights in lane order (gain, sqrt(C) and the softmax scale folded in)
+    const float* wo;      // attn16_pack: to_out weights in lane order
+    const float* bias;    // to_out bias (C)
+    const float* mem_kv;  // (2, 4, 4, 32) as the reference stores it
+};
+bool attn16_eligible(int dim, int heads, int dh);
+void attn16_pack(const float* w_qkv, const float* norm_g, const float* w_out, int C, std::vector<float>& wp,
+                 std::vector<float>& wo);
+int launch_attn16_fused(const Attn16& w, const float* x, float* y, int B, bool add_x, hipStream_t s);
+
 // Nearest x2 upsampling + 3x3 convolution as a 9-multiply bilinear algorithm per source pixel (upwino_mfma.hip):
 // (B, Hl, Wl) is the SOURCE tensor, the output is (B, 2 Hl, 2 Wl).  ConvParams: up = 1, Hin / Win = source size,
 // Ho / Wo = output size, w = upwino_pack_weights, chunks of 8 input channels, single source (C1 == 0).
