@@ -76,23 +76,45 @@ __global__ __launch_bounds__(256) void attn16_fused_kernel(const float* __restri
     const int l15 = lane & 15, kq = lane >> 4;
     const size_t img = blockIdx.x;
 
-    // ---- x^ = x / max(|x|, 1e-12) -> LDS: 16 threads (one DPP row) per token
+    // ---- projection weights of this head: a ring of A16_D iterations, requested before anything else (they do not
+    //      depend on x); tile order in a ring slot: q0 q1 k0 k1 v0 v1
+    const int S = C / 16;
+    const float* wl = w.wp + (size_t)lane * 4;
+    f32x4 wr[A16_D][6];
+    auto load = [&](int s, int d) {
+        const float* ws = wl + (size_t)s * (24 * 256);
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                wr[d][2 * part + t] = *reinterpret_cast<const f32x4*>(ws + (8 * part + 2 * h + t) * 256);
+    };
+#pragma unroll
+    for (int d = 0; d < A16_D; ++d) load(min(d, S - 1), d);
+
+    // ---- x^ = x / max(|x|, 1e-12) -> LDS: 16 threads (one DPP row) per token, the row held in registers (C <= 1024)
     {
         const int token = tid >> 4, li = tid & 15;
         const float* xr = x + (img * 16 + token) * C;
+        f32x4 xv[16];
         float ss = 0.f;
-        for (int c = 4 * li; c < C; c += 64) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
-            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = 4 * li + 64 * i;
+            if (c < C) {
+                xv[i] = *reinterpret_cast<const f32x4*>(xr + c);
+                ss += xv[i].x * xv[i].x + xv[i].y * xv[i].y + xv[i].z * xv[i].z + xv[i].w * xv[i].w;
+            }
         }
         ss += dpp_f<0xB1>(ss);
         ss += dpp_f<0x4E>(ss);
         ss += dpp_f<0x141>(ss);
         ss += dpp_f<0x140>(ss);
         const float rn = fast_rsq(fmaxf(ss, 1e-24f));
-        for (int c = 4 * li; c < C; c += 64) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
-            *reinterpret_cast<f32x4*>(xs + token * XS + c) = v * rn;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = 4 * li + 64 * i;
+            if (c < C) *reinterpret_cast<f32x4*>(xs + token * XS + c) = xv[i] * rn;
         }
     }
     __syncthreads();
@@ -101,20 +123,6 @@ __global__ __launch_bounds__(256) void attn16_fused_kernel(const float* __restri
     const f32x4 z4 = make_f32x4(0.f, 0.f, 0.f, 0.f);
     f32x4 qT[2] = {z4, z4}, kT[2] = {z4, z4}, vv[2] = {z4, z4};
     {
-        const int S = C / 16;
-        const float* wl = w.wp + (size_t)lane * 4;
-        // tile order in a ring slot: q0 q1 k0 k1 v0 v1
-        f32x4 wr[A16_D][6];
-        auto load = [&](int s, int d) {
-            const float* ws = wl + (size_t)s * (24 * 256);
-#pragma unroll
-            for (int part = 0; part < 3; ++part)
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    wr[d][2 * part + t] = *reinterpret_cast<const f32x4*>(ws + (8 * part + 2 * h + t) * 256);
-        };
-#pragma unroll
-        for (int d = 0; d < A16_D; ++d) load(min(d, S - 1), d);
         const float* xrow = xs + l15 * XS + 4 * kq;
         for (int s = 0; s < S; s += A16_D) {
 #pragma unroll
@@ -135,6 +143,23 @@ __global__ __launch_bounds__(256) void attn16_fused_kernel(const float* __restri
             }
         }
     }
+
+    // ---- to_out weights: wave h finishes the output channels [h C/4, (h + 1) C/4), four 16-channel tiles per pass, K = 128
+    //      = 8 iterations per pass; a ring of 4 iterations over the flattened (pass, s) index, started here so that the
+    //      first loads fly during the softmax
+    const int CT = C / 16;
+    const int ct_per_wave = CT / 4;
+    const int n_it = (ct_per_wave / 4) * 8;
+    const float* wol = w.wo + (size_t)lane * 4;
+    f32x4 wv4[4][4];
+    auto load_o = [&](int it, int slot) {
+        const int c0 = (it >> 3) * 4, so = it & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            wv4[slot][i] = *reinterpret_cast<const f32x4*>(wol + ((size_t)so * CT + h * ct_per_wave + c0 + i) * 256);
+    };
+#pragma unroll
+    for (int d = 0; d < 4; ++d) load_o(d, d);
 
     // ---- scores, keys on the rows: S^T = k q^T (16 keys) and the 4 memory keys (rows 0..3 of a second tile)
     const float* mk = w.mem_kv + (size_t)h * 4 * 32;
@@ -197,22 +222,17 @@ __global__ __launch_bounds__(256) void attn16_fused_kernel(const float* __restri
     f32x4 ob[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) ob[s] = *reinterpret_cast<const f32x4*>(ol + l15 * A16_OS + 16 * s + 4 * kq);
-    const int CT = C / 16;
-    const int ct_per_wave = CT / 4;
-    const float* wol = w.wo + (size_t)lane * 4;
     const size_t row = (img * 16 + l15) * C;  // this lane's token
     for (int c0 = 0; c0 < ct_per_wave; c0 += 4) {
         f32x4 acc[4] = {z4, z4, z4, z4};
+        const int it0 = (c0 >> 2) * 8;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            f32x4 wv4[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                wv4[i] = *reinterpret_cast<const f32x4*>(wol + ((size_t)s * CT + h * ct_per_wave + c0 + i) * 256);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = a16_mfma(wv4[i][j], ob[s][j], acc[i]);
+                for (int i = 0; i < 4; ++i) acc[i] = a16_mfma(wv4[s & 3][i][j], ob[s][j], acc[i]);
+            if (it0 + s + 4 < n_it) load_o(it0 + s + 4, s & 3);
         }
         // D tile: rows = channels 16 ct + 4 kq + e, columns = tokens: four consecutive channels of token l15 per lane
 #pragma unroll
