@@ -210,6 +210,7 @@ struct AttnLayer {
 struct CrossLayer {
     ConvLayer q, out;
     float *wk = nullptr, *wv = nullptr, *g = nullptr;
+    float* wo_raw = nullptr;  // to_out.0.weight as stored (dim, inner): the one-context-token path runs it per image
 };
 
 struct Stage {
@@ -552,7 +553,8 @@ static int build_cross_body(dm_unet* u, CrossLayer& C, const std::string& p, int
     if (make_conv(u->own, C.q, P(u, p + ".to_q.weight").data.data(), nullptr, inner, dim, 0, 1, 1, 1, 0, false)) return 1;
     if (make_conv(u->own, C.out, P(u, p + ".to_out.0.weight").data.data(), P(u, p + ".to_out.0.bias").data.data(), dim,
                   inner, 0, 1, 1, 1, 0, false)) return 1;
-    if (up1(u, p + ".to_k.weight", &C.wk) || up1(u, p + ".to_v.weight", &C.wv) || up1(u, p + ".to_out.1.g", &C.g))
+    if (up1(u, p + ".to_k.weight", &C.wk) || up1(u, p + ".to_v.weight", &C.wv) || up1(u, p + ".to_out.1.g", &C.g) ||
+        up1(u, p + ".to_out.0.weight", &C.wo_raw))
         return 1;
     return 0;
 }
@@ -960,6 +962,29 @@ static int run_cross(Ctx& c, const CrossLayer& Cr, const float* x, int H, int W,
     dm_unet* u = c.u;
     const int n = H * W, inner = 4 * u->dh, dim = Cr.out.Cout, E = u->cfg.text_emb_dim;
     const size_t rows = (size_t)c.B * n;
+    static const bool one_token_path = std::getenv("DM_NO_CROSS1") == nullptr;
+    if (m == 1 && one_token_path) {
+        // One context token (what every sampler of the reference passes: (B, 512) -> (B, 1, 512), :57-58): the softmax
+        // over a single key is exactly 1.0, so every query's output is v and the q / k projections drop out.  The layer
+        // is z_b = RMSNorm1D(to_out(to_v(ctx_b))) spread over the pixels of image b -- three row-per-image launches and
+        // one broadcast instead of two 1x1 convolutions over every pixel and an attention core.
+        float* v = c.A->alloc((size_t)c.B * inner);
+        float* yb = c.A->alloc((size_t)c.B * dim);
+        float* zb = c.A->alloc((size_t)c.B * dim);
+        float* y = c.A->alloc(rows * dim);
+        if (!c.dry()) {
+            if (launch_linear_rows(ctx, E, Cr.wv, nullptr, v, inner, c.B, E, inner, 0, 0, c.s)) return 1;
+            if (launch_linear_rows(v, inner, Cr.wo_raw, Cr.out.bias, yb, dim, c.B, inner, dim, 0, 0, c.s)) return 1;
+            if (launch_norm_act(yb, 1, 0, nullptr, Cr.g, nullptr, 0, 1, nullptr, zb, (int64_t)c.B, dim, EPI_NORM, c.s))
+                return 1;
+            if (launch_broadcast_rows(zb, y, (int)rows, dim, dim, c.s, n)) return 1;
+        }
+        c.A->release(v);
+        c.A->release(yb);
+        c.A->release(zb);
+        *out = y;
+        return 0;
+    }
     float* q = c.A->alloc(rows * inner);
     float* k = c.A->alloc((size_t)c.B * m * inner);
     float* v = c.A->alloc((size_t)c.B * m * inner);

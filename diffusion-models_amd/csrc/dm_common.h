@@ -244,7 +244,8 @@ int launch_sampler_update(int kind, const float* x, const float* eps, const floa
 int launch_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, uint64_t element_offset, hipStream_t s);
 int launch_step_advance(SamplerState* state_dev, hipStream_t s);
 int launch_finalize(const float* x, float* out, int64_t n, int unnormalize, hipStream_t s);
-int launch_broadcast_rows(const float* src, float* dst, int rows, int n, int ld, hipStream_t s);
+int launch_broadcast_rows(const float* src, float* dst, int rows, int n, int ld, hipStream_t s, int group = 0);
+// (group > 0: source row r / group feeds destination row r; 0: one source row for all)
 
 // ---------------------------------------------------------------------------------------
 // Attention cores (attention.hip); qkv is NHWC (B, n, 3*heads*dh) = [q | k | v] per pixel

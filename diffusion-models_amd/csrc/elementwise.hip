@@ -373,17 +373,21 @@ int launch_copy_channels(const float* src, float* dst, int B, int Cs, int Cd, in
 }
 // dst[r][0..n) = src[0..n) for r < rows (dst rows ld floats apart): the time embedding of a sampler step in front
 // of every row of the text-concat input (DD/denoising_diffusion_text_conditional.py:146-152), one launch
-__global__ void broadcast_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int ld, int64_t total) {
+// With group < rows: source row r / group serves destination row r (one vector per image spread over its pixels: the
+// CrossAttention layer with a single context token, DD/denoising_diffusion_text_conditional.py:54-78).
+__global__ void broadcast_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int ld, int64_t total,
+                                      int group) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int64_t r = i / n;
     const int c = (int)(i - r * n);
-    dst[r * ld + c] = src[c];
+    dst[r * ld + c] = src[(r / group) * n + c];
 }
-int launch_broadcast_rows(const float* src, float* dst, int rows, int n, int ld, hipStream_t s) {
+int launch_broadcast_rows(const float* src, float* dst, int rows, int n, int ld, hipStream_t s, int group) {
     const int64_t total = (int64_t)rows * n;
     if (total == 0) return 0;
-    hipLaunchKernelGGL(broadcast_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, dst, n, ld, total);
+    if (group <= 0) group = rows;
+    hipLaunchKernelGGL(broadcast_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, dst, n, ld, total, group);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
