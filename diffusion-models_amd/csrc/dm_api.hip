@@ -1016,6 +1016,10 @@ static int unet_forward_impl(dm_unet* u, Arena& A, const float* x_nchw, const in
     const int td = u->time_dim;
     const bool text_concat = cfg.text_mode == DM_TEXT_CONCAT && ctx != nullptr;
     const bool text_cross = cfg.text_mode == DM_TEXT_CROSS && ctx != nullptr;
+    // one context token: the three CrossAttention layers ignore their image input (run_cross), which makes everything
+    // between the last skip connection and cross_attn_up dead code (DM_NO_CROSS1 computes it anyway)
+    static const bool cross1 = std::getenv("DM_NO_CROSS1") == nullptr;
+    const bool dead_bottleneck = text_cross && ctx_tokens == 1 && cross1;
     // the time embedding is one row when the whole batch shares t (samplers), else one row per sample
     const int Bt = (step_times && !text_concat) ? 1 : B;
     const int Rt = step_times ? 1 : B;  // rows of the sinusoid / time_mlp
@@ -1084,17 +1088,30 @@ static int unet_forward_impl(dm_unet* u, Arena& A, const float* x_nchw, const in
         rel(b2);
         skips.push_back(at);
         int ho = (i < n_st - 1) ? h / 2 : h, wo = (i < n_st - 1) ? w / 2 : w;
+        if (i == n_st - 1 && dead_bottleneck) {  // its only consumer is a CrossAttention that ignores x (see below)
+            cur = nullptr;
+            break;
+        }
         float* d = A.alloc((size_t)B * ho * wo * S.resample.Cout);
         if (run_conv(c, S.resample, at, nullptr, h, w, d, 0, nullptr, nullptr, nullptr)) return 1;
         cur = d; h = ho; w = wo;
     }
     float* t0;
-    if (text_cross) { if (run_cross(c, u->cross_down, cur, h, w, ctx, ctx_tokens, &t0)) return 1; rel(cur); cur = t0; }
-    if (run_resnet(c, u->mid1, cur, nullptr, h, w, &t0)) return 1; rel(cur); cur = t0;
-    if (text_cross) { if (run_cross(c, u->cross_mid, cur, h, w, ctx, ctx_tokens, &t0)) return 1; rel(cur); cur = t0; }
-    if (run_attn(c, u->mid_attn, cur, h, w, &t0)) return 1; rel(cur); cur = t0;
-    if (run_resnet(c, u->mid2, cur, nullptr, h, w, &t0)) return 1; rel(cur); cur = t0;
-    if (text_cross) { if (run_cross(c, u->cross_up, cur, h, w, ctx, ctx_tokens, &t0)) return 1; rel(cur); cur = t0; }
+    if (dead_bottleneck) {
+        // CrossAttention REPLACES x (:173-177, :187-191, :199-203), and with one context token its output does not depend
+        // on x at all (run_cross): cross_attn_down discards the last down conv, cross_attn discards mid_block1,
+        // cross_attn_up discards mid_attn and mid_block2.  None of that work can reach the output, so the up path starts
+        // from cross_attn_up(ctx); the skip connections carry the image signal, exactly as in the reference.
+        if (run_cross(c, u->cross_up, nullptr, h, w, ctx, ctx_tokens, &t0)) return 1;
+        cur = t0;
+    } else {
+        if (text_cross) { if (run_cross(c, u->cross_down, cur, h, w, ctx, ctx_tokens, &t0)) return 1; rel(cur); cur = t0; }
+        if (run_resnet(c, u->mid1, cur, nullptr, h, w, &t0)) return 1; rel(cur); cur = t0;
+        if (text_cross) { if (run_cross(c, u->cross_mid, cur, h, w, ctx, ctx_tokens, &t0)) return 1; rel(cur); cur = t0; }
+        if (run_attn(c, u->mid_attn, cur, h, w, &t0)) return 1; rel(cur); cur = t0;
+        if (run_resnet(c, u->mid2, cur, nullptr, h, w, &t0)) return 1; rel(cur); cur = t0;
+        if (text_cross) { if (run_cross(c, u->cross_up, cur, h, w, ctx, ctx_tokens, &t0)) return 1; rel(cur); cur = t0; }
+    }
     for (int j = 0; j < n_st; ++j) {
         Stage& S = u->ups[j];
         float *a, *b2, *at;
