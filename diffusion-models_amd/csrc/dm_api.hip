@@ -764,8 +764,8 @@ static int plan_conv(const Ctx& c, const ConvLayer& L, bool has_in1, int Hin, in
                     pw_shape_ok(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
     if (pw) {
         p.w = L.wpw;
-        p.chunks0 = L.C0 / 8;
-        p.n_chunks = (L.C0 + L.C1) / 8;
+        p.chunks0 = L.C0 / 16;
+        p.n_chunks = (L.C0 + L.C1) / 16;
         p.geo = pw_plan(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1, true);
         P.kind = 5;
     } else if (wino4) {

@@ -1,16 +1,18 @@
 // 1x1 convolutions (res_conv DD/denoising_diffusion.py:134, the to_qkv / to_out projections of the attention layers
 // :163-170 / :209-213, the VAE's nin_shortcut and q / k / v / proj_out) as a register-direct GEMM on
-// v_mfma_f32_32x32x2_f32:  out[pixel][cout] = sum_c in[pixel][c] W[cout][c]   over one or two NHWC sources.
+// v_mfma_f32_16x16x4_f32:  out[pixel][cout] = sum_c in[pixel][c] W[cout][c]   over one or two NHWC sources.
 //
-// A 1x1 convolution has no window, so neither MFMA operand needs LDS: lane (row l31, half lh) of a wave loads the 16
-// bytes in[pixel l31][8 chunk + 4 lh .. + 3] (A) and W'[chunk][cout tile][lane][0..3] (B, packed on the host in exactly
-// that order) and feeds component j of both to MFMA step j -- the K index of a step is the channel 8 chunk + 4 lh + j,
-// a fixed permutation of the reduction.  No staging loads, no barriers, no LDS traffic in the loop; four chunks are in
-// flight per wave and several workgroups share a CU.  (The generic kernel conv_mfma.hip stages a pixel window and the
-// weights through LDS for every 16 channels: at these shapes less than half of its time is MFMA issue.)
-// One wave = 64 pixels x 64 couts (2 x 2 MFMA tiles, 64 accumulators); one workgroup = 4 waves as 256 px x 64 couts
-// (WGN = 1) or 128 px x 128 couts (WGN = 2).  Epilogue: the shared row epilogue (conv_device.h) after a per-wave
-// transposition through LDS, 32 pixel rows at a time.
+// A 1x1 convolution has no window, so neither MFMA operand needs LDS: lane (row l15, kq) of a wave loads the 16 bytes
+// in[pixel l15][16 chunk + 4 kq .. + 3] (A) and W'[chunk][cout tile][lane][0..3] (B, packed on the host in exactly that
+// order) and feeds component j of both to MFMA step j -- the K index of a step is the channel 16 chunk + 4 kq + j, a
+// fixed permutation of the reduction.  No staging loads, no barriers, no LDS traffic in the loop; three chunks are in
+// flight per wave and two workgroups share a CU.  (The generic kernel conv_mfma.hip stages a pixel window and the weights
+// through LDS for every 16 channels: at these shapes less than half of its time is MFMA issue.)
+// One wave = 64 pixels x 64 couts (4 x 4 MFMA tiles, 64 accumulators); one workgroup = 4 waves as 256 px x 64 couts
+// (WGN = 1) or 128 px x 128 couts (WGN = 2).  The 16-row MFMA is chosen for its operand addressing: the four kq lanes
+// of a pixel row read 64 consecutive bytes, 16 cache lines per load instruction instead of the 64 of the 32x32x2
+// mapping (measured 3 % faster over the 1x1 layers of a forward).  Epilogue: the shared row epilogue (conv_device.h)
+// after a per-wave transposition through LDS, 32 pixel rows at a time.
 #include "conv_device.h"
 
 #include <algorithm>
@@ -20,9 +22,9 @@
 
 namespace dm {
 
-static constexpr int PWCK = 8;   // input channels per K chunk
+static constexpr int PWCK = 16;  // input channels per K chunk
 static constexpr int PWTS = 68;  // row stride (floats) of the epilogue staging tile
-static constexpr int PWD = 4;    // chunks in flight per wave (2 waves per SIMD; measured: 3, 4 and 6 in flight equal, 3 waves per SIMD with spills slower)
+static constexpr int PWD = 3;    // chunks in flight per wave
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t pw_rsrc(const float* base, size_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)min(bytes, (size_t)0xFFFFFFFFu),
@@ -45,14 +47,14 @@ bool pw_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, 
 
 size_t pw_packed_floats(int Cout, int C0, int C1) { return (size_t)(C0 + C1) * Cout; }
 
-// oihw = (Cout, C0 + C1) -> [chunk of 8 channels][cout tile of 32][lane = 32 lh + l31][j 4] = W[32 t + l31][8 chunk + 4 lh + j]
+// oihw = (Cout, C0 + C1) -> [chunk of 16 channels][cout tile of 16][lane = 16 kq + l15][j 4] = W[16 t + l15][16 chunk + 4 kq + j]
 void pw_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1) {
     const int Cin = C0 + C1;
     for (int co = 0; co < Cout; ++co)
         for (int ci = 0; ci < Cin; ++ci) {
-            const int chunk = ci / PWCK, cc = ci % PWCK, lh = cc / 4, j = cc % 4;
-            const int t = co / 32, l31 = co % 32;
-            packed[(((size_t)chunk * (Cout / 32) + t) * 64 + lh * 32 + l31) * 4 + j] = oihw[(size_t)co * Cin + ci];
+            const int chunk = ci / PWCK, cc = ci % PWCK, kq = cc / 4, j = cc % 4;
+            const int t = co / 16, l15 = co % 16;
+            packed[(((size_t)chunk * (Cout / 16) + t) * 64 + kq * 16 + l15) * 4 + j] = oihw[(size_t)co * Cin + ci];
         }
 }
 
@@ -74,7 +76,7 @@ ConvGeom pw_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_spl
     int splits = 1;
     if (allow_split) {
         static const int target = pw_env_int("DM_PW_TARGET_WGS", 256);
-        static const int min_chunks = pw_env_int("DM_PW_MIN_CHUNKS", 16);
+        static const int min_chunks = pw_env_int("DM_PW_MIN_CHUNKS", 8);
         while (wgs * splits < target && splits < 8 && n_chunks / (splits * 2) >= min_chunks) splits *= 2;
     }
     g.chunks_per_split = (n_chunks + splits - 1) / splits;
@@ -97,8 +99,8 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31;
-    const int lh = lane >> 5;
+    const int l15 = lane & 15;
+    const int kq = lane >> 4;
     const int wn = wave % WGN, wm = wave / WGN;
 
     int n_blk, m_blk;
@@ -110,38 +112,40 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
     const int cb = split * g.chunks_per_split;
     const int ce = min(cb + g.chunks_per_split, p.n_chunks);
 
-    // ---- operand addressing: A rows of this lane (clamped: rows past the tensor load row M - 1 and are never stored)
+    // ---- operand addressing: A rows of this lane (clamped: rows past the tensor load row M - 1 and are never stored).
+    //      Lane (row l15, kq) of row tile rt loads channels 16 chunk + 4 kq .. + 3 of pixel px0 + 16 rt + l15: the four kq
+    //      lanes of a row read 64 consecutive bytes, so one load instruction touches 16 cache lines (the 32x32x2 mapping,
+    //      one 16-byte piece of 64 different rows per instruction, left the kernel bound by the texture addresser)
     const __amdgpu_buffer_rsrc_t rs_in0 = pw_rsrc(p.in0, (size_t)M * p.C0 * 4);
     const __amdgpu_buffer_rsrc_t rs_in1 = pw_rsrc(p.C1 ? p.in1 : p.in0, (size_t)M * (p.C1 ? p.C1 : p.C0) * 4);
-    unsigned avo0[2], avo1[2];
+    unsigned avo0[4], avo1[4];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const unsigned px = min(px0 + 32u * r + (unsigned)l31, M - 1u);
-        avo0[r] = (__umul24(px, (unsigned)p.C0) + 4u * lh) * 4u;
-        avo1[r] = (__umul24(px, (unsigned)p.C1) + 4u * lh) * 4u;
+    for (int rt = 0; rt < 4; ++rt) {
+        const unsigned px = min(px0 + 16u * rt + (unsigned)l15, M - 1u);
+        avo0[rt] = (__umul24(px, (unsigned)p.C0) + 4u * kq) * 4u;
+        avo1[rt] = (__umul24(px, (unsigned)p.C1) + 4u * kq) * 4u;
     }
     const size_t w_chunk = (size_t)p.Cout * PWCK;  // floats per chunk
     const __amdgpu_buffer_rsrc_t rs_w = pw_rsrc(p.w, (size_t)p.n_chunks * w_chunk * 4);
-    const unsigned wvo = (unsigned)(((2 * ct) * 64 + lane) * 4 * 4);  // cout tile 2 ct; tile 2 ct + 1 is 1024 bytes on
+    const unsigned wvo = (unsigned)(((4 * ct) * 64 + lane) * 4 * 4);  // cout tile 4 ct; the next tiles are 1024 bytes apart
 
-    f32x4 a[PWD][2], b[PWD][2];
+    f32x4 a[PWD][4], b[PWD][4];
     auto load = [&](int c, int d) {
         const bool s1 = c >= p.chunks0;
         const unsigned so = (unsigned)(s1 ? c - p.chunks0 : c) * (PWCK * 4);
 #pragma unroll
-        for (int r = 0; r < 2; ++r) a[d][r] = pw_bufload4(s1 ? rs_in1 : rs_in0, s1 ? avo1[r] : avo0[r], so);
+        for (int rt = 0; rt < 4; ++rt) a[d][rt] = pw_bufload4(s1 ? rs_in1 : rs_in0, s1 ? avo1[rt] : avo0[rt], so);
         const unsigned wo = (unsigned)c * (unsigned)(w_chunk * 4);
-        b[d][0] = pw_bufload4(rs_w, wvo, wo);
-        b[d][1] = pw_bufload4(rs_w, wvo + 1024u, wo);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[d][t] = pw_bufload4(rs_w, wvo + 1024u * t, wo);
     };
 
-    f32x16 acc[2][2];
+    const f32x4 z4 = make_f32x4(0.f, 0.f, 0.f, 0.f);
+    f32x4 acc[4][4];  // [row tile][cout tile]: register e of lane (n = l15, kq) = pixel 16 rt + 4 kq + e, cout 16 t + n
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[r][q][e] = 0.f;
+        for (int t = 0; t < 4; ++t) acc[rt][t] = z4;
 
 #pragma unroll
     for (int d = 0; d < PWD; ++d) load(min(cb + d, ce - 1), d);
@@ -152,16 +156,16 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 2; ++r)
+                    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-                        for (int q = 0; q < 2; ++q)
-                            acc[r][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][r][j], b[d][q][j], acc[r][q], 0, 0, 0);
+                        for (int t = 0; t < 4; ++t)
+                            acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][rt][j], b[d][t][j], acc[rt][t], 0, 0, 0);
                 if (c + d + PWD < ce) load(c + d + PWD, d);
             }
         }
     }
 
-    // ---- epilogue: 32 pixel rows (one MFMA row tile) at a time through this wave's staging tile
+    // ---- epilogue: 32 pixel rows (two row tiles) at a time through this wave's staging tile
     const int rsub = lane >> 4;
     const int c4 = (lane & 15) * 4;
     const int cg = ct * 64 + c4;
@@ -188,11 +192,17 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
         }
         RowsPrefetch<8, true> pf;
         rows_prefetch<8, true>(p, re, pixv, cg, cvalid, pf);
-        // accumulator register e of lane (l31, lh): row (e & 3) + 8 (e >> 2) + 4 lh, column l31
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) T[((e & 3) + 8 * (e >> 2) + 4 * lh) * PWTS + q * 32 + l31] = acc[r][q][e];
+            for (int t = 0; t < 4; ++t) {
+                float* dst = T + (16 * h + 4 * kq) * PWTS + 16 * t + l15;
+                const f32x4 v4 = acc[2 * r + h][t];
+                dst[0 * PWTS] = v4.x;
+                dst[1 * PWTS] = v4.y;
+                dst[2 * PWTS] = v4.z;
+                dst[3 * PWTS] = v4.w;
+            }
         __builtin_amdgcn_wave_barrier();
         f32x4 v[8];
 #pragma unroll
