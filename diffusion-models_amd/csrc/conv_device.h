@@ -77,6 +77,17 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     return v;
 }
 
+// 16-byte load through a buffer resource: base and size in 4 SGPRs, byte offset = VGPR part (per lane, loop invariant)
+// + SGPR part (per chunk / position / column, scalar arithmetic): no vector address arithmetic at all.  Reads past the
+// size return 0.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)min(bytes, (size_t)0xFFFFFFFFu),
+                                             0x00020000);
+}
+__device__ __forceinline__ f32x4 bufload4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, (int)soff_bytes, 0));
+}
+
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 

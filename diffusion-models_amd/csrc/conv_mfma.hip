@@ -46,10 +46,6 @@ static inline int ilog2(int v) {
 }
 static inline int ckp_for(int CK) { return CK == 4 ? 4 : CK + 4; }
 static inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
-static inline int env_int(const char* name, int dflt) {
-    const char* v = std::getenv(name);
-    return v ? std::atoi(v) : dflt;
-}
 
 int conv_ck_for(int C0, int C1) { return (C0 % 16 == 0 && C1 % 16 == 0) ? 16 : 4; }
 

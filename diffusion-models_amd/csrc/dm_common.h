@@ -8,7 +8,16 @@
 #include <string>
 #include <vector>
 
+#include <cstdlib>
+
 namespace dm {
+
+// integer tuning knob from the environment (read once by the callers: they keep the value in a function-local static)
+inline int env_int(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
+}
+
 
 void set_error(const std::string& msg);
 

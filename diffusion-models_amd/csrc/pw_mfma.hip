@@ -26,18 +26,6 @@ static constexpr int PWCK = 16;  // input channels per K chunk
 static constexpr int PWTS = 68;  // row stride (floats) of the epilogue staging tile
 static constexpr int PWD = 3;    // chunks in flight per wave
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t pw_rsrc(const float* base, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)min(bytes, (size_t)0xFFFFFFFFu),
-                                             0x00020000);
-}
-__device__ __forceinline__ f32x4 pw_bufload4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, (int)soff_bytes, 0));
-}
-
-static inline int pw_env_int(const char* name, int dflt) {
-    const char* e = std::getenv(name);
-    return e ? std::atoi(e) : dflt;
-}
 
 bool pw_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up) {
     static const bool off = std::getenv("DM_NO_PW") != nullptr;
@@ -75,8 +63,8 @@ ConvGeom pw_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_spl
     const int wgs = g.tiles_x * g.n_tiles_n;
     int splits = 1;
     if (allow_split) {
-        static const int target = pw_env_int("DM_PW_TARGET_WGS", 256);
-        static const int min_chunks = pw_env_int("DM_PW_MIN_CHUNKS", 8);
+        static const int target = env_int("DM_PW_TARGET_WGS", 256);
+        static const int min_chunks = env_int("DM_PW_MIN_CHUNKS", 8);
         while (wgs * splits < target && splits < 8 && n_chunks / (splits * 2) >= min_chunks) splits *= 2;
     }
     g.chunks_per_split = (n_chunks + splits - 1) / splits;
@@ -116,8 +104,8 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
     //      Lane (row l15, kq) of row tile rt loads channels 16 chunk + 4 kq .. + 3 of pixel px0 + 16 rt + l15: the four kq
     //      lanes of a row read 64 consecutive bytes, so one load instruction touches 16 cache lines (the 32x32x2 mapping,
     //      one 16-byte piece of 64 different rows per instruction, left the kernel bound by the texture addresser)
-    const __amdgpu_buffer_rsrc_t rs_in0 = pw_rsrc(p.in0, (size_t)M * p.C0 * 4);
-    const __amdgpu_buffer_rsrc_t rs_in1 = pw_rsrc(p.C1 ? p.in1 : p.in0, (size_t)M * (p.C1 ? p.C1 : p.C0) * 4);
+    const __amdgpu_buffer_rsrc_t rs_in0 = make_rsrc(p.in0, (size_t)M * p.C0 * 4);
+    const __amdgpu_buffer_rsrc_t rs_in1 = make_rsrc(p.C1 ? p.in1 : p.in0, (size_t)M * (p.C1 ? p.C1 : p.C0) * 4);
     unsigned avo0[4], avo1[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
@@ -126,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
         avo1[rt] = (__umul24(px, (unsigned)p.C1) + 4u * kq) * 4u;
     }
     const size_t w_chunk = (size_t)p.Cout * PWCK;  // floats per chunk
-    const __amdgpu_buffer_rsrc_t rs_w = pw_rsrc(p.w, (size_t)p.n_chunks * w_chunk * 4);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (size_t)p.n_chunks * w_chunk * 4);
     const unsigned wvo = (unsigned)(((4 * ct) * 64 + lane) * 4 * 4);  // cout tile 4 ct; the next tiles are 1024 bytes apart
 
     f32x4 a[PWD][4], b[PWD][4];
@@ -134,10 +122,10 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
         const bool s1 = c >= p.chunks0;
         const unsigned so = (unsigned)(s1 ? c - p.chunks0 : c) * (PWCK * 4);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) a[d][rt] = pw_bufload4(s1 ? rs_in1 : rs_in0, s1 ? avo1[rt] : avo0[rt], so);
+        for (int rt = 0; rt < 4; ++rt) a[d][rt] = bufload4(s1 ? rs_in1 : rs_in0, s1 ? avo1[rt] : avo0[rt], so);
         const unsigned wo = (unsigned)c * (unsigned)(w_chunk * 4);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b[d][t] = pw_bufload4(rs_w, wvo + 1024u * t, wo);
+        for (int t = 0; t < 4; ++t) b[d][t] = bufload4(rs_w, wvo + 1024u * t, wo);
     };
 
     const f32x4 z4 = make_f32x4(0.f, 0.f, 0.f, 0.f);
@@ -241,7 +229,7 @@ int pw_launch(const ConvParams& pin, hipStream_t s) {
                "pointwise: K split does not cover the chunks");
     DM_REQUIRE(g.lds_bytes >= 4 * 32 * PWTS * 4, "pointwise: LDS size");
     const int blocks = g.n_tiles_n * g.tiles_x;
-    static const bool xcd_order = pw_env_int("DM_NO_XCD_ORDER", 0) == 0;
+    static const bool xcd_order = env_int("DM_NO_XCD_ORDER", 0) == 0;
     p.geo.xcd_groups = (xcd_order && blocks % 8 == 0 && 8 % g.n_tiles_n == 0) ? 8 / g.n_tiles_n : 0;
     const bool timed = prof::enabled();
     if (timed) {

@@ -47,18 +47,6 @@ struct UWGeo {
     static constexpr int BUF = NB * IH * RS;  // floats per window buffer
 };
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uw_rsrc(const float* base, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)min(bytes, (size_t)0xFFFFFFFFu),
-                                             0x00020000);
-}
-__device__ __forceinline__ f32x4 uw_bufload4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, (int)soff_bytes, 0));
-}
-
-static inline int uw_env_int(const char* name, int dflt) {
-    const char* e = std::getenv(name);
-    return e ? std::atoi(e) : dflt;
-}
 
 bool upwino_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up) {
     static const bool off = std::getenv("DM_NO_UPWINO") != nullptr || std::getenv("DM_NO_WINOGRAD") != nullptr;
@@ -118,8 +106,8 @@ ConvGeom upwino_plan(int B, int Hl, int Wl, int Cout, int C0, int C1, bool allow
     const int wgs = g.tiles_x * g.tiles_y * g.groups * g.n_tiles_n;
     int splits = 1;
     if (allow_split) {
-        static const int target = uw_env_int("DM_UPWINO_TARGET_WGS", 256);
-        static const int min_chunks = uw_env_int("DM_UPWINO_MIN_CHUNKS", 8);
+        static const int target = env_int("DM_UPWINO_TARGET_WGS", 256);
+        static const int min_chunks = env_int("DM_UPWINO_MIN_CHUNKS", 8);
         while (wgs * splits < target && splits < 8 && n_chunks / (splits * 2) >= min_chunks) splits *= 2;
     }
     g.chunks_per_split = (n_chunks + splits - 1) / splits;
@@ -138,8 +126,8 @@ bool upwino_shape_ok(int B, int Hl, int Wl, int Cout, int C0, int C1) {
     const ConvGeom g = upwino_plan(B, Hl, Wl, Cout, C0, C1, true);
     // one 4-wave workgroup per CU: needs enough workgroups to cover the chip and a reduction that amortises its
     // prologue / epilogue (the folded direct kernel keeps the rest)
-    static const int min_wgs = uw_env_int("DM_UPWINO_MIN_WGS", 128);
-    static const int min_k = uw_env_int("DM_UPWINO_MIN_K", 8);
+    static const int min_wgs = env_int("DM_UPWINO_MIN_WGS", 128);
+    static const int min_k = env_int("DM_UPWINO_MIN_K", 8);
     const int wgs = g.tiles_x * g.tiles_y * g.groups * g.n_tiles_n * g.splits;
     const size_t out_px = (size_t)B * Hl * Wl * 4;
     return wgs >= min_wgs && g.chunks_per_split >= min_k && out_px < (1u << 24) &&
@@ -198,9 +186,9 @@ __global__ __launch_bounds__(256, 1) void upwino_mfma_kernel(const ConvParams p)
         }
     }
     const size_t in_px = (size_t)p.B * p.Hin * p.Win;
-    const __amdgpu_buffer_rsrc_t rs_in = uw_rsrc(p.in0, in_px * p.C0 * 4);
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in0, in_px * p.C0 * 4);
     const unsigned hvo = (__umul24((unsigned)hpix, (unsigned)p.C0) + 4 * (tid & 1)) * 4;
-    auto window_value = [&](int chunk) { return uw_bufload4(rs_in, hvo, (unsigned)chunk * (UWCK * 4)); };
+    auto window_value = [&](int chunk) { return bufload4(rs_in, hvo, (unsigned)chunk * (UWCK * 4)); };
 
     // ---- patch addressing of this lane: source pixel (ty, tx) of the wave's block, channel pair kq; byte offsets inside a
     //      window buffer of patch element (r, c)
@@ -220,15 +208,15 @@ __global__ __launch_bounds__(256, 1) void upwino_mfma_kernel(const ConvParams p)
 
     // ---- weights: lane (n = l15, kq) loads its 8 floats [gq 4][st 2] of a position as two 16-byte loads
     const size_t u_chunk = (size_t)9 * p.Cout * UWCK;  // floats per chunk
-    const __amdgpu_buffer_rsrc_t rs_w = uw_rsrc(p.w, (size_t)p.n_chunks * u_chunk * 4);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (size_t)p.n_chunks * u_chunk * 4);
     const unsigned uvo = (unsigned)((kq * 128 + l15 * 8) * 4);
     const unsigned u_slot = (unsigned)p.Cout * UWCK * 4;  // bytes between consecutive positions
     const unsigned u_tile = (unsigned)n_tile * (64 * UWCK * 4);
     f32x4 U[9][2];  // [xi][gq pair]: .xy = (gq even, st 0 / 1), .zw = (gq odd, st 0 / 1)
     auto load_u = [&](int chunk, int k) {
         const unsigned so = (unsigned)chunk * (unsigned)(u_chunk * 4) + u_tile + k * u_slot;
-        U[k][0] = uw_bufload4(rs_w, uvo, so);
-        U[k][1] = uw_bufload4(rs_w, uvo, so + 16);
+        U[k][0] = bufload4(rs_w, uvo, so);
+        U[k][1] = bufload4(rs_w, uvo, so + 16);
     };
 
     f32x2 A[9];       // V of the current chunk: position k, channels 2 kq (.x, K step 0) and 2 kq + 1 (.y, K step 1)
@@ -425,7 +413,7 @@ int upwino_launch(const ConvParams& pin, hipStream_t s) {
     DM_REQUIRE(g.splits * g.chunks_per_split >= p.n_chunks && (g.splits - 1) * g.chunks_per_split < p.n_chunks,
                "upwino: K split does not cover the chunks");
     const int blocks = g.n_tiles_n * g.tiles_x * g.tiles_y * g.groups;
-    static const bool xcd_order = uw_env_int("DM_NO_XCD_ORDER", 0) == 0;
+    static const bool xcd_order = env_int("DM_NO_XCD_ORDER", 0) == 0;
     p.geo.xcd_groups = (xcd_order && blocks % 8 == 0 && 8 % g.n_tiles_n == 0) ? 8 / g.n_tiles_n : 0;
     const bool timed = prof::enabled();
     if (timed) {

@@ -47,13 +47,6 @@ static constexpr int W4CK = 8;      // input channels per K chunk
 static constexpr int W4TILES = 16;  // 4x4-pixel tiles per workgroup
 static constexpr int W4WTS = 64;    // row stride (floats) of the epilogue staging tiles
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t w4_rsrc(const float* base, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)min(bytes, (size_t)0xFFFFFFFFu),
-                                             0x00020000);
-}
-__device__ __forceinline__ f32x4 w4_bufload4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, (int)soff_bytes, 0));
-}
 
 // geometry classes: LTW = log2(tiles across); whole images per workgroup below 16 pixels across
 template <int LTW>
@@ -69,11 +62,6 @@ struct W4Geo {
 // XOR code of image nb on the 16-byte slot index: images of one ds_read pass land in different bank groups
 __host__ __device__ constexpr int w4_nbcode(int ltw, int nb) {
     return ltw == 2 ? 0 : (ltw == 1 ? ((nb & 1) | ((nb & 2) << 1)) : (nb & 15));
-}
-
-static inline int w4_env_int(const char* name, int dflt) {
-    const char* e = std::getenv(name);
-    return e ? std::atoi(e) : dflt;
 }
 
 bool wino4_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up) {
@@ -148,8 +136,8 @@ ConvGeom wino4_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_
     const int wgs = g.tiles_x * g.tiles_y * g.groups * g.n_tiles_n;
     int splits = 1;
     if (allow_split) {
-        static const int target = w4_env_int("DM_WINO4_TARGET_WGS", 256);
-        static const int min_chunks = w4_env_int("DM_WINO4_MIN_CHUNKS", 8);
+        static const int target = env_int("DM_WINO4_TARGET_WGS", 256);
+        static const int min_chunks = env_int("DM_WINO4_MIN_CHUNKS", 8);
         while (wgs * splits < target && splits < 8 && n_chunks / (splits * 2) >= min_chunks) splits *= 2;
     }
     g.chunks_per_split = (n_chunks + splits - 1) / splits;
@@ -171,8 +159,8 @@ bool wino4_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1) {
     // epilogue behind another workgroup, as the two-per-CU F(2x2) kernel does: this kernel wins where those fixed costs
     // are amortised over a long reduction (measured at B = 256, 32x32: 16 chunks 1.10-1.18x, 32-48 chunks 1.19-1.23x,
     // 8 chunks 1.0x) and the chip is filled.
-    static const int min_wgs = w4_env_int("DM_WINO4_MIN_WGS", 200);
-    static const int min_k = w4_env_int("DM_WINO4_MIN_K", 12);  // chunks of 8 input channels per workgroup
+    static const int min_wgs = env_int("DM_WINO4_MIN_WGS", 200);
+    static const int min_k = env_int("DM_WINO4_MIN_K", 12);  // chunks of 8 input channels per workgroup
     const int wgs = g.tiles_x * g.tiles_y * g.groups * g.n_tiles_n * g.splits;
     return wgs >= min_wgs && g.chunks_per_split >= min_k && g.lds_bytes <= 160 * 1024 &&
            (size_t)B * Ho * Wo < (1u << 24) && (size_t)B * Ho * Wo * std::max(C0, C1) < (1ull << 30);
@@ -289,8 +277,8 @@ __global__ __launch_bounds__(256, 1) void wino4_mfma_kernel(const ConvParams p) 
     }
     f32x4 hreg[HR];
     const size_t in_px = (size_t)p.B * p.Hin * p.Win;
-    const __amdgpu_buffer_rsrc_t rs_in0 = w4_rsrc(p.in0, in_px * p.C0 * 4);
-    const __amdgpu_buffer_rsrc_t rs_in1 = w4_rsrc(p.C1 ? p.in1 : p.in0, in_px * (p.C1 ? p.C1 : p.C0) * 4);
+    const __amdgpu_buffer_rsrc_t rs_in0 = make_rsrc(p.in0, in_px * p.C0 * 4);
+    const __amdgpu_buffer_rsrc_t rs_in1 = make_rsrc(p.C1 ? p.in1 : p.in0, in_px * (p.C1 ? p.C1 : p.C0) * 4);
     const unsigned hq = 4 * (tid & 1);
     unsigned hvo[HR];
     auto window_offsets = [&](unsigned Cs) {
@@ -299,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void wino4_mfma_kernel(const ConvParams p) 
     };
     auto window_value = [&](int chunk, int i) {
         const bool s1 = chunk >= p.chunks0;
-        return w4_bufload4(s1 ? rs_in1 : rs_in0, hvo[i], (unsigned)(s1 ? chunk - p.chunks0 : chunk) * (W4CK * 4));
+        return bufload4(s1 ? rs_in1 : rs_in0, hvo[i], (unsigned)(s1 ? chunk - p.chunks0 : chunk) * (W4CK * 4));
     };
 
     // ---- transform addressing of this lane: tile l15, channel pair kq; byte offsets inside a window buffer of
@@ -326,15 +314,15 @@ __global__ __launch_bounds__(256, 1) void wino4_mfma_kernel(const ConvParams p) 
 
     // ---- weights: lane (n = l15, kq) loads its 8 floats [gq 4][st 2] of a slot as two 16-byte loads
     const size_t u_chunk = (size_t)36 * p.Cout * W4CK;  // floats per chunk
-    const __amdgpu_buffer_rsrc_t rs_w = w4_rsrc(p.w, (size_t)p.n_chunks * u_chunk * 4);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (size_t)p.n_chunks * u_chunk * 4);
     const unsigned uvo = (unsigned)((kq * 128 + l15 * 8) * 4);
     const unsigned u_slot = (unsigned)p.Cout * W4CK * 4;  // bytes between consecutive slots
     const unsigned u_wave = (unsigned)(9 * wave) * u_slot + (unsigned)n_tile * (64 * W4CK * 4);
     f32x4 U[9][2];  // [slot][gq pair]: .xy = (gq even, st 0 / 1), .zw = (gq odd, st 0 / 1)
     auto load_u = [&](int chunk, int k) {
         const unsigned so = (unsigned)chunk * (unsigned)(u_chunk * 4) + u_wave + k * u_slot;
-        U[k][0] = w4_bufload4(rs_w, uvo, so);
-        U[k][1] = w4_bufload4(rs_w, uvo, so + 16);
+        U[k][0] = bufload4(rs_w, uvo, so);
+        U[k][1] = bufload4(rs_w, uvo, so + 16);
     };
 
     f32x2 A[9];        // V of the current chunk: slot k, channels 2 kq (.x, K step 0) and 2 kq + 1 (.y, K step 1)
@@ -634,7 +622,7 @@ int wino4_launch(const ConvParams& pin, hipStream_t s) {
     DM_REQUIRE(p.chunks0 == p.C0 / W4CK && p.n_chunks == (p.C0 + p.C1) / W4CK, "winograd4: chunk counts");
     const int blocks = g.n_tiles_n * g.tiles_x * g.tiles_y * g.groups;
     // XCD-aware block order (conv_device.h: block_to_tile); DM_NO_XCD_ORDER=1 keeps the raw order for A/B runs
-    static const bool xcd_order = w4_env_int("DM_NO_XCD_ORDER", 0) == 0;
+    static const bool xcd_order = env_int("DM_NO_XCD_ORDER", 0) == 0;
     p.geo.xcd_groups = (xcd_order && blocks % 8 == 0 && 8 % g.n_tiles_n == 0) ? 8 / g.n_tiles_n : 0;
     const bool timed = prof::enabled();
     if (timed) {

@@ -39,16 +39,6 @@ namespace dm {
 static constexpr int WCK = 8;     // input channels per K chunk
 static constexpr int WTS = 68;    // padded row stride of the transposed epilogue tiles (floats)
 
-// 16-byte load through a buffer resource: base and size in 4 SGPRs, byte offset = VGPR part (per lane, loop invariant)
-// + SGPR part (per chunk / xi / column, scalar arithmetic): no vector address arithmetic at all.  Reads past the
-// size return 0.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)min(bytes, (size_t)0xFFFFFFFFu),
-                                             0x00020000);
-}
-__device__ __forceinline__ f32x4 bufload4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, (int)soff_bytes, 0));
-}
 
 static inline int w_pow2ceil(int v) {
     int p = 1;
@@ -60,11 +50,6 @@ static inline int w_ilog2(int v) {
     while ((1 << l) < v) ++l;
     return l;
 }
-static inline int w_env_int(const char* name, int dflt) {
-    const char* e = std::getenv(name);
-    return e ? std::atoi(e) : dflt;
-}
-
 bool wino_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up) {
     static const bool off = std::getenv("DM_NO_WINOGRAD") != nullptr;
     return !off && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !up && C0 > 0 && C0 % WCK == 0 &&
@@ -94,7 +79,7 @@ void wino_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C
 ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_split) {
     // R = Winograd tiles per lane: 2 -> 64 tiles per workgroup, 256 accumulator registers, one workgroup per CU;
     //                              1 -> 32 tiles per workgroup, 128 accumulator registers, two workgroups per CU
-    static const int R = w_env_int("DM_WINO_R", 1) == 2 ? 2 : 1;
+    static const int R = env_int("DM_WINO_R", 1) == 2 ? 2 : 1;
     const int tiles = 32 * R;
     ConvGeom g{};
     g.WM = R;
@@ -121,8 +106,8 @@ ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_s
     const int wgs = g.tiles_x * g.tiles_y * g.groups * g.n_tiles_n;
     int splits = 1;
     if (allow_split) {
-        static const int target = w_env_int("DM_WINO_TARGET_WGS", 256);
-        static const int min_chunks = w_env_int("DM_WINO_MIN_CHUNKS", 8);
+        static const int target = env_int("DM_WINO_TARGET_WGS", 256);
+        static const int min_chunks = env_int("DM_WINO_MIN_CHUNKS", 8);
         while (wgs * splits < target * (3 - R) && splits < 8 && n_chunks / (splits * 2) >= min_chunks) splits *= 2;
     }
     g.chunks_per_split = (n_chunks + splits - 1) / splits;
@@ -565,7 +550,7 @@ int wino_launch(const ConvParams& pin, hipStream_t s) {
     DM_REQUIRE(p.chunks0 == p.C0 / WCK && p.n_chunks == (p.C0 + p.C1) / WCK, "winograd: chunk counts");
     const int blocks = g.n_tiles_n * g.tiles_x * g.tiles_y * g.groups;
     // XCD-aware block order (conv_device.h: block_to_tile); DM_NO_XCD_ORDER=1 keeps the raw order for A/B runs
-    static const bool xcd_order = w_env_int("DM_NO_XCD_ORDER", 0) == 0;
+    static const bool xcd_order = env_int("DM_NO_XCD_ORDER", 0) == 0;
     p.geo.xcd_groups = (xcd_order && blocks % 8 == 0 && 8 % g.n_tiles_n == 0) ? 8 / g.n_tiles_n : 0;
     const bool timed = prof::enabled();
     if (timed) {
