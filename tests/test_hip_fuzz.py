@@ -76,3 +76,46 @@ def test_conv2d_random_shapes(case):
     got = hip_conv(x0, w, b, x1, res, pad, up2)
     assert got.shape == ref.shape
     assert rel_l2(got, ref) < TOL
+
+
+def _block_cases():
+    rng = random.Random(4242)
+    out = []
+    for _ in range(8):
+        size = rng.choice([(16, 16), (32, 16), (8, 8), (4, 4), (12, 20), (6, 6)])
+        cout = rng.choice([64, 64, 128, 256])
+        cin = 8 * rng.randint(2, 24)
+        need = 220 * 256 // max(1, cout // 64)
+        b = max(2, min(96, -(-need // (size[0] * size[1]))))
+        out.append((b + rng.randint(0, 2), cin, cout, size[0], size[1], rng.random() < 0.6))
+    return out
+
+
+BLOCK_RANDOM = _block_cases()
+
+
+@pytest.mark.parametrize("case", BLOCK_RANDOM, ids=[str(c) for c in BLOCK_RANDOM])
+def test_block_random_shapes(case):
+    """Block.forward (conv3x3 + RMSNorm + scale / shift + SiLU) on drawn shapes: fused epilogues of the Winograd kernels
+    (Cout = 64) and the landing pass (several cout tiles)."""
+    import ctypes  # noqa: F401
+
+    from diffusion_models_amd import _lib
+    from oracle import unet_oracle as uo
+    from test_hip_ops import DEV, dev
+
+    B, Cin, Cout, H, W, ss = case
+    x = seeded((B, Cin, H, W), 21)
+    sd = {
+        "b.proj.weight": seeded((Cout, Cin, 3, 3), 22, (9 * Cin) ** -0.5),
+        "b.proj.bias": seeded((Cout,), 23, 0.1),
+        "b.norm.g": 1 + 0.3 * seeded((1, Cout, 1, 1), 24),
+    }
+    scale = seeded((B, Cout), 25, 0.5) if ss else None
+    shift = seeded((B, Cout), 26, 0.5) if ss else None
+    ref = uo.block(sd, "b", x, (scale[:, :, None, None], shift[:, :, None, None]) if ss else None)
+    out = torch.empty(ref.shape, device=DEV)
+    a = [dev(t) for t in (x, sd["b.proj.weight"], sd["b.proj.bias"], sd["b.norm.g"], scale, shift)]
+    _lib.check(_lib.load().dm_op_block(_lib.ptr(a[0]), Cin, _lib.ptr(a[1]), _lib.ptr(a[2]), _lib.ptr(a[3]),
+                                       _lib.ptr(a[4]), _lib.ptr(a[5]), _lib.ptr(out), B, H, W, Cout, None))
+    assert rel_l2(out.cpu(), ref) < TOL
