@@ -396,6 +396,11 @@ static int make_conv(DeviceOwner& own, ConvLayer& L, const float* oihw, const fl
         pw_pack_weights(oihw, wp.data(), Cout, C0, C1);
         if (own.upload(wp.data(), wp.size(), &L.wpw)) return 1;
     }
+    if (pw_s2d_eligible(Cout, C0, C1, KH, KW, stride, pad, up)) {
+        std::vector<float> wp((size_t)4 * C0 * Cout);
+        pw_pack_weights_s2d(oihw, wp.data(), Cout, C0);
+        if (own.upload(wp.data(), wp.size(), &L.wpw)) return 1;
+    }
     L.wraw = nullptr;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && !up && Cout <= 4 && C1 == 0 && C0 % 4 == 0 &&
         own.upload(oihw, (size_t)Cout * C0, &L.wraw))
@@ -736,6 +741,14 @@ static int plan_conv(const Ctx& c, const ConvLayer& L, bool has_in1, int Hin, in
         p.Hin = p.Ho; p.Win = p.Wo;
         p.chunks0 = p.n_chunks = 4 * (L.C0 / 16);
         P.out_h = p.Ho; P.out_w = p.Wo;
+        if (L.wpw && !out_nchw && pw_shape_ok(c.B, p.Ho, p.Wo, L.Cout, 4 * L.C0, 0)) {
+            // the 1x1 GEMM kernel in space-to-depth mode (pw_mfma.hip)
+            p.w = L.wpw;
+            p.geo = pw_plan(c.B, p.Ho, p.Wo, L.Cout, 4 * L.C0, 0, true);
+            P.kind = 5;
+            P.in_kernel = p.geo.splits == 1 && (!want_norm || p.geo.fused_norm);
+            return 0;
+        }
         p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, 1, 1, 1, 4 * L.C0, 0, want_norm && !out_nchw, !out_nchw);
     } else {
         p.fold = 0; p.fold_w_stride = 0; p.up = L.up ? 1 : 0;

@@ -153,6 +153,9 @@ int wino4_launch(const ConvParams& p, hipStream_t s);
 bool pw_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up);
 size_t pw_packed_floats(int Cout, int C0, int C1);
 void pw_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1);
+// Downsample (2x2 / stride 2 over (Cout, C0, 2, 2) weights) on the same kernel: ConvParams::s2d = 1, C0 = source channels
+bool pw_s2d_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up);
+void pw_pack_weights_s2d(const float* oihw, float* packed, int Cout, int C0);
 ConvGeom pw_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_split);
 bool pw_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1);
 int pw_launch(const ConvParams& p, hipStream_t s);

@@ -46,6 +46,22 @@ void pw_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1)
         }
 }
 
+// Downsample weights (Cout, C0, 2, 2) -> the same lane order over K = (sub-pixel 2 dy + dx, channel)
+void pw_pack_weights_s2d(const float* oihw, float* packed, int Cout, int C0) {
+    std::vector<float> w((size_t)Cout * 4 * C0);
+    for (int co = 0; co < Cout; ++co)
+        for (int c = 0; c < C0; ++c)
+            for (int sub = 0; sub < 4; ++sub) w[(size_t)co * 4 * C0 + sub * C0 + c] = oihw[((size_t)co * C0 + c) * 4 + sub];
+    pw_pack_weights(w.data(), packed, Cout, 4 * C0, 0);
+}
+
+bool pw_s2d_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up) {
+    static const bool off = std::getenv("DM_NO_PW") != nullptr;
+    const int cps = C0 / PWCK;
+    return !off && KH == 2 && KW == 2 && stride == 2 && pad == 0 && !up && C1 == 0 && C0 > 0 && C0 % PWCK == 0 &&
+           (cps & (cps - 1)) == 0 && Cout % 64 == 0;
+}
+
 // M = output pixels (B * Ho * Wo)
 ConvGeom pw_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_split) {
     ConvGeom g{};
@@ -104,15 +120,25 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
     //      Lane (row l15, kq) of row tile rt loads channels 16 chunk + 4 kq .. + 3 of pixel px0 + 16 rt + l15: the four kq
     //      lanes of a row read 64 consecutive bytes, so one load instruction touches 16 cache lines (the 32x32x2 mapping,
     //      one 16-byte piece of 64 different rows per instruction, left the kernel bound by the texture addresser)
-    const __amdgpu_buffer_rsrc_t rs_in0 = make_rsrc(p.in0, (size_t)M * p.C0 * 4);
+    //      Space-to-depth mode (p.s2d: Downsample = pixel-unshuffle + 1x1, :54-58): the source is (B, 2 Ho, 2 Wo, C0), the K
+    //      index runs over (sub-pixel 2 dy + dx, channel); a lane addresses the top-left source pixel of its output pixel
+    //      and the sub-pixel is a wave-uniform offset per chunk.
+    const unsigned src_px = p.s2d ? 4u * M : M;
+    const __amdgpu_buffer_rsrc_t rs_in0 = make_rsrc(p.in0, (size_t)src_px * p.C0 * 4);
     const __amdgpu_buffer_rsrc_t rs_in1 = make_rsrc(p.C1 ? p.in1 : p.in0, (size_t)M * (p.C1 ? p.C1 : p.C0) * 4);
     unsigned avo0[4], avo1[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-        const unsigned px = min(px0 + 16u * rt + (unsigned)l15, M - 1u);
-        avo0[rt] = (__umul24(px, (unsigned)p.C0) + 4u * kq) * 4u;
+        unsigned px = min(px0 + 16u * rt + (unsigned)l15, M - 1u);
         avo1[rt] = (__umul24(px, (unsigned)p.C1) + 4u * kq) * 4u;
+        if (p.s2d) {
+            const unsigned hw = (unsigned)(p.Ho * p.Wo), bimg = px / hw, r = px - bimg * hw;
+            const unsigned y = r / (unsigned)p.Wo, x = r - y * (unsigned)p.Wo;
+            px = (bimg * 2u * p.Ho + 2u * y) * (2u * p.Wo) + 2u * x;
+        }
+        avo0[rt] = (__umul24(px, (unsigned)p.C0) + 4u * kq) * 4u;
     }
+    const int sub_shift = p.s2d;  // log2(chunks per sub-pixel) + 1 in space-to-depth mode (set by the launcher), else 0
     const size_t w_chunk = (size_t)p.Cout * PWCK;  // floats per chunk
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (size_t)p.n_chunks * w_chunk * 4);
     const unsigned wvo = (unsigned)(((4 * ct) * 64 + lane) * 4 * 4);  // cout tile 4 ct; the next tiles are 1024 bytes apart
@@ -120,7 +146,11 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
     f32x4 a[PWD][4], b[PWD][4];
     auto load = [&](int c, int d) {
         const bool s1 = c >= p.chunks0;
-        const unsigned so = (unsigned)(s1 ? c - p.chunks0 : c) * (PWCK * 4);
+        unsigned so = (unsigned)(s1 ? c - p.chunks0 : c) * (PWCK * 4);
+        if (sub_shift) {
+            const unsigned sub = (unsigned)c >> (sub_shift - 1), cs = (unsigned)c & ((1u << (sub_shift - 1)) - 1u);
+            so = (((sub >> 1) * 2u * p.Wo + (sub & 1u)) * (unsigned)p.C0 + cs * PWCK) * 4u;
+        }
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) a[d][rt] = bufload4(s1 ? rs_in1 : rs_in0, s1 ? avo1[rt] : avo0[rt], so);
         const unsigned wo = (unsigned)c * (unsigned)(w_chunk * 4);
@@ -211,7 +241,18 @@ int pw_launch(const ConvParams& pin, hipStream_t s) {
     ConvParams p = pin;
     p.stamps = nullptr;
     const ConvGeom& g = p.geo;
-    DM_REQUIRE(p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && !p.up && !p.fold && !p.s2d, "pointwise: plain 1x1 only");
+    DM_REQUIRE(p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && !p.up && !p.fold, "pointwise: 1x1 only");
+    if (p.s2d) {
+        // space-to-depth: C0 = channels of the SOURCE, n_chunks = 4 * C0 / 16; the kernel takes log2(C0 / 16) + 1 in p.s2d
+        const int cps = p.C0 / PWCK;
+        DM_REQUIRE(p.C1 == 0 && cps > 0 && (cps & (cps - 1)) == 0 && p.n_chunks == 4 * cps && p.chunks0 == p.n_chunks,
+                   "pointwise: space-to-depth mode needs one source with a power-of-two number of 16-channel chunks");
+        DM_REQUIRE((size_t)4 * p.B * p.Ho * p.Wo * p.C0 < (1ull << 30) && (size_t)4 * p.B * p.Ho * p.Wo < (1u << 24),
+                   "pointwise: space-to-depth source too large");
+        int lg = 0;
+        while ((1 << lg) < cps) ++lg;
+        p.s2d = lg + 1;
+    }
     DM_REQUIRE(!p.in_nchw && !p.out_nchw, "pointwise: NHWC only");
     DM_REQUIRE(p.C0 % PWCK == 0 && p.C1 % PWCK == 0 && p.Cout % 64 == 0, "pointwise: channel counts");
     DM_REQUIRE(p.Hin == p.Ho && p.Win == p.Wo, "pointwise: same-size convolution");
@@ -224,7 +265,7 @@ int pw_launch(const ConvParams& pin, hipStream_t s) {
                "pointwise: plan does not match the tensor");
     DM_REQUIRE(!(p.epi & EPI_NORM) || (p.Cout == 64 && g.splits == 1), "pointwise: fused RMSNorm needs all couts in one wave");
     DM_REQUIRE(g.splits == 1 || p.partial, "pointwise: split-K writes partial sums");
-    DM_REQUIRE(p.chunks0 == p.C0 / PWCK && p.n_chunks == (p.C0 + p.C1) / PWCK, "pointwise: chunk counts");
+    DM_REQUIRE(p.s2d || (p.chunks0 == p.C0 / PWCK && p.n_chunks == (p.C0 + p.C1) / PWCK), "pointwise: chunk counts");
     DM_REQUIRE(g.splits * g.chunks_per_split >= p.n_chunks && (g.splits - 1) * g.chunks_per_split < p.n_chunks,
                "pointwise: K split does not cover the chunks");
     DM_REQUIRE(g.lds_bytes >= 4 * 32 * PWTS * 4, "pointwise: LDS size");
@@ -233,13 +274,13 @@ int pw_launch(const ConvParams& pin, hipStream_t s) {
     p.geo.xcd_groups = (xcd_order && blocks % 8 == 0 && 8 % g.n_tiles_n == 0) ? 8 / g.n_tiles_n : 0;
     const bool timed = prof::enabled();
     if (timed) {
-        const double pix = (double)M, cin = p.C0 + p.C1;
+        const double pix = (double)M, cin = p.s2d ? 4.0 * p.C0 : p.C0 + p.C1;
         const double flops = 2.0 * cin * p.Cout * pix;
         const double bytes = 4.0 * (cin * pix + p.Cout * pix + cin * p.Cout);
         char name[64];
         if (prof::detail())
-            snprintf(name, sizeof(name), "pw<%d> 1x1 %d+%d->%d @%dx%d e%d k%d", g.WN, p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.epi,
-                     g.splits);
+            snprintf(name, sizeof(name), "pw<%d> 1x1 %d+%d->%d @%dx%d%s e%d k%d", g.WN, p.C0, p.C1, p.Cout, p.Ho, p.Wo,
+                     p.s2d ? " s2d" : "", p.epi, g.splits);
         else
             snprintf(name, sizeof(name), "pw_mfma_kernel<%d>", g.WN);
         if (prof::begin(name, flops, bytes, s)) return 1;
