@@ -185,6 +185,7 @@ struct ConvLayer {
     float* ww4 = nullptr;  // F(4x4,3x3) transformed weights (wino4_mfma.hip)
     float* wwu = nullptr;  // transformed weights of the upsample + 3x3 algorithm (upwino_mfma.hip)
     float* wpw = nullptr;  // lane-ordered weights of the 1x1 GEMM kernel (pw_mfma.hip)
+    float* wi7 = nullptr;  // weights of the 7x7 first-conv kernel (init7_mfma.hip)
     float* wraw = nullptr;  // (Cout, Cin) weights of a 1x1 conv with Cout <= 4 (pointwise_small_kernel)
     float* bias = nullptr;
 };
@@ -400,6 +401,12 @@ static int make_conv(DeviceOwner& own, ConvLayer& L, const float* oihw, const fl
         std::vector<float> wp((size_t)4 * C0 * Cout);
         pw_pack_weights_s2d(oihw, wp.data(), Cout, C0);
         if (own.upload(wp.data(), wp.size(), &L.wpw)) return 1;
+    }
+    L.wi7 = nullptr;
+    if (init7_eligible(Cout, C0, C1, KH, KW, stride, pad, up)) {
+        std::vector<float> wp(init7_packed_floats(C0));
+        init7_pack_weights(oihw, wp.data(), C0);
+        if (own.upload(wp.data(), wp.size(), &L.wi7)) return 1;
     }
     L.wraw = nullptr;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && !up && Cout <= 4 && C1 == 0 && C0 % 4 == 0 &&
@@ -687,7 +694,7 @@ struct ResParts {
 struct PlannedConv {
     ConvParams p;      // everything but the tensor pointers
     int out_h, out_w;  // dims of the output tensor
-    int kind;          // 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3), 3 upsample algorithm, 4 one thread per pixel, 5 1x1 GEMM
+    int kind;          // 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3), 3 upsample algorithm, 4 one thread per pixel, 5 1x1 GEMM, 7 7x7 first conv
     bool in_kernel;    // the epilogue runs inside the conv kernel (else: partial sums + landing kernel)
 };
 
@@ -761,6 +768,13 @@ static int plan_conv(const Ctx& c, const ConvLayer& L, bool has_in1, int Hin, in
         p.geo = conv_plan(c.B, p.Ho, p.Wo, L.Cout, L.KH, L.KW, L.stride, L.C0, L.C1, want_norm && !out_nchw,
                           !out_nchw);
     }
+    if (P.kind == 0 && L.wi7 && in_nchw && !out_nchw && !has_in1 && epi == 0 && L.pad_hi == 0 && padw == L.pad &&
+        (size_t)c.B * p.Ho * p.Wo < (1u << 24)) {
+        p.w = L.wi7;
+        P.kind = 7;
+        P.in_kernel = true;
+        return 0;
+    }
     if (L.wraw && out_nchw && !in_nchw && !has_in1 && epi == 0) {
         // a handful of output channels (final_conv): one pixel per thread instead of a 64-column MFMA tile
         P.kind = 4;
@@ -800,6 +814,7 @@ static int plan_conv(const Ctx& c, const ConvLayer& L, bool has_in1, int Hin, in
 
 static int launch_planned(const PlannedConv& P, const ConvParams& q, hipStream_t s) {
     switch (P.kind) {
+        case 7: return init7_launch(q, s);
         case 5: return pw_launch(q, s);
         case 3: return upwino_launch(q, s);
         case 2: return wino4_launch(q, s);

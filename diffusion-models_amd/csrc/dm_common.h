@@ -148,6 +148,12 @@ ConvGeom wino4_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_
 bool wino4_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1);
 int wino4_launch(const ConvParams& p, hipStream_t s);
 
+// The 7x7 / pad 3 first convolution over an NCHW image with 1-8 channels -> 64 NHWC channels (init7_mfma.hip)
+bool init7_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up);
+size_t init7_packed_floats(int Cin);
+void init7_pack_weights(const float* oihw, float* packed, int Cin);
+int init7_launch(const ConvParams& p, hipStream_t s);
+
 // 1x1 convolution as a register-direct GEMM (pw_mfma.hip): NHWC, one or two sources, C % 8 == 0, Cout % 64 == 0;
 // w = pw_pack_weights, chunks of 8 input channels.
 bool pw_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up);

@@ -56,6 +56,9 @@ CONV_CASES = [
     (2, 128, 0, 8, 8, 64, 1, 0, False, True, True),       # to_out 1x1 + residual
     (2, 3, 0, 32, 32, 64, 7, 3, False, True, False),      # init_conv: thin input, CK=4 path
     (2, 4, 0, 16, 16, 32, 7, 3, False, True, False),      # latent init_conv
+    (3, 4, 0, 20, 28, 64, 7, 3, False, True, False),      # first-conv kernel (init7_mfma.hip): ragged 16x16 blocks, 4 channels
+    (1, 6, 0, 8, 8, 64, 7, 3, False, False, False),       # image smaller than a block, 6 channels, no bias
+    (2, 8, 0, 16, 16, 64, 7, 3, False, True, False),      # 8 channels: 98 K steps
     (2, 64, 0, 32, 32, 3, 1, 0, False, True, False),      # final_conv: 3 output channels
     (1, 64, 0, 64, 64, 64, 3, 1, False, True, False),     # 64x64 image: 2 tiles across, 8 down
     (2, 16, 0, 24, 24, 16, 3, 1, False, True, False),     # non power-of-two image (masked tile)
