@@ -105,7 +105,8 @@ def cpu_baseline(n_steps):
     """BASELINE config 1 exactly: Unet(dim 64, mults (1,2,4,8), channels 3), 32x32, linear beta,
     T = 1000, p_sample_loop, B = 64, fp32 -- the oracle (CPU restatement pinned to the reference's outputs) on this
     box's host cores.  The loop is per-step homogeneous: `n_steps` DDPM steps are timed after one warm-up step and
-    extrapolated linearly to 1000.  The thread count is swept over {8, 16, 32, 64} (2 steps each) and the best is used."""
+    extrapolated linearly to 1000.  The thread count is swept over {8, 16, 32, 64} (3 steps each); the two best run the
+    full sample and the faster one is reported."""
     import torch
 
     import diffusion_models_amd as dm
@@ -134,10 +135,15 @@ def cpu_baseline(n_steps):
     sweep = {}
     for n in sorted({min(c, avail) for c in (8, 16, 32, 64)}):
         torch.set_num_threads(n)
-        sweep[n] = run(2) / 2
-    best = min(sweep, key=sweep.get)
-    torch.set_num_threads(best)
-    dt = run(n_steps)
+        sweep[n] = run(3) / 3
+    # the short sweep is noisy on a shared host: the two best thread counts both run the full sample, the faster one counts
+    finalists = sorted(sweep, key=sweep.get)[:2]
+    timed = {}
+    for n in finalists:
+        torch.set_num_threads(n)
+        timed[n] = run(n_steps)
+    best = min(timed, key=timed.get)
+    dt = timed[best]
     step_s = dt / n_steps
     return {
         "value": B / (step_s * T),
@@ -148,7 +154,7 @@ def cpu_baseline(n_steps):
         "sample": f"BASELINE config 1: B=64, 32x32, p_sample (DDPM), {n_steps} of 1000 steps timed ({dt:.1f} s) after 1 "
                   f"warm-up step, linear extrapolation to 1000; threads swept {{"
                   + ", ".join(f"{k}: {1e3 * v:.0f} ms/step" for k, v in sweep.items())
-                  + f"}} of {avail} available, best = {best}; torch {torch.__version__} CPU ops, fp32",
+                  + f"}} of {avail} available, full sample at {finalists}, best = {best}; torch {torch.__version__} CPU ops, fp32",
     }
 
 
