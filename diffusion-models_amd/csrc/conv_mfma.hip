@@ -856,7 +856,8 @@ static int launch_one(const ConvParams& p, hipStream_t s) {
         const double in_pix = (double)p.B * (p.up ? (p.Hin / 2) * (p.Win / 2) : p.Hin * p.Win) * (p.s2d ? 4 : 1);
         const double taps = p.fold ? 9.0 : (p.s2d ? 4.0 : (double)p.KH * p.KW);
         const double flops = 2.0 * taps * cin * p.Cout * pix;
-        const double bytes = 4.0 * (cin * in_pix + p.Cout * pix + taps * cin * p.Cout);
+        const double res_rows = (!p.partial && (p.epi & EPI_RESIDUAL)) ? 1.0 : 0.0;  // the fused residual add reads one more tensor
+        const double bytes = 4.0 * (cin * in_pix + (1.0 + res_rows) * p.Cout * pix + taps * cin * p.Cout);
         char name[64];
         if (prof::detail())
             snprintf(name, sizeof(name), "conv<%d,%d,%d> %dx%d s%d %d+%d->%d @%dx%d%s e%d k%d t%d", WM, WN, CK, p.KH,

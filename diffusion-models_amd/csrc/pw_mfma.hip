@@ -276,7 +276,8 @@ int pw_launch(const ConvParams& pin, hipStream_t s) {
     if (timed) {
         const double pix = (double)M, cin = p.s2d ? 4.0 * p.C0 : p.C0 + p.C1;
         const double flops = 2.0 * cin * p.Cout * pix;
-        const double bytes = 4.0 * (cin * pix + p.Cout * pix + cin * p.Cout);
+        const double res_rows = (!p.partial && (p.epi & EPI_RESIDUAL)) ? 1.0 : 0.0;  // the fused residual add reads one more tensor
+        const double bytes = 4.0 * (cin * pix + (1.0 + res_rows) * p.Cout * pix + cin * p.Cout);
         char name[64];
         if (prof::detail())
             snprintf(name, sizeof(name), "pw<%d> 1x1 %d+%d->%d @%dx%d%s e%d k%d", g.WN, p.C0, p.C1, p.Cout, p.Ho, p.Wo,

@@ -421,7 +421,8 @@ int upwino_launch(const ConvParams& pin, hipStream_t s) {
         // the multiply-adds of that count
         const double pix = (double)p.B * p.Ho * p.Wo;
         const double flops = 2.0 * 9.0 * p.C0 * p.Cout * pix;
-        const double bytes = 4.0 * (p.C0 * pix / 4 + p.Cout * pix + 9.0 * p.C0 * p.Cout);
+        const double res_rows = (!p.partial && (p.epi & EPI_RESIDUAL)) ? 1.0 : 0.0;  // the fused residual add reads one more tensor
+        const double bytes = 4.0 * (p.C0 * pix / 4 + (1.0 + res_rows) * p.Cout * pix + 9.0 * p.C0 * p.Cout);
         char name[64];
         if (prof::detail())
             snprintf(name, sizeof(name), "upwino<%d> 3x3 up %d->%d @%dx%d e%d k%d", cls, p.C0, p.Cout, p.Ho, p.Wo, p.epi,

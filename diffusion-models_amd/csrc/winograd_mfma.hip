@@ -559,7 +559,8 @@ int wino_launch(const ConvParams& pin, hipStream_t s) {
         const double pix = (double)p.B * p.Ho * p.Wo;
         const double cin = p.C0 + p.C1;
         const double flops = 2.0 * 9.0 * cin * p.Cout * pix;
-        const double bytes = 4.0 * (cin * pix + p.Cout * pix + 9.0 * cin * p.Cout);
+        const double res_rows = (!p.partial && (p.epi & EPI_RESIDUAL)) ? 1.0 : 0.0;  // the fused residual add reads one more tensor
+        const double bytes = 4.0 * (cin * pix + (1.0 + res_rows) * p.Cout * pix + 9.0 * cin * p.Cout);
         char name[64];
         if (prof::detail())
             snprintf(name, sizeof(name), "wino<%d> 3x3 s1 %d+%d->%d @%dx%d e%d k%d", R, p.C0, p.C1, p.Cout, p.Ho, p.Wo,
