@@ -14,14 +14,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DM_LIB") or os.path.join(_HERE, "libdm_hip.so")
 DM_MAX_STAGES = 8
 DM_COEFS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/dm_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
     "dm_last_error", "dm_abi_version",
     "dm_unet_create", "dm_unet_destroy", "dm_unet_set_param", "dm_unet_missing_params", "dm_unet_finalize",
     "dm_unet_update_param", "dm_unet_refresh", "dm_unet_graph_captures", "dm_unet_workspace_bytes",
-    "dm_unet_forward", "dm_sample", "dm_sample_cond", "dm_randn",
+    "dm_unet_forward", "dm_sample", "dm_sample_cond", "dm_sample_ex", "dm_randn",
     "dm_decoder_create", "dm_decoder_destroy", "dm_decoder_set_param", "dm_decoder_missing_params",
     "dm_decoder_finalize", "dm_decoder_forward",
     "dm_encoder_create", "dm_encoder_destroy", "dm_encoder_set_param", "dm_encoder_missing_params",
@@ -61,6 +61,22 @@ class EncoderCfg(C.Structure):
     ]
 
 
+class SampleArgs(C.Structure):
+    """dm_sample_args (include/dm_hip.h)."""
+    _fields_ = [
+        ("kind", C.c_int32), ("objective", C.c_int32), ("self_condition", C.c_int32), ("n_steps", C.c_int32),
+        ("times_host", C.POINTER(C.c_int64)), ("coefs_host", C.POINTER(C.c_float)),
+        ("x_T", C.c_void_p), ("noise", C.c_void_p), ("seed", C.c_uint64), ("sample_offset", C.c_uint64),
+        ("ctx", C.c_void_p), ("ctx_tokens", C.c_int32), ("cond_channels", C.c_int32), ("cond", C.c_void_p),
+        ("out", C.c_void_p), ("all_steps", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("unnormalize", C.c_int32), ("use_graph", C.c_int32),
+        ("reserved_", C.c_int32), ("stream", C.c_void_p),
+    ]
+
+
+OBJECTIVES = {"pred_noise": 0, "pred_x0": 1, "pred_v": 2}
+
+
 class ProfileRow(C.Structure):
     _fields_ = [("kernel", C.c_char * 64), ("launches", C.c_int64), ("total_ms", C.c_double),
                 ("total_flops", C.c_double), ("total_bytes", C.c_double)]
@@ -90,6 +106,7 @@ def _declare(lib: C.CDLL) -> None:
                               i32, i32, i32, i32, i32, vp]
     lib.dm_sample_cond.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, u64, u64, fp, i32, fp,
                                    i32, fp, fp, i32, i32, i32, i32, i32, vp]
+    lib.dm_sample_ex.argtypes = [vp, C.POINTER(SampleArgs)]
     lib.dm_randn.argtypes = [fp, i64, u64, u64, u64, vp]
     lib.dm_decoder_create.argtypes = [C.POINTER(DecoderCfg), i32, C.POINTER(vp)]
     lib.dm_decoder_destroy.argtypes = [vp]
@@ -111,7 +128,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_op_block.argtypes = [fp, i32, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, vp]
     lib.dm_op_linear_attention.argtypes = [fp, fp, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, vp]
     lib.dm_op_attention.argtypes = [fp, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, vp]
-    lib.dm_op_sampler_update.argtypes = [i32, fp, fp, fp, C.POINTER(C.c_float), fp, i64, vp]
+    lib.dm_op_sampler_update.argtypes = [i32, i32, fp, fp, fp, C.POINTER(C.c_float), fp, fp, i64, vp]
     lib.dm_conv_create.argtypes = [fp, fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]
     lib.dm_conv_destroy.argtypes = [vp]
     lib.dm_conv_destroy.restype = None

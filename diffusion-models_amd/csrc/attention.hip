@@ -349,12 +349,8 @@ int launch_attention_core(const float* q, int ldq, const float* k, const float* 
     int ntok = nk + n_mem;
     size_t lds = ((size_t)ntok * (DH + 1) + (size_t)ntok * DH + 4 * (size_t)ntok + 4 * DH) * sizeof(float);
     DM_REQUIRE(lds <= 160 * 1024, "attention: sequence too long for the LDS-resident kernel");
-    static bool attr_set = false;
-    if (!attr_set) {
-        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_core_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsOptIn lds_flag;
+    if (lds_opt_in(lds_flag, reinterpret_cast<const void*>(attention_core_kernel), 1)) return 1;
     const int qblocks = std::max(1, std::min((nq + 3) / 4, (512 + heads * B - 1) / (heads * B)));
     hipLaunchKernelGGL(attention_core_kernel, dim3(heads, B, qblocks), dim3(256), lds, s, q, ldq, k, v, ldk, mem_k,
                        mem_v, n_mem, out, ldo, nq, nk, scale);

@@ -248,12 +248,8 @@ __global__ __launch_bounds__(256) void attn16_fused_kernel(const float* __restri
 int launch_attn16_fused(const Attn16& w, const float* x, float* y, int B, bool add_x, hipStream_t s) {
     DM_REQUIRE(w.C % 256 == 0 && w.C >= 256 && w.C <= 1024 && B > 0, "attn16: channel count");
     const size_t lds = (size_t)(16 * (w.C + 4) + 16 * A16_OS) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_fused_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsOptIn lds_flag;
+    if (lds_opt_in(lds_flag, reinterpret_cast<const void*>(attn16_fused_kernel), 1)) return 1;
     const bool timed = prof::enabled();
     if (timed) {
         const double tok = 16.0 * B;

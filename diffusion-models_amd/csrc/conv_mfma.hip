@@ -836,13 +836,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 
 template <int WM, int WN, int CK, int TPSC>  // TPSC: taps per weight slab at compile time (0 = run time)
 static int launch_one(const ConvParams& p, hipStream_t s) {
-    static bool attr_set = false;
+    static LdsOptIn lds_flag;
     auto kern = conv_mfma_kernel<WM, WN, CK, TPSC>;
-    if (!attr_set) {
-        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    if (lds_opt_in(lds_flag, reinterpret_cast<const void*>(kern), 1)) return 1;
     const ConvGeom& g = p.geo;
     DM_REQUIRE(g.TPS * (WN * 64) * (CK / 4) <= 256 * wregs_for(WN, CK), "conv: weight slab exceeds staging registers");
     int blocks = g.n_tiles_n * g.tiles_x * g.tiles_y * g.groups;

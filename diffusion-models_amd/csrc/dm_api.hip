@@ -232,6 +232,7 @@ struct dm_unet {
     std::map<std::string, HostTensor> params;  // expected entries, filled by set_param
     std::vector<std::string> order;
     bool finalized = false;
+    bool poisoned = false;  // a refresh failed half-way: device weights are a mix of old and new values
     DeviceOwner own;
     // layers
     ConvLayer init_conv, final_conv;
@@ -256,16 +257,30 @@ struct dm_unet {
     std::vector<std::pair<std::string, ResBlock*>> resnets;  // in ss_off order
     // the instantiated graph of one denoise step, reused while the key (shape, kind, every captured pointer) holds
     struct GraphKey {
-        int kind = -1, B = 0, H = 0, W = 0, ctx_tokens = 0, cond_channels = 0;
+        int kind = -1, B = 0, H = 0, W = 0, ctx_tokens = 0, cond_channels = 0, objective = 0, self_cond = 0;
         const void *noise = nullptr, *all_steps = nullptr, *ws = nullptr, *times = nullptr, *coefs = nullptr;
         bool operator==(const GraphKey& o) const {
             return kind == o.kind && B == o.B && H == o.H && W == o.W && ctx_tokens == o.ctx_tokens &&
-                   cond_channels == o.cond_channels && noise == o.noise && all_steps == o.all_steps && ws == o.ws &&
+                   cond_channels == o.cond_channels && objective == o.objective && self_cond == o.self_cond && noise == o.noise && all_steps == o.all_steps && ws == o.ws &&
                    times == o.times && coefs == o.coefs;
         }
     } gkey;
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
+    // Workspace, sampler state and the cached graph are shared by every call on the handle: a call waits for the previous
+    // call's last kernel (recorded here) before it touches them, so two calls on DIFFERENT streams are still ordered.
+    hipEvent_t done_ev = nullptr;
+    bool done_recorded = false;
+    int order_after_previous(hipStream_t s) {
+        if (!done_ev) DM_CHECK_HIP(hipEventCreateWithFlags(&done_ev, hipEventDisableTiming));
+        if (done_recorded) DM_CHECK_HIP(hipStreamWaitEvent(s, done_ev, 0));
+        return 0;
+    }
+    int mark_done(hipStream_t s) {
+        DM_CHECK_HIP(hipEventRecord(done_ev, s));
+        done_recorded = true;
+        return 0;
+    }
     hipStream_t cap_stream = nullptr;  // capture / replay stream when the caller passes the legacy default stream
     int graph_captures = 0;            // diagnostics (dm_unet_graph_captures)
     void drop_graph() {
@@ -1204,7 +1219,7 @@ static int check_hw(dm_unet* u, int H, int W) {
 extern "C" {
 
 const char* dm_last_error(void) { return g_err.c_str(); }
-int dm_abi_version(void) { return 2; }
+int dm_abi_version(void) { return 3; }
 
 int dm_unet_create(const dm_unet_cfg* cfg, int device, dm_unet** out) {
     DM_REQUIRE(cfg && out, "null argument");
@@ -1290,6 +1305,7 @@ void dm_unet_destroy(dm_unet* u) {
     (void)hipSetDevice(u->device);
     u->drop_graph();
     if (u->cap_stream) (void)hipStreamDestroy(u->cap_stream);
+    if (u->done_ev) (void)hipEventDestroy(u->done_ev);
     if (u->ws) (void)hipFree(u->ws);
     if (u->state_dev) (void)hipFree(u->state_dev);
     if (u->times_dev) (void)hipFree(u->times_dev);
@@ -1365,7 +1381,7 @@ int dm_unet_update_param(dm_unet* u, const char* name, const float* data_host, c
 int dm_unet_refresh(dm_unet* u) {
     DM_REQUIRE(u, "null handle");
     DM_REQUIRE(u->finalized, "dm_unet_refresh before dm_unet_finalize");
-    bool any = false;
+    bool any = u->poisoned;
     for (auto& kv : u->params) any = any || kv.second.dirty;
     if (!any) return 0;
     DM_CHECK_HIP(hipSetDevice(u->device));
@@ -1378,8 +1394,16 @@ int dm_unet_refresh(dm_unet* u) {
         rc = 1;
     }
     u->own.refreshing = false;
+    if (rc) {
+        // Some buffers hold new values, some old ones.  The dirty flags stay set so that a retry re-packs everything that
+        // changed, the cached step graph is dropped, and the handle refuses to run until a refresh has succeeded.
+        u->drop_graph();
+        u->poisoned = true;
+        return rc;
+    }
+    u->poisoned = false;
     for (auto& kv : u->params) kv.second.dirty = false;
-    return rc;
+    return 0;
 }
 
 int dm_unet_graph_captures(dm_unet* u) { return u ? u->graph_captures : -1; }
@@ -1389,6 +1413,7 @@ int dm_unet_forward(dm_unet* u, const float* x, const int64_t* time, const float
                     int B, int H, int W, void* stream) {
     DM_REQUIRE(u && x && time && out, "null argument");
     DM_REQUIRE(u->finalized, "dm_unet_finalize has not been called");
+    DM_REQUIRE(!u->poisoned, "the last dm_unet_refresh failed: refresh again before running the model");
     DM_REQUIRE(B > 0, "empty batch");
     if (check_hw(u, H, W)) return 1;
     DM_CHECK_HIP(hipSetDevice(u->device));
@@ -1400,7 +1425,9 @@ int dm_unet_forward(dm_unet* u, const float* x, const int64_t* time, const float
     Arena A;
     A.base = u->ws;
     A.cap = u->ws_cap;
-    return unet_forward_impl(u, A, x, time, nullptr, nullptr, ctx, ctx_tokens, out, B, H, W, s);
+    if (u->order_after_previous(s)) return 1;
+    if (unet_forward_impl(u, A, x, time, nullptr, nullptr, ctx, ctx_tokens, out, B, H, W, s)) return 1;
+    return u->mark_done(s);
 }
 
 }  // extern "C"
@@ -1417,22 +1444,29 @@ int dm_unet_forward(dm_unet* u, const float* x, const int64_t* time, const float
 static int sample_impl(dm_unet* u, int kind, int n_steps, const int64_t* times_host, const float* coefs_host,
                        const float* x_T, const float* noise, uint64_t seed, uint64_t sample_offset, const float* ctx,
                        int ctx_tokens, const float* cond, int cond_channels, float* out, float* all_steps, int B, int H,
-                       int W, int unnormalize, int use_graph, void* stream) {
+                       int W, int unnormalize, int use_graph, void* stream, int objective = DM_OBJ_PRED_NOISE,
+                       int self_cond = 0) {
     DM_REQUIRE(u && times_host && coefs_host && x_T && out, "null argument");
     DM_REQUIRE(u->finalized, "dm_unet_finalize has not been called");
+    DM_REQUIRE(!u->poisoned, "the last dm_unet_refresh failed: refresh again before running the model");
     DM_REQUIRE(kind == DM_SAMPLER_DDPM || kind == DM_SAMPLER_DDIM, "unknown sampler kind");
     DM_REQUIRE(n_steps > 0 && B > 0, "empty run");
     DM_REQUIRE(u->out_dim == u->cfg.channels, "sampler needs out_dim == channels (DD/denoising_diffusion.py:456)");
     DM_REQUIRE((cond == nullptr) == (cond_channels == 0) && cond_channels >= 0, "cond and cond_channels come together");
-    DM_REQUIRE(u->cfg.input_channels == u->cfg.channels + cond_channels,
-               "U-Net input channels != channels + cond_channels (self-conditioning is not on this path)");
+    DM_REQUIRE(objective >= DM_OBJ_PRED_NOISE && objective <= DM_OBJ_PRED_V, "unknown objective");
+    DM_REQUIRE(!self_cond || cond_channels == 0, "self-conditioning and an image condition are not combined");
+    DM_REQUIRE(u->cfg.input_channels == u->cfg.channels * (self_cond ? 2 : 1) + cond_channels,
+               "U-Net input channels != channels [* 2 with self-conditioning] + cond_channels");
     DM_REQUIRE((ctx == nullptr) == (ctx_tokens == 0), "ctx and ctx_tokens come together");
     if (check_hw(u, H, W)) return 1;
     DM_CHECK_HIP(hipSetDevice(u->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int C = u->cfg.channels;
     const int64_t n = (int64_t)B * C * H * W;
-    const int64_t n_in = (int64_t)B * (C + cond_channels) * H * W;
+    // the U-Net input when it is wider than x: [x | cond] (image condition) or [x_start | x] (self-conditioning)
+    const int Cin = self_cond ? 2 * C : C + cond_channels;
+    const bool wide = Cin != C;
+    const int64_t n_in = (int64_t)B * Cin * H * W;
     const int64_t n_ctx = ctx ? (int64_t)B * ctx_tokens * u->cfg.text_emb_dim : 0;
     const uint64_t elem_off = sample_offset * (uint64_t)C * H * W;  // global element index of this shard's first value
     DM_REQUIRE(elem_off % 4 == 0, "sample_offset * C * H * W must be a multiple of 4");
@@ -1463,13 +1497,15 @@ static int sample_impl(dm_unet* u, int kind, int n_steps, const int64_t* times_h
     dry.dry = true;
     dry.alloc(n);
     dry.alloc(n);
-    if (cond) dry.alloc(n_in);
+    if (wide) dry.alloc(n_in);
+    if (self_cond) dry.alloc(n);
     if (ctx) dry.alloc(n_ctx);
     const float* ctx_marker = ctx ? reinterpret_cast<const float*>(16) : nullptr;
     if (unet_forward_impl(u, dry, nullptr, nullptr, u->times_dev, u->state_dev, ctx_marker, ctx_tokens, nullptr, B, H, W, s))
         return 1;
     if (ensure_workspace(u, dry.off)) return 1;
 
+    if (u->order_after_previous(s)) return 1;
     SamplerState st_host{};
     st_host.step = 0;
     st_host.n_steps = n_steps;
@@ -1487,26 +1523,33 @@ static int sample_impl(dm_unet* u, int kind, int n_steps, const int64_t* times_h
     A.cap = u->ws_cap;
     float* xbuf = A.alloc(n);
     float* eps = A.alloc(n);
-    float* xin = cond ? A.alloc(n_in) : nullptr;  // [x | cond] per image, what init_conv reads
+    float* xin = wide ? A.alloc(n_in) : nullptr;  // [x | cond] or [x_start | x] per image, what init_conv reads
+    float* xstart = self_cond ? A.alloc(n) : nullptr;  // clamped x_0 estimate of the previous step
     float* ctxbuf = ctx ? A.alloc(n_ctx) : nullptr;
     const std::vector<Arena::Blk> arena_mark = A.blks;  // allocator state in front of a denoise step
     DM_CHECK_HIP(hipMemcpyAsync(xbuf, x_T, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (ctx) DM_CHECK_HIP(hipMemcpyAsync(ctxbuf, ctx, n_ctx * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (cond && launch_copy_channels(cond, xin, B, cond_channels, C + cond_channels, C, H * W, s)) return 1;
+    if (self_cond) DM_CHECK_HIP(hipMemsetAsync(xstart, 0, n * sizeof(float), s));  // x_self_cond = zeros_like(x) (:353)
     if (all_steps) DM_CHECK_HIP(hipMemcpyAsync(all_steps, x_T, n * sizeof(float), hipMemcpyDeviceToDevice, s));
 
     auto one_step = [&](hipStream_t st) -> int {
         A.blks = arena_mark;
-        if (cond && launch_copy_channels(xbuf, xin, B, C, C + cond_channels, 0, H * W, st)) return 1;
-        if (unet_forward_impl(u, A, cond ? xin : xbuf, nullptr, u->times_dev, u->state_dev, ctxbuf, ctx_tokens, eps, B, H,
+        if (cond && launch_copy_channels(xbuf, xin, B, C, Cin, 0, H * W, st)) return 1;
+        if (self_cond && (launch_copy_channels(xstart, xin, B, C, Cin, 0, H * W, st) ||
+                          launch_copy_channels(xbuf, xin, B, C, Cin, C, H * W, st)))
+            return 1;
+        if (unet_forward_impl(u, A, wide ? xin : xbuf, nullptr, u->times_dev, u->state_dev, ctxbuf, ctx_tokens, eps, B, H,
                               W, st))
             return 1;
-        if (launch_sampler_update(kind, xbuf, eps, noise, u->coefs_dev, u->state_dev, n, xbuf, all_steps, nullptr, n, st))
+        if (launch_sampler_update(kind, xbuf, eps, noise, u->coefs_dev, u->state_dev, n, xbuf, all_steps, nullptr, n, st,
+                                  objective, xstart))
             return 1;
         return launch_step_advance(u->state_dev, st);
     };
     auto finish = [&]() -> int {  // out = x_0 [ (x + 1) / 2 ]
         if (launch_finalize(xbuf, out, n, unnormalize, s)) return 1;
+        if (u->mark_done(s)) return 1;
         if (own_stream) DM_CHECK_HIP(hipStreamSynchronize(s));
         return 0;
     };
@@ -1520,6 +1563,7 @@ static int sample_impl(dm_unet* u, int kind, int n_steps, const int64_t* times_h
     }
     dm_unet::GraphKey key;
     key.kind = kind; key.B = B; key.H = H; key.W = W; key.ctx_tokens = ctx_tokens; key.cond_channels = cond_channels;
+    key.objective = objective; key.self_cond = self_cond;
     key.noise = noise; key.all_steps = all_steps; key.ws = u->ws; key.times = u->times_dev; key.coefs = u->coefs_dev;
     if (!u->gexec || !(u->gkey == key)) {
         u->drop_graph();
@@ -1565,6 +1609,13 @@ int dm_sample_cond(dm_unet* u, int kind, int n_steps, const int64_t* times_host,
     DM_REQUIRE(cond && cond_channels > 0, "dm_sample_cond needs a condition image");
     return sample_impl(u, kind, n_steps, times_host, coefs_host, x_T, noise, seed, sample_offset, ctx, ctx_tokens, cond,
                        cond_channels, out, all_steps, B, H, W, unnormalize, use_graph, stream);
+}
+
+int dm_sample_ex(dm_unet* u, const dm_sample_args* a) {
+    DM_REQUIRE(u && a, "null argument");
+    return sample_impl(u, a->kind, a->n_steps, a->times_host, a->coefs_host, a->x_T, a->noise, a->seed, a->sample_offset,
+                       a->ctx, a->ctx_tokens, a->cond, a->cond_channels, a->out, a->all_steps, a->B, a->H, a->W,
+                       a->unnormalize, a->use_graph, a->stream, a->objective, a->self_condition);
 }
 
 int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, uint64_t element_offset, void* stream) {

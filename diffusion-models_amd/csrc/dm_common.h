@@ -38,6 +38,23 @@ void set_error(const std::string& msg);
         }                                                                                   \
     } while (0)
 
+// Opt-in of a kernel to more than 64 KB of dynamic LDS.  hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE
+// attribute, so the "already done" state is kept per device: a process that builds handles on two GPUs (cond_vae on
+// cuda:1 next to the U-Net on cuda:0) opts in on both.  One LdsOptIn per launch site; `n_kernels` = how many kernels
+// that site opts in through it (they are always called in the same order).
+struct LdsOptIn {
+    unsigned char done[64] = {};
+};
+inline int lds_opt_in(LdsOptIn& f, const void* kernel, int n_kernels) {
+    int dev = 0;
+    DM_CHECK_HIP(hipGetDevice(&dev));
+    const bool tracked = dev >= 0 && dev < 64;
+    if (tracked && f.done[dev] >= n_kernels) return 0;
+    DM_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (tracked) ++f.done[dev];
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // Implicit-GEMM convolution on the f32 MFMA (conv_mfma.hip)
 // ---------------------------------------------------------------------------------------
@@ -257,7 +274,7 @@ int launch_pointwise_small(const float* x, const float* w_oc, const float* bias,
 // state_dev == nullptr: one stand-alone update (step 0 of 1, no Philox noise, no unnormalize)
 int launch_sampler_update(int kind, const float* x, const float* eps, const float* noise, const float* coefs_dev,
                           const SamplerState* state_dev, int64_t noise_step_stride, float* out, float* all_steps,
-                          float* final_out, int64_t n, hipStream_t s);
+                          float* final_out, int64_t n, hipStream_t s, int objective = 0, float* xstart_out = nullptr);
 // element e of the tensor uses Philox counter ((element_offset + e) / 4, draw); element_offset % 4 == 0
 int launch_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, uint64_t element_offset, hipStream_t s);
 int launch_step_advance(SamplerState* state_dev, hipStream_t s);

@@ -510,11 +510,14 @@ int launch_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, uint64_t e
 // Contraction is off so that the expression tree rounds exactly like the reference's tensor ops.
 // ---------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
-__global__ void sampler_update_kernel(int kind, const float* __restrict__ x, const float* __restrict__ eps,
-                                      const float* __restrict__ noise, const float* __restrict__ coefs,
-                                      const SamplerState* __restrict__ st, int64_t noise_step_stride,
-                                      float* __restrict__ out, float* __restrict__ all_steps,
-                                      float* __restrict__ final_out, int64_t n) {
+// objective (what the U-Net output `eps` means, :603-626): 0 pred_noise, 1 pred_x0, 2 pred_v.  x_start (clamped, the
+// value both loops hand to the next step as x_self_cond, :657 / :683) is also written to xstart_out when given.
+__global__ void sampler_update_kernel(int kind, int objective, const float* __restrict__ x,
+                                      const float* __restrict__ eps, const float* __restrict__ noise,
+                                      const float* __restrict__ coefs, const SamplerState* __restrict__ st,
+                                      int64_t noise_step_stride, float* __restrict__ out,
+                                      float* __restrict__ all_steps, float* __restrict__ final_out,
+                                      float* __restrict__ xstart_out, int64_t n) {
     // everything that changes between two sample() calls of one shape is read from the device-side state, so a
     // captured step graph stays valid across calls (seed, Philox offset, step count, unnormalize)
     const int step = st ? st->step : 0;
@@ -523,7 +526,7 @@ __global__ void sampler_update_kernel(int kind, const float* __restrict__ x, con
     const uint64_t seed = st ? st->seed : 0;
     const uint64_t off4 = st ? st->off4 : 0;
     const float* c = coefs + (size_t)step * 8;
-    const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4];
+    const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c6 = c[6], c7 = c[7];
     const bool flag = c[5] != 0.0f;
     int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i4 * 4 >= n) return;
@@ -543,8 +546,12 @@ __global__ void sampler_update_kernel(int kind, const float* __restrict__ x, con
         int64_t i = i4 * 4 + j;
         if (i >= n) break;
         float xv = x[i], ev = eps[i];
-        float x0 = c0 * xv - c1 * ev;
+        float x0;
+        if (objective == 0) x0 = c0 * xv - c1 * ev;       // predict_start_from_noise :570-574
+        else if (objective == 1) x0 = ev;                  // the model predicts x_0 :614-617
+        else x0 = c6 * xv - c7 * ev;                       // predict_start_from_v :588-592
         x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        if (xstart_out) xstart_out[i] = x0;
         float r;
         if (kind == 0) {
             float mean = c2 * x0 + c3 * xv;
@@ -575,10 +582,10 @@ int launch_finalize(const float* x, float* out, int64_t n, int unnormalize, hipS
 
 int launch_sampler_update(int kind, const float* x, const float* eps, const float* noise, const float* coefs_dev,
                           const SamplerState* state_dev, int64_t noise_step_stride, float* out, float* all_steps,
-                          float* final_out, int64_t n, hipStream_t s) {
+                          float* final_out, int64_t n, hipStream_t s, int objective, float* xstart_out) {
     int64_t n4 = (n + 3) / 4;
-    hipLaunchKernelGGL(sampler_update_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, kind, x, eps, noise,
-                       coefs_dev, state_dev, noise_step_stride, out, all_steps, final_out, n);
+    hipLaunchKernelGGL(sampler_update_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, kind, objective, x, eps, noise,
+                       coefs_dev, state_dev, noise_step_stride, out, all_steps, final_out, xstart_out, n);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -165,12 +165,8 @@ int init7_launch(const ConvParams& pin, hipStream_t s) {
     const int n_steps = i7_ksteps(p.C0);
     const size_t lds = ((size_t)n_steps * 4 * 64 + std::max((size_t)p.C0 * I7_WR * I7_WS, (size_t)4 * 32 * I7_TS)) * 4;
     DM_REQUIRE(lds <= 160 * 1024, "init7: LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(init7_mfma_kernel<8>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsOptIn lds_flag;
+    if (lds_opt_in(lds_flag, reinterpret_cast<const void*>(init7_mfma_kernel<8>), 1)) return 1;
     const int blocks = p.B * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16);
     const bool timed = prof::enabled();
     if (timed) {

@@ -381,14 +381,9 @@ int launch_linattn_bf16x6(const LinAttnFused& w, const float* x, float* ws, floa
     const int nblk = (n + LB_TOK1 - 1) / LB_TOK1;
     const size_t lds1 = (size_t)3 * LB_TOK1 * (C + 8) * 2 + LB_TOK1 * 4;
     const size_t lds2 = (size_t)(LB_TOK2 * (C + 4) + LB_TOK2 + LB_HEADS * 32 * (C + 4)) * 4 + (size_t)3 * LB_TOK2 * (C + 8) * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_ctx_bf16x6_kernel<C>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_out_bf16x6_kernel<C>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsOptIn lds_flag;
+    if (lds_opt_in(lds_flag, reinterpret_cast<const void*>(linattn_ctx_bf16x6_kernel<C>), 2)) return 1;
+    if (lds_opt_in(lds_flag, reinterpret_cast<const void*>(linattn_out_bf16x6_kernel<C>), 2)) return 1;
     const bool timed = prof::enabled();
     const double tokens = (double)B * n;
     if (timed && prof::begin("linattn_ctx_bf16x6_kernel", 2.0 * tokens * (2.0 * LB_HID * C + LB_HID * LB_DH),

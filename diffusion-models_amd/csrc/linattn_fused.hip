@@ -346,12 +346,8 @@ __global__ __launch_bounds__(256) void linattn_out_fused_kernel(const float* __r
 template <int C, int TOK1>
 static int launch_ctx(const LinAttnFused& w, const float* x, float* ws, int B, int n, int nblk, hipStream_t s) {
     const size_t lds1 = (size_t)(TOK1 * (C + 4) + TOK1) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_ctx_fused_kernel<C, TOK1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsOptIn lds_flag;
+    if (lds_opt_in(lds_flag, reinterpret_cast<const void*>(linattn_ctx_fused_kernel<C, TOK1>), 1)) return 1;
     hipLaunchKernelGGL((linattn_ctx_fused_kernel<C, TOK1>), dim3(nblk, B), dim3(256), lds1, s, x, w, ws, n, nblk);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
@@ -364,12 +360,8 @@ static int launch_c(const LinAttnFused& w, const float* x, float* ws, float* y, 
     const int tok1 = big ? 256 : LA_TOK1;
     const int nblk = (n + tok1 - 1) / tok1;
     const size_t lds2 = (size_t)(LA_TOK2 * (C + 4) + LA_TOK2 + LA_HEADS * 32 * (C + 4)) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_out_fused_kernel<C>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsOptIn lds_flag;
+    if (lds_opt_in(lds_flag, reinterpret_cast<const void*>(linattn_out_fused_kernel<C>), 1)) return 1;
     const bool timed = prof::enabled();
     const double tokens = (double)B * n;
     if (timed && prof::begin("linattn_ctx_fused_kernel", 2.0 * tokens * (2.0 * LA_HID * C + LA_HID * LA_DH),

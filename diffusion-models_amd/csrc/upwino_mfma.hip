@@ -377,12 +377,8 @@ __global__ __launch_bounds__(256, 1) void upwino_mfma_kernel(const ConvParams p)
 
 template <int CLS>
 static int upwino_launch_t(const ConvParams& p, int blocks, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(upwino_mfma_kernel<CLS>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsOptIn lds_flag;
+    if (lds_opt_in(lds_flag, reinterpret_cast<const void*>(upwino_mfma_kernel<CLS>), 1)) return 1;
     hipLaunchKernelGGL(upwino_mfma_kernel<CLS>, dim3(blocks, p.geo.splits, 1), dim3(256), p.geo.lds_bytes, s, p);
     DM_CHECK_HIP(hipGetLastError());
     return 0;

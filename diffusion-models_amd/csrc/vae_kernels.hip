@@ -159,12 +159,8 @@ int launch_vae_attn_mfma(const float* q, const float* k, const float* v, float* 
     const size_t lds = (size_t)4 * 32 * (C + 4) * sizeof(float);
 #define DM_VAE_ATTN(CB_)                                                                                              \
     {                                                                                                                 \
-        static bool attr = false;                                                                                     \
-        if (!attr) {                                                                                                  \
-            DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vae_attn_mfma_kernel<CB_>),                \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                \
-            attr = true;                                                                                              \
-        }                                                                                                             \
+        static LdsOptIn lds_flag; \
+        if (lds_opt_in(lds_flag, reinterpret_cast<const void*>(vae_attn_mfma_kernel<CB_>), 1)) return 1;                                                                                                             \
         hipLaunchKernelGGL(vae_attn_mfma_kernel<CB_>, grid, block, lds, s, q, k, v, out, n, scale_log2e);             \
     }
     if (C == 64) DM_VAE_ATTN(2)

@@ -566,12 +566,8 @@ __global__ __launch_bounds__(256, 1) void wino4_mfma_kernel(const ConvParams p) 
 
 template <int LTW>
 static int wino4_launch_t(const ConvParams& p, int blocks, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_mfma_kernel<LTW>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsOptIn lds_flag;
+    if (lds_opt_in(lds_flag, reinterpret_cast<const void*>(wino4_mfma_kernel<LTW>), 1)) return 1;
 #ifdef DM_STAMPS
     // diagnostic build: run the launch synchronously with a stamp buffer and print the phase averages
     {

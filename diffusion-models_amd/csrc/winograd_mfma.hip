@@ -494,12 +494,8 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
 
 template <int R>
 static int wino_launch_r(const ConvParams& p, int blocks, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        DM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_mfma_kernel<R>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsOptIn lds_flag;
+    if (lds_opt_in(lds_flag, reinterpret_cast<const void*>(wino_mfma_kernel<R>), 1)) return 1;
 #ifdef DM_STAMPS
     // diagnostic build: run the launch synchronously with a stamp buffer and print the phase averages
     {

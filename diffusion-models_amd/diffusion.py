@@ -75,11 +75,8 @@ class DenoisingDiffusion:
         )
         self.image_size = tuple(image_size)
         assert objective in {"pred_noise", "pred_x0", "pred_v"}, "objective must be pred_noise, pred_x0 or pred_v"
-        if objective != "pred_noise":
-            raise NotImplementedError("the HIP sampling path implements objective='pred_noise' (the reference default)")
-        if self.self_condition:
-            raise NotImplementedError("self-conditioning is not on the accelerated sampling path")
         self.objective = objective
+        self._objective_id = _lib.OBJECTIVES[objective]
         sched = make_schedule(timesteps, beta_schedule, **schedule_fn_kwargs)  # raises ValueError on unknown name
         self.num_timesteps = int(sched["betas"].shape[0])
         self.sampling_timesteps = sampling_timesteps if sampling_timesteps is not None else self.num_timesteps
@@ -102,6 +99,12 @@ class DenoisingDiffusion:
 
     def eval(self):
         return self
+
+    def sample_shape(self):
+        """(C, H, W) of one sample as ``sample()`` returns it (``dist.sample_global`` builds empty shards from it)."""
+        (h, w), c = self.image_size, self.channels
+        vae = getattr(self, "vae", None)
+        return tuple(vae.decoded_shape((c, h, w))) if vae is not None else (c, h, w)
 
     def state_dict(self):
         return {k: getattr(self, k) for k in SCHEDULE_BUFFERS}
@@ -171,19 +174,19 @@ class DenoisingDiffusion:
         coefs = coefs[:n_steps].contiguous()
         coefs_ptr = C.cast(coefs.data_ptr(), C.POINTER(C.c_float))
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        a = _lib.SampleArgs()
+        a.kind, a.objective, a.self_condition, a.n_steps = kind, self._objective_id, int(bool(self.self_condition)), n_steps
+        a.times_host, a.coefs_host = C.cast(times_arr, C.POINTER(C.c_int64)), coefs_ptr
+        a.x_T, a.noise, a.seed, a.sample_offset = _lib.ptr(x_T), _lib.ptr(noise_dev), seed, sample_offset
+        a.ctx, a.ctx_tokens = _lib.ptr(ctx), m
         if cond is not None:
             cond = cond.to(self.device, torch.float32).contiguous()
             assert cond.shape[0] == B and tuple(cond.shape[2:]) == (H, W), "batch / size mismatch between x and cond"
-            _lib.check(self._lib.dm_sample_cond(
-                self.model._handle, kind, n_steps, times_arr, coefs_ptr, _lib.ptr(x_T), _lib.ptr(noise_dev),
-                C.c_uint64(seed), C.c_uint64(sample_offset), _lib.ptr(ctx), m, _lib.ptr(cond), int(cond.shape[1]),
-                _lib.ptr(out),
-                _lib.ptr(all_steps), B, H, W, self._unnormalize_flag, 1 if self.use_graph else 0, stream))
-        else:
-            _lib.check(self._lib.dm_sample(
-                self.model._handle, kind, n_steps, times_arr, coefs_ptr, _lib.ptr(x_T), _lib.ptr(noise_dev),
-                C.c_uint64(seed), C.c_uint64(sample_offset), _lib.ptr(ctx), m, _lib.ptr(out), _lib.ptr(all_steps), B, H, W,
-                self._unnormalize_flag, 1 if self.use_graph else 0, stream))
+            a.cond, a.cond_channels = _lib.ptr(cond), int(cond.shape[1])
+        a.out, a.all_steps = _lib.ptr(out), _lib.ptr(all_steps)
+        a.B, a.H, a.W = B, H, W
+        a.unnormalize, a.use_graph, a.stream = self._unnormalize_flag, 1 if self.use_graph else 0, stream
+        _lib.check(self._lib.dm_sample_ex(self.model._handle, C.byref(a)))
         if not return_all_timesteps:
             return out
         ret = all_steps.permute(1, 0, 2, 3, 4).contiguous()  # (B, n_steps+1, C, H, W) like torch.stack(imgs, dim=1)
@@ -217,39 +220,39 @@ class DenoisingDiffusion:
         """The U-Net call of ``model_predictions`` (:603-606); subclasses thread their condition through ``cond_kw``."""
         return self.model(x, bt, **cond_kw)
 
-    def _p_sample(self, x, t: int, noise, cond_kw):
+    def _p_sample(self, x, t: int, noise, cond_kw, x_self_cond=None):
         """One reverse step (denoising_diffusion.py:638-645): (pred_img, x_start); the update runs in sampler_update_kernel."""
         b = x.shape[0]
         t = int(t)
         x = x.to(self.device, torch.float32).contiguous()
         bt = torch.full((b,), t, device=self.device, dtype=torch.long)
+        if self.self_condition:
+            cond_kw = dict(cond_kw, x_self_cond=x_self_cond)
+        else:
+            assert x_self_cond is None, "the model was built without self_condition"
         eps = self._eps(x, bt, **cond_kw)
         s = self._sched
-        c0, c1 = s["sqrt_recip_alphas_cumprod"][t], s["sqrt_recipm1_alphas_cumprod"][t]
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        # x_start through the DDIM form of the update kernel with the "last step" flag (returns clamp(x0))
-        coef0 = (C.c_float * _lib.DM_COEFS)(float(c0), float(c1), 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
-        x_start = torch.empty_like(x)
-        _lib.check(self._lib.dm_op_sampler_update(DDIM, _lib.ptr(x), _lib.ptr(eps), None, coef0, _lib.ptr(x_start),
-                                                  x.numel(), stream))
-        coef = (C.c_float * _lib.DM_COEFS)(float(c0), float(c1), float(s["posterior_mean_coef1"][t]),
-                                           float(s["posterior_mean_coef2"][t]),
+        coef = (C.c_float * _lib.DM_COEFS)(float(s["sqrt_recip_alphas_cumprod"][t]),
+                                           float(s["sqrt_recipm1_alphas_cumprod"][t]),
+                                           float(s["posterior_mean_coef1"][t]), float(s["posterior_mean_coef2"][t]),
                                            float((0.5 * s["posterior_log_variance_clipped"][t]).exp()),
-                                           1.0 if t > 0 else 0.0, 0.0, 0.0)
+                                           1.0 if t > 0 else 0.0, float(s["sqrt_alphas_cumprod"][t]),
+                                           float(s["sqrt_one_minus_alphas_cumprod"][t]))
         z = None
         if t > 0:
             z = (noise(x.shape).to(self.device, torch.float32).contiguous() if noise is not None
                  else self._randn(x.shape, _default_seed(), 1))
         out = torch.empty_like(x)
-        _lib.check(self._lib.dm_op_sampler_update(DDPM, _lib.ptr(x), _lib.ptr(eps), _lib.ptr(z), coef, _lib.ptr(out),
-                                                  x.numel(), stream))
+        x_start = torch.empty_like(x)
+        _lib.check(self._lib.dm_op_sampler_update(DDPM, self._objective_id, _lib.ptr(x), _lib.ptr(eps), _lib.ptr(z), coef,
+                                                  _lib.ptr(out), _lib.ptr(x_start), x.numel(), stream))
         return out, x_start
 
     @torch.inference_mode()
     def p_sample(self, x, t: int, x_self_cond=None, *, noise=None):
         """:638-645.  Returns (pred_img, x_start)."""
-        assert x_self_cond is None, "self-conditioning is not on the accelerated sampling path"
-        return self._p_sample(x, t, noise, {})
+        return self._p_sample(x, t, noise, {}, x_self_cond)
 
 
 class TextConditionalDenoisingDiffusion(DenoisingDiffusion):
@@ -309,8 +312,7 @@ class TextConditionalDenoisingDiffusion(DenoisingDiffusion):
     @torch.inference_mode()
     def p_sample(self, x, t: int, text_emb=None, x_self_cond=None, *, noise=None):
         """denoising_diffusion_text_conditional.py:310-317 (the reference's positional order: x, t, text_emb)."""
-        assert x_self_cond is None, "self-conditioning is not on the accelerated sampling path"
-        return self._p_sample(x, t, noise, {"text_emb": text_emb} if text_emb is not None else {})
+        return self._p_sample(x, t, noise, {"text_emb": text_emb} if text_emb is not None else {}, x_self_cond)
 
 
 class ImageConditionalDenoisingDiffusion(DenoisingDiffusion):
@@ -376,9 +378,8 @@ class ImageConditionalDenoisingDiffusion(DenoisingDiffusion):
     @torch.inference_mode()
     def p_sample(self, x, t: int, cond=None, x_self_cond=None, *, noise=None):
         """denoising_diffusion_image_conditional.py:114-120: ``cond`` is what the U-Net sees behind x."""
-        assert x_self_cond is None, "self-conditioning is not on the accelerated sampling path"
         assert cond is not None, "the image-conditional U-Net needs cond="
-        return self._p_sample(x, t, noise, {"cond": cond})
+        return self._p_sample(x, t, noise, {"cond": cond}, x_self_cond)
 
 
 class LatentDiffusion(DenoisingDiffusion):

@@ -48,7 +48,10 @@ def gather_shards(local: torch.Tensor, batch_size: int, group=None) -> torch.Ten
 def sample_sharded(sample_fn: Callable[[int, int], torch.Tensor], batch_size: int, group=None) -> torch.Tensor:
     """`sample_fn(lo, hi)` produces samples [lo, hi) of the global batch on this rank's GPU
     (key any randomness by the GLOBAL sample index so the result does not depend on the world size:
-    ``diffusion.sample(batch_size=hi - lo, seed=seed, sample_offset=lo)`` does, see :func:`sample_global`)."""
+    ``diffusion.sample(batch_size=hi - lo, seed=seed, sample_offset=lo)`` does, see :func:`sample_global`).
+
+    A rank whose slice is empty (batch_size < world size, e.g. the remainder group of an FID run) must return a
+    ``(0, ...)`` tensor from `sample_fn` -- it still enters the collective, so the other ranks do not hang."""
     if not (dist.is_available() and dist.is_initialized()):
         return sample_fn(0, batch_size)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -68,10 +71,46 @@ def shared_seed(seed=None, group=None) -> int:
     return int(t.item())
 
 
+def _slice_batch_kwargs(kw: dict, batch_size: int, lo: int, hi: int) -> dict:
+    """Per-sample keyword tensors (dim 0 == the GLOBAL batch: ``text_emb=``, ``cond=``) cut to this rank's rows."""
+    out = {}
+    for k, v in kw.items():
+        if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == batch_size:
+            v = v[lo:hi]
+        out[k] = v
+    return out
+
+
+def _sample_shape(diffusion) -> Tuple[int, ...]:
+    """(C, H, W) of what ``diffusion.sample`` returns per sample, without running it (the empty-shard result)."""
+    probe = getattr(diffusion, "sample_shape", None)
+    if callable(probe):
+        return tuple(probe())
+    (h, w), c = diffusion.image_size, diffusion.channels
+    return (c, h, w)
+
+
 def sample_global(diffusion, batch_size: int, seed=None, group=None, **sample_kw) -> torch.Tensor:
     """``diffusion.sample(batch_size)`` with the batch sharded over the ranks of `group` and ONE all-gather at the
     end.  Every rank draws the noise of ITS global sample indices (Philox counter = global element index), so the
-    result is the same tensor for any world size, including 1."""
+    result is the same tensor for any world size, including 1.
+
+    Conditions are per-sample data and are sharded like the batch: a keyword tensor whose dim 0 equals `batch_size`
+    (``text_emb=``, ``cond=``) is sliced to the rank's rows.  A text-conditional model called WITHOUT ``text_emb=``
+    would draw different random captions on every rank and for every world size, so that combination is refused here:
+    draw the embeddings once (``diffusion.get_random_text_condition(batch_size, device)`` on rank 0 + broadcast, or any
+    fixed tensor) and pass them in.  Ranks whose slice is empty (batch_size < world size) skip the library call and
+    contribute a (0, C, H, W) tensor, so every rank still enters the collective."""
+    if getattr(getattr(diffusion, "model", None), "text_condition", False) and sample_kw.get("text_emb") is None:
+        raise ValueError("sample_global on a text-conditional model needs text_emb= (B, E): every rank would otherwise "
+                         "draw its own random captions")
     seed = shared_seed(seed, group)
-    return sample_sharded(lambda lo, hi: diffusion.sample(batch_size=hi - lo, seed=seed, sample_offset=lo, **sample_kw),
-                          batch_size, group)
+
+    def shard(lo: int, hi: int) -> torch.Tensor:
+        if hi == lo:
+            dev = getattr(diffusion, "device", "cpu")
+            return torch.zeros((0,) + _sample_shape(diffusion), dtype=torch.float32, device=dev)
+        return diffusion.sample(batch_size=hi - lo, seed=seed, sample_offset=lo,
+                                **_slice_batch_kwargs(sample_kw, batch_size, lo, hi))
+
+    return sample_sharded(shard, batch_size, group)

@@ -70,7 +70,8 @@ class InceptionV3:
     DEFAULT_BLOCK_INDEX = 3
 
     def __init__(self, output_blocks: Sequence[int] = (3,), resize_input=True, normalize_input=True, requires_grad=False,
-                 variant="fid", state_dict: Optional[Dict[str, torch.Tensor]] = None, device="cuda:0"):
+                 variant="fid", state_dict: Optional[Dict[str, torch.Tensor]] = None, device="cuda:0",
+                 allow_synthetic=False):
         assert variant in ("fid", "torchvision")
         self.output_blocks = sorted(output_blocks)
         assert max(self.output_blocks) <= 3, "Last possible output block index is 3"
@@ -78,7 +79,14 @@ class InceptionV3:
         self.device = torch.device(device)
         self._dev_index = _device_index(device)
         self._lib = _lib.load()
+        self.synthetic_weights = state_dict is None
         if state_dict is None:
+            if not allow_synthetic:
+                # the reference fails here too (its constructors download the pretrained weights); returning
+                # plausible-looking scores from random weights would be worse
+                raise RuntimeError("InceptionV3 needs state_dict= (the pytorch_fid / torchvision pretrained weights, "
+                                   "same key names); pass allow_synthetic=True for name-seeded random weights "
+                                   "(kernel tests only: FID / IS values computed with them are meaningless)")
             warnings.warn("InceptionV3 without state_dict=: name-seeded SYNTHETIC weights (no network to fetch the "
                           "pretrained ones); FID / IS values computed with them are meaningless")
             state_dict = synth_state_dict(inception_param_spec(), salt=0)
@@ -281,13 +289,14 @@ class FIDEvaluation:
     """fid_evaluation.py:15-133 with the Inception features computed by the HIP path."""
 
     def __init__(self, batch_size, dl, sampler, channels=3, accelerator=None, stats_dir="./results", device="cuda:0",
-                 num_fid_samples=50000, inception_block_idx=2048, inception_state_dict=None):
+                 num_fid_samples=50000, inception_block_idx=2048, inception_state_dict=None, allow_synthetic=False):
         self.batch_size, self.n_samples, self.device, self.channels = batch_size, num_fid_samples, device, channels
         self.dl, self.sampler, self.stats_dir = dl, sampler, stats_dir
         self.print_fn = print if accelerator is None else accelerator.print
         assert inception_block_idx in InceptionV3.BLOCK_INDEX_BY_DIM
         self.inception_v3 = InceptionV3([InceptionV3.BLOCK_INDEX_BY_DIM[inception_block_idx]],
-                                        state_dict=inception_state_dict, device=device)
+                                        state_dict=inception_state_dict, device=device,
+                                        allow_synthetic=allow_synthetic)
         self.dataset_stats_loaded = False
 
     def calculate_inception_features(self, samples):
@@ -300,7 +309,10 @@ class FIDEvaluation:
 
     def load_or_precalc_dataset_stats(self):
         path = os.path.join(self.stats_dir, "dataset_stats")
+        synthetic = self.inception_v3.synthetic_weights  # random weights: never read or write the statistics cache
         try:
+            if synthetic:
+                raise OSError("synthetic weights")
             ckpt = np.load(path + ".npz")
             self.m2, self.s2 = ckpt["m2"], ckpt["s2"]
             self.print_fn("Dataset stats loaded from disk.")
@@ -317,9 +329,10 @@ class FIDEvaluation:
                 feats.append(self.calculate_inception_features(real_samples.to(self.device)))
             feats = torch.cat(feats, dim=0).cpu().numpy()
             m2, s2 = np.mean(feats, axis=0), np.cov(feats, rowvar=False)
-            os.makedirs(self.stats_dir, exist_ok=True)
-            np.savez_compressed(path, m2=m2, s2=s2)
-            self.print_fn(f"Dataset stats cached to {path}.npz for future use.")
+            if not synthetic:
+                os.makedirs(self.stats_dir, exist_ok=True)
+                np.savez_compressed(path, m2=m2, s2=s2)
+                self.print_fn(f"Dataset stats cached to {path}.npz for future use.")
             self.m2, self.s2 = m2, s2
         self.dataset_stats_loaded = True
 
@@ -341,11 +354,12 @@ class InceptionScoreEvaluation:
     """inception_score_evaluation.py:11-113 with the logits computed by the HIP path."""
 
     def __init__(self, batch_size, sampler, channels=3, accelerator=None, stats_dir="./results", device="cuda:0",
-                 num_samples=50000, inception_state_dict=None):
+                 num_samples=50000, inception_state_dict=None, allow_synthetic=False):
         self.batch_size, self.n_samples, self.device, self.channels = batch_size, num_samples, device, channels
         self.sampler, self.stats_dir = sampler, stats_dir
         self.print_fn = print if accelerator is None else accelerator.print
-        self.inception_model = InceptionV3(variant="torchvision", state_dict=inception_state_dict, device=device)
+        self.inception_model = InceptionV3(variant="torchvision", state_dict=inception_state_dict, device=device,
+                                           allow_synthetic=allow_synthetic)
         os.makedirs(stats_dir, exist_ok=True)
         self.log_path = os.path.join(stats_dir, "inception_score_log.txt")
 

@@ -294,7 +294,8 @@ DM_COEFS = 8  # floats per step row handed to dm_sample (include/dm_hip.h)
 def ddpm_step_table(sched: Dict[str, torch.Tensor]) -> Tuple[List[int], torch.Tensor]:
     """Per-step scalars of p_sample_loop, computed with the reference's own fp32
     tensor arithmetic (denoising_diffusion.py:570-574, :594-601, :643-644).
-    Row i (t = T-1-i): [sqrt_recip_ac, sqrt_recipm1_ac, coef1, coef2, exp(0.5*logvar), t>0, 0, 0]."""
+    Row i (t = T-1-i): [sqrt_recip_ac, sqrt_recipm1_ac, coef1, coef2, exp(0.5*logvar), t>0, sqrt_ac, sqrt_1m_ac]
+    (the last two feed predict_start_from_v, :588-592, objective pred_v)."""
     T = int(sched["betas"].shape[0])
     times = list(reversed(range(T)))
     idx = torch.tensor(times)
@@ -305,12 +306,14 @@ def ddpm_step_table(sched: Dict[str, torch.Tensor]) -> Tuple[List[int], torch.Te
     c[:, 3] = sched["posterior_mean_coef2"][idx]
     c[:, 4] = (0.5 * sched["posterior_log_variance_clipped"][idx]).exp()
     c[:, 5] = (idx > 0).to(torch.float32)
+    c[:, 6] = sched["sqrt_alphas_cumprod"][idx]
+    c[:, 7] = sched["sqrt_one_minus_alphas_cumprod"][idx]
     return times, c
 
 
 def ddim_step_table(sched: Dict[str, torch.Tensor], sampling_timesteps: int, eta: float) -> Tuple[List[int], torch.Tensor]:
     """Per-step scalars of ddim_sample (denoising_diffusion.py:684-701) on 0-dim fp32 tensors.
-    Row i: [sqrt_recip_ac[t], sqrt_recipm1_ac[t], sqrt(alpha_next), c, sigma, t_next>=0, 0, 0]."""
+    Row i: [sqrt_recip_ac[t], sqrt_recipm1_ac[t], sqrt(alpha_next), c, sigma, t_next>=0, sqrt_ac[t], sqrt_1m_ac[t]]."""
     T = int(sched["betas"].shape[0])
     pairs = ddim_time_pairs(T, sampling_timesteps)
     ac = sched["alphas_cumprod"]
@@ -318,6 +321,8 @@ def ddim_step_table(sched: Dict[str, torch.Tensor], sampling_timesteps: int, eta
     for i, (t, tn) in enumerate(pairs):
         c[i, 0] = sched["sqrt_recip_alphas_cumprod"][t]
         c[i, 1] = sched["sqrt_recipm1_alphas_cumprod"][t]
+        c[i, 6] = sched["sqrt_alphas_cumprod"][t]
+        c[i, 7] = sched["sqrt_one_minus_alphas_cumprod"][t]
         if tn < 0:
             continue  # flag 0: img = x_start (:686-689)
         alpha, alpha_next = ac[t], ac[tn]

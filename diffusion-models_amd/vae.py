@@ -71,6 +71,11 @@ class VQDecoder:
         self._loaded = True
         return self
 
+    def decoded_shape(self, latent_chw):
+        """(C, H, W) of ``decode`` for one latent of shape (embed_dim, h, w)."""
+        f = 2 ** (self.cfg.num_resolutions - 1)
+        return (self.cfg.out_ch, int(latent_chw[1]) * f, int(latent_chw[2]) * f)
+
     @torch.inference_mode()
     def decode(self, quant):
         if not self._loaded:
@@ -205,4 +210,7 @@ class VQModel:
 
     def decode(self, quant):
         return self.decoder.decode(quant)
+
+    def decoded_shape(self, latent_chw):
+        return self.decoder.decoded_shape(latent_chw)
 

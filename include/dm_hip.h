@@ -125,6 +125,12 @@ int dm_unet_forward(dm_unet* u, const float* x, const int64_t* time, const float
 #define DM_COEFS 8
 #define DM_SAMPLER_DDPM 0
 #define DM_SAMPLER_DDIM 1
+/* what the U-Net output means (`objective` of DenoisingDiffusion.__init__, DD/denoising_diffusion.py:443; branches of
+ * model_predictions :607-624).  pred_v reads c[6]=sqrt_alphas_cumprod[t], c[7]=sqrt_one_minus_alphas_cumprod[t]
+ * (predict_start_from_v :588-592) from the step table. */
+#define DM_OBJ_PRED_NOISE 0
+#define DM_OBJ_PRED_X0 1
+#define DM_OBJ_PRED_V 2
 
 int dm_sample(dm_unet* u, int kind, int n_steps, const int64_t* times_host, const float* coefs_host,
               const float* x_T, const float* noise, uint64_t seed, uint64_t sample_offset, const float* ctx,
@@ -139,6 +145,35 @@ int dm_sample_cond(dm_unet* u, int kind, int n_steps, const int64_t* times_host,
                    const float* x_T, const float* noise, uint64_t seed, uint64_t sample_offset, const float* ctx,
                    int ctx_tokens, const float* cond, int cond_channels, float* out, float* all_steps, int B, int H,
                    int W, int unnormalize, int use_graph, void* stream);
+
+/* The general form of the two calls above: every option of the loop in one struct (zero-initialise it; unused fields
+ * stay 0 / NULL).  objective: DM_OBJ_*.  self_condition != 0: the handle was built with input_channels == 2*channels and
+ * every step feeds the U-Net [x_start of the previous step | x] (zeros at the first step), as p_sample_loop / ddim_sample
+ * do when model.self_condition is set (DD/denoising_diffusion.py:352-354,:657,:683); not combined with cond. */
+typedef struct dm_sample_args {
+    int32_t kind;           /* DM_SAMPLER_* */
+    int32_t objective;      /* DM_OBJ_* */
+    int32_t self_condition;
+    int32_t n_steps;
+    const int64_t* times_host;
+    const float* coefs_host;
+    const float* x_T;
+    const float* noise;
+    uint64_t seed;
+    uint64_t sample_offset;
+    const float* ctx;
+    int32_t ctx_tokens;
+    int32_t cond_channels;
+    const float* cond;
+    float* out;
+    float* all_steps;
+    int32_t B, H, W;
+    int32_t unnormalize;
+    int32_t use_graph;
+    int32_t reserved_;
+    void* stream;
+} dm_sample_args;
+int dm_sample_ex(dm_unet* u, const dm_sample_args* args);
 
 /* N(0,1) noise from the library's Philox4x32-10 stream (what dm_sample uses when noise == NULL);
  * element e of the tensor of draw `draw` uses counter ((element_offset + e)/4, draw) under key `seed`
@@ -225,9 +260,10 @@ int dm_op_linear_attention(const float* x, const float* norm_g, const float* mem
 int dm_op_attention(const float* x, const float* norm_g, const float* mem_kv, const float* w_qkv,
                     const float* w_out, const float* b_out, float* out, int B, int C, int H, int W, int heads,
                     int dim_head, void* stream);
-/* one DDPM / DDIM update on (n) elements given eps = model output; c = DM_COEFS floats (host) */
-int dm_op_sampler_update(int kind, const float* x, const float* eps, const float* noise, const float* c_host,
-                         float* out, int64_t n, void* stream);
+/* one DDPM / DDIM update on (n) elements given eps = model output (meaning per `objective`, DM_OBJ_*); c = DM_COEFS
+ * floats (host); x_start (optional) receives the clamped x_0 estimate of the step (pred_x_start of model_predictions) */
+int dm_op_sampler_update(int kind, int objective, const float* x, const float* eps, const float* noise,
+                         const float* c_host, float* out, float* x_start, int64_t n, void* stream);
 
 /* ---- sample consumer: the InceptionV3 feature extractor behind the reference's FID and
  *      Inception-score evaluators (DD/fid_evaluation.py:41-51 -> pytorch_fid.inception.InceptionV3;

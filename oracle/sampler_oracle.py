@@ -51,12 +51,33 @@ def predict_noise_from_start(sched, x_t, t: int, x0):
     return (_tbl(sched, "sqrt_recip_alphas_cumprod", t) * x_t - x0) / _tbl(sched, "sqrt_recipm1_alphas_cumprod", t)
 
 
-def p_sample(model: Model, sched, x: torch.Tensor, t: int, noise: Optional[torch.Tensor]):
-    """DD/denoising_diffusion.py:638-645 (+ :628-636, :594-601) for objective pred_noise."""
-    b = x.shape[0]
-    bt = torch.full((b,), t, dtype=torch.long)
-    eps = model(x, bt)
-    x0 = predict_start_from_noise(sched, x, t, eps).clamp(-1.0, 1.0)
+def predict_start_from_v(sched, x_t, t: int, v):
+    """DD/denoising_diffusion.py:588-592."""
+    return _tbl(sched, "sqrt_alphas_cumprod", t) * x_t - _tbl(sched, "sqrt_one_minus_alphas_cumprod", t) * v
+
+
+def _call(model: Model, x, bt, x_self_cond):
+    # the model takes x_self_cond only when the loop carries one (self_condition=True)
+    return model(x, bt) if x_self_cond is None else model(x, bt, x_self_cond)
+
+
+def model_x_start(model: Model, sched, x, t: int, objective: str = "pred_noise", x_self_cond=None):
+    """``model_predictions(...).pred_x_start`` before clipping (DD/denoising_diffusion.py:603-624)."""
+    bt = torch.full((x.shape[0],), t, dtype=torch.long)
+    out = _call(model, x, bt, x_self_cond)
+    if objective == "pred_noise":
+        return predict_start_from_noise(sched, x, t, out)
+    if objective == "pred_x0":
+        return out
+    if objective == "pred_v":
+        return predict_start_from_v(sched, x, t, out)
+    raise ValueError(f"unknown objective {objective}")
+
+
+def p_sample(model: Model, sched, x: torch.Tensor, t: int, noise: Optional[torch.Tensor], objective: str = "pred_noise",
+             x_self_cond=None):
+    """DD/denoising_diffusion.py:638-645 (+ :628-636, :594-601)."""
+    x0 = model_x_start(model, sched, x, t, objective, x_self_cond).clamp(-1.0, 1.0)
     mean = _tbl(sched, "posterior_mean_coef1", t) * x0 + _tbl(sched, "posterior_mean_coef2", t) * x
     logvar = _tbl(sched, "posterior_log_variance_clipped", t)
     if t > 0:
@@ -73,16 +94,21 @@ def p_sample_loop(
     unnormalize: bool = True,
     return_all_timesteps: bool = False,
     num_steps: Optional[int] = None,
+    objective: str = "pred_noise",
+    self_condition: bool = False,
 ):
     """DD/denoising_diffusion.py:647-664.  ``num_steps`` (oracle-only) stops
-    after that many iterations, for timing a bounded sample of the loop."""
+    after that many iterations, for timing a bounded sample of the loop.
+    ``self_condition``: the model is called as ``model(x, t, x_self_cond)`` with the previous step's x_start (:657)."""
     T = sched["betas"].shape[0]
     img = noise(shape)
     imgs = [img]
     done = 0
+    x_start = None
     for t in reversed(range(T)):
         z = noise(shape) if t > 0 else None
-        img, _ = p_sample(model, sched, img, t, z)
+        sc = (x_start if x_start is not None else torch.zeros_like(img)) if self_condition else None
+        img, x_start = p_sample(model, sched, img, t, z, objective, sc)
         imgs.append(img)
         done += 1
         if num_steps is not None and done >= num_steps:
@@ -108,17 +134,18 @@ def ddim_sample(
     eta: float = 0.0,
     unnormalize: bool = True,
     return_all_timesteps: bool = False,
+    objective: str = "pred_noise",
+    self_condition: bool = False,
 ):
-    """DD/denoising_diffusion.py:666-708 for objective pred_noise."""
+    """DD/denoising_diffusion.py:666-708."""
     T = sched["betas"].shape[0]
-    b = shape[0]
     img = noise(shape)
     imgs = [img]
     ac = sched["alphas_cumprod"]
+    x0 = None
     for t, t_next in ddim_pairs(T, sampling_timesteps):
-        bt = torch.full((b,), t, dtype=torch.long)
-        eps = model(img, bt)
-        x0 = predict_start_from_noise(sched, img, t, eps).clamp(-1.0, 1.0)
+        sc = (x0 if x0 is not None else torch.zeros_like(img)) if self_condition else None
+        x0 = model_x_start(model, sched, img, t, objective, sc).clamp(-1.0, 1.0)
         eps = predict_noise_from_start(sched, img, t, x0)
         if t_next < 0:
             img = x0

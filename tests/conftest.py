@@ -72,3 +72,10 @@ def golden_encoder():
 def golden_configs():
     """BASELINE configs 3 / 4 / 5 as workloads, from the reference (tests/golden/make_golden_configs.py)."""
     return load_golden("configs.pt")
+
+
+@pytest.fixture(scope="session")
+def golden_r3():
+    """Round-3 fixtures from the reference (tests/golden/make_golden_r3.py): the LDM YAML shapes (3x16x16 / 3x8x8 latents,
+    the ch_mult (1,2,4,8) VQModel), objectives pred_x0 / pred_v, self-conditioning."""
+    return load_golden("r3.pt")

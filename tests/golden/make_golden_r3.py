@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Round-3 golden vectors, generated from the REFERENCE itself (build container only):
+``python tests/golden/make_golden_r3.py``  ->  ``tests/golden/r3.pt``.
+
+* the shapes the reference's own LDM YAMLs produce (latent-diffusion/train/configs/ldm_cifar.yaml: latents 3x16x16;
+  ldm_text_conditional_coco.yaml:8-18: VAE ``ch_mult [1,2,4,8]`` at resolution 64 -> latents 3x8x8) through the
+  4-stage dim-64 U-Net, whose bottleneck is then 2x2 / 1x1: U-Net forwards, the reference's ``LatentDiffusion.sample``
+  (DDIM on 3x16x16 + ``VQModel.decode``), the text / cross-attention loop on 3x8x8, and ``VQModel`` with
+  ``ch_mult (1,2,4,8)``, ``z_channels 3``, ``n_embed 8192`` (``decode`` and ``encode_to_prequant``);
+* objectives ``pred_x0`` / ``pred_v`` (DD/denoising_diffusion.py:614-624) through both loops;
+* self-conditioning (``Unet(self_condition=True)``, :352-354, :657, :683) through both loops.
+
+Imports and noise redirection follow make_golden.py / make_golden_configs.py.  Only DATA is written.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import tempfile
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+from make_golden import import_reference, patched_noise, save, seeded  # noqa: E402
+from make_golden_configs import import_ldm  # noqa: E402
+
+import diffusion_models_amd as dm  # noqa: E402
+from diffusion_models_amd.spec import DecoderConfig, EncoderConfig, UnetConfig, encoder_param_spec  # noqa: E402
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    dd, ddt, _ = import_reference()
+    ae, ld = import_ldm()
+    out = {}
+    tt = torch.tensor([17, 903], dtype=torch.long)
+
+    # ---- ldm_cifar.yaml: 4-stage U-Net on 3x16x16 latents (bottleneck 2x2), VQModel ch_mult (1,2) at 32 ------------
+    full_sd = dm.synth_state_dict(dm.unet_param_spec(UnetConfig()), salt=0)
+    ref_full = dd.Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=3).eval()
+    ref_full.load_state_dict(full_sd, strict=True)
+    with torch.inference_mode():
+        for side, seed in ((16, 71), (8, 72)):
+            x = seeded((2, 3, side, side), seed)
+            out[f"unet_full_{side}"] = dict(x=x, t=tt, y=ref_full(x, tt))
+    dd_cifar = dict(double_z=False, z_channels=3, resolution=32, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2],
+                    num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    vq = ae.VQModel(ddconfig=dd_cifar, lossconfig={"target": "torch.nn.Identity"}, n_embed=8192, embed_dim=3).eval()
+    ecfg = EncoderConfig(n_embed=8192)
+    vsd = dm.synth_state_dict(encoder_param_spec(ecfg) + dm.decoder_param_spec(DecoderConfig()), salt=21)
+    missing, unexpected = vq.load_state_dict(vsd, strict=False)
+    assert not unexpected and all(k.startswith("loss") for k in missing), (missing, unexpected)
+    ldm = ld.LatentDiffusion(ref_full, vq, latent_shape=(3, 16, 16), timesteps=1000, sampling_timesteps=5).eval()
+    with patched_noise(dd, 311):
+        out["ldm_cifar_ddim5"] = dict(seed=311, B=2, S=5, y=ldm.sample(batch_size=2))
+    ldm8 = dd.DenoisingDiffusion(ref_full, image_size=8, timesteps=1000, sampling_timesteps=5, auto_normalize=False).eval()
+    with patched_noise(dd, 312):
+        out["latent8_ddim5"] = dict(seed=312, shape=(2, 3, 8, 8), S=5, y=ldm8.ddim_sample((2, 3, 8, 8)))
+    d50 = dd.DenoisingDiffusion(ref_full, image_size=8, timesteps=50, auto_normalize=False).eval()
+    with patched_noise(dd, 313):
+        out["latent8_ddpm50"] = dict(seed=313, shape=(2, 3, 8, 8), T=50, y=d50.p_sample_loop((2, 3, 8, 8)))
+    del ref_full, ldm, ldm8, d50, vq
+
+    # ---- ldm_text_conditional_coco.yaml: text / cross-attention U-Net on 3x8x8 latents (bottleneck 1x1) --------------
+    tcfg = UnetConfig(text_condition=True, use_cross_attn=True)
+    text_sd = dm.synth_state_dict(dm.unet_param_spec(tcfg), salt=0)
+    ref_text = ddt.Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=3, text_condition=True, use_cross_attn=True).eval()
+    ref_text.load_state_dict(text_sd, strict=True)
+    emb2 = seeded((2, 512), 73)
+    with torch.inference_mode():
+        x8 = seeded((2, 3, 8, 8), 74)
+        out["unet_text_full_8"] = dict(x=x8, t=tt, ctx=emb2, y=ref_text(x8, tt, text_emb=emb2))
+    with tempfile.NamedTemporaryFile(suffix=".pkl") as f:
+        tdiff = ddt.TextConditionalDenoisingDiffusion(model=ref_text, embedding_file=f.name, image_size=8,
+                                                      timesteps=1000, sampling_timesteps=4, auto_normalize=False).eval()
+        tdiff.get_random_text_condition = lambda batch, device: (emb2[:batch], ["caption"] * batch)
+        with patched_noise(ddt, 314):
+            out["text8_ddim4"] = dict(seed=314, shape=(2, 3, 8, 8), S=4, ctx=emb2, y=tdiff.ddim_sample((2, 3, 8, 8)))
+    del ref_text, tdiff
+
+    # ---- the coco VAE: ch_mult (1,2,4,8), z 3, n_embed 8192, resolution 64 ---------------------------------------------
+    dd_coco = dict(double_z=False, z_channels=3, resolution=64, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2, 4, 8],
+                   num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    vq = ae.VQModel(ddconfig=dd_coco, lossconfig={"target": "torch.nn.Identity"}, n_embed=8192, embed_dim=3).eval()
+    ecfg = EncoderConfig(ch=64, ch_mult=(1, 2, 4, 8), num_res_blocks=2, resolution=64, z_channels=3, embed_dim=3,
+                         n_embed=8192)
+    dcfg = DecoderConfig(ch=64, ch_mult=(1, 2, 4, 8), num_res_blocks=2, resolution=64, z_channels=3, embed_dim=3)
+    vsd = dm.synth_state_dict(encoder_param_spec(ecfg) + dm.decoder_param_spec(dcfg), salt=22)
+    missing, unexpected = vq.load_state_dict(vsd, strict=False)
+    assert not unexpected and all(k.startswith("loss") for k in missing), (missing, unexpected)
+    with torch.inference_mode():
+        z = seeded((2, 3, 8, 8), 75)
+        img = seeded((2, 3, 64, 64), 76)
+        out["vq_coco"] = dict(z=z, dec=vq.decode(z), x=img, prequant=vq.encode_to_prequant(img))
+    del vq
+
+    # ---- objectives pred_x0 / pred_v and self-conditioning on a small U-Net ------------------------------------------
+    small = UnetConfig(dim=64, dim_mults=(1, 2), channels=3)
+    ssd = dm.synth_state_dict(dm.unet_param_spec(small), salt=31)
+    ref_small = dd.Unet(dim=64, dim_mults=(1, 2), channels=3).eval()
+    ref_small.load_state_dict(ssd, strict=True)
+    for obj, seed in (("pred_x0", 320), ("pred_v", 330)):
+        dT = dd.DenoisingDiffusion(ref_small, image_size=16, timesteps=50, objective=obj).eval()
+        with patched_noise(dd, seed):
+            out[f"{obj}_ddpm50"] = dict(seed=seed, shape=(2, 3, 16, 16), T=50, y=dT.p_sample_loop((2, 3, 16, 16)))
+        dS = dd.DenoisingDiffusion(ref_small, image_size=16, timesteps=1000, sampling_timesteps=4, objective=obj,
+                                   ddim_sampling_eta=0.5).eval()
+        with patched_noise(dd, seed + 1):
+            out[f"{obj}_ddim4"] = dict(seed=seed + 1, shape=(2, 3, 16, 16), S=4, eta=0.5, y=dS.ddim_sample((2, 3, 16, 16)))
+    sc_cfg = UnetConfig(dim=64, dim_mults=(1, 2), channels=3, self_condition=True)
+    scsd = dm.synth_state_dict(dm.unet_param_spec(sc_cfg), salt=32)
+    ref_sc = dd.Unet(dim=64, dim_mults=(1, 2), channels=3, self_condition=True).eval()
+    ref_sc.load_state_dict(scsd, strict=True)
+    with torch.inference_mode():
+        x = seeded((2, 3, 16, 16), 77)
+        xs = seeded((2, 3, 16, 16), 78)
+        out["unet_selfcond"] = dict(x=x, t=tt, x_self_cond=xs, y=ref_sc(x, tt, xs), y_none=ref_sc(x, tt))
+    dT = dd.DenoisingDiffusion(ref_sc, image_size=16, timesteps=50).eval()
+    with patched_noise(dd, 340):
+        out["selfcond_ddpm50"] = dict(seed=340, shape=(2, 3, 16, 16), T=50, y=dT.p_sample_loop((2, 3, 16, 16)))
+    dS = dd.DenoisingDiffusion(ref_sc, image_size=16, timesteps=1000, sampling_timesteps=4).eval()
+    with patched_noise(dd, 341):
+        out["selfcond_ddim4"] = dict(seed=341, shape=(2, 3, 16, 16), S=4, y=dS.ddim_sample((2, 3, 16, 16)))
+    save("r3.pt", out)
+
+
+if __name__ == "__main__":
+    main()

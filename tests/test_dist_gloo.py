@@ -7,7 +7,8 @@ diffusion_models_amd.dist.
   sampler on both sides (the GPU equivalent, Philox keyed by global element index, is
   tests/test_hip_configs.py::test_sharded_seeded_sampling_equals_unsharded_bitwise).
 * ``test_world2_sample_global``: ``dist.sample_global`` hands every rank the same seed (broadcast from rank 0) and its
-  own ``sample_offset``; even and ragged splits.
+  own ``sample_offset``; even and ragged splits, a batch smaller than the world (one rank's slice is EMPTY: it must
+  still enter the collective), and a per-sample condition tensor (sliced to each rank's rows).
 """
 import os
 import socket
@@ -94,19 +95,27 @@ def test_world2_oracle_sampler_sharded_equals_unsharded(tmp_path):
 
 
 class _FakeDiffusion:
-    """Stands in for DenoisingDiffusion on CPU: a 'sample' is a function of (seed, global sample index) only."""
+    """Stands in for DenoisingDiffusion on CPU: a 'sample' is a function of (seed, global sample index[, its condition
+    row]) only.  Like the real classes it refuses an empty batch (dm_sample: "empty run")."""
+
+    image_size = SHAPE[1:]
+    channels = SHAPE[0]
+    device = "cpu"
 
     def __init__(self):
         self.calls = []
 
-    def sample(self, batch_size, seed, sample_offset):
+    def sample(self, batch_size, seed, sample_offset, cond=None):
+        assert batch_size > 0, "empty run"
+        assert cond is None or cond.shape[0] == batch_size, "condition rows != batch"
         self.calls.append((batch_size, seed, sample_offset))
         rows = [torch.randn(SHAPE, generator=torch.Generator().manual_seed(seed % (2 ** 31) + i))
                 for i in range(sample_offset, sample_offset + batch_size)]
-        return torch.stack(rows) if rows else torch.zeros((0,) + SHAPE)
+        out = torch.stack(rows)
+        return out if cond is None else out + cond.reshape(batch_size, 1, 1, 1)
 
 
-def _worker_global(rank, world, port, batch, out_dir):
+def _worker_global(rank, world, port, batch, out_dir, with_cond):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -118,19 +127,41 @@ def _worker_global(rank, world, port, batch, out_dir):
     try:
         torch.manual_seed(100 + rank)  # ranks disagree about the default seed: rank 0's must win
         d = _FakeDiffusion()
-        full = sample_global(d, batch)
+        kw = {"cond": torch.arange(batch, dtype=torch.float32) * 10.0} if with_cond else {}
+        full = sample_global(d, batch, **kw)
         torch.save({"full": full, "calls": d.calls}, os.path.join(out_dir, f"g{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
 def test_world2_sample_global(tmp_path):
-    for batch in (6, 5):
+    for batch, with_cond in ((6, False), (5, False), (1, False), (5, True), (1, True)):
         port = _free_port()
-        mp.spawn(_worker_global, args=(2, port, batch, str(tmp_path)), nprocs=2, join=True)
+        mp.spawn(_worker_global, args=(2, port, batch, str(tmp_path), with_cond), nprocs=2, join=True)
         r0 = torch.load(os.path.join(tmp_path, "g0.pt"), weights_only=True)
         r1 = torch.load(os.path.join(tmp_path, "g1.pt"), weights_only=True)
-        (b0, seed0, off0), (b1, seed1, off1) = r0["calls"][0], r1["calls"][0]
-        assert seed0 == seed1 and off0 == 0 and off1 == b0 and b0 + b1 == batch
-        want = _FakeDiffusion().sample(batch, seed0, 0)
+        (b0, seed0, off0) = r0["calls"][0]
+        if batch == 1:
+            assert r1["calls"] == [], "the rank with an empty slice must not call the library"
+            b1 = 0
+        else:
+            (b1, seed1, off1) = r1["calls"][0]
+            assert seed0 == seed1 and off1 == b0
+        assert off0 == 0 and b0 + b1 == batch
+        cond = torch.arange(batch, dtype=torch.float32) * 10.0 if with_cond else None
+        want = _FakeDiffusion().sample(batch, seed0, 0, cond)
+        assert r0["full"].shape == want.shape
         assert torch.equal(r0["full"], want) and torch.equal(r1["full"], want)
+
+
+def test_sample_global_refuses_text_model_without_embeddings():
+    import pytest
+
+    from diffusion_models_amd.dist import sample_global
+
+    class _Text(_FakeDiffusion):
+        class model:
+            text_condition = True
+
+    with pytest.raises(ValueError, match="text_emb"):
+        sample_global(_Text(), 4)

@@ -21,3 +21,29 @@ def test_small_shapes_through_the_large_shape_kernels():
                         "-m", "gpu", "-k", "conv2d or block or attention", "-p", "no:cacheprovider"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
+MODEL_CASES = "test_unet_full_forward or test_unet_latent_and_text_full or test_full_samplers or test_unet_text_variants"
+
+
+def _run_models(env_extra):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_model.py"),
+                        os.path.join(ROOT, "tests", "test_hip_r3.py"), "-q", "-x", "-m", "gpu", "-k",
+                        MODEL_CASES + " or test_ldm_coco_text_shapes or test_ldm_cifar_shapes", "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
+def test_model_goldens_with_the_alternative_kernels():
+    """The model-level goldens of the reference (full 32x32 U-Net, latent / text variants, DDPM + DDIM loops, the LDM YAML
+    shapes) with every dispatch alternative forced: no F(4x4) Winograd and no 1x1 GEMM kernel (the F(2x2) / direct
+    kernels take their layers), the general CrossAttention path instead of the one-token algebra, separate res_conv
+    landings, no fused attention kernels, the folded instead of the 9-multiply upsample conv."""
+    _run_models(dict(DM_NO_WINO4="1", DM_NO_PW="1", DM_NO_CROSS1="1", DM_NO_RES_MERGE="1", DM_NO_UPWINO="1",
+                     DM_NO_FUSED_LINATTN="1", DM_NO_ATTN16="1", DM_NO_INIT7="1"))
+
+
+def test_model_goldens_without_any_winograd():
+    """... and with every Winograd-family kernel off (the direct implicit-GEMM kernel takes all 3x3 layers)."""
+    _run_models(dict(DM_NO_WINOGRAD="1"))

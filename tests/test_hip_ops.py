@@ -227,26 +227,31 @@ def test_attention(shape):
 
 def test_sampler_update_bit_exact():
     """The update is elementwise fp32 with contraction off: it must equal the reference's
-    expression tree bit for bit (clamp included)."""
+    expression tree bit for bit (clamp included), for every objective (pred_noise / pred_x0 / pred_v,
+    DD/denoising_diffusion.py:607-624), and hand back the clamped x_start."""
     n = 3 * 32 * 32 * 2 + 3  # not a multiple of 4
     x, eps, z = seeded((n,), 1), seeded((n,), 2, 3.0), seeded((n,), 3)
     lib = _lib.load()
-    for kind, c in ((0, [1.7, 1.3, 0.4, 0.6, 0.2, 1.0, 0, 0]), (0, [1.0, 0.01, 1.0, 0.0, 1e-10, 0.0, 0, 0]),
-                    (1, [3.5, 3.4, 0.9, 0.43, 0.1, 1.0, 0, 0]), (1, [1.2, 0.6, 0, 0, 0, 0.0, 0, 0])):
-        ct = torch.tensor(c, dtype=torch.float32)
-        x0 = (ct[0] * x - ct[1] * eps).clamp(-1.0, 1.0)
-        if kind == 0:
-            mean = ct[2] * x0 + ct[3] * x
-            ref = mean + ct[4] * z if c[5] else mean + ct[4] * 0.0
-        else:
-            e2 = (ct[0] * x - x0) / ct[1]
-            ref = (x0 * ct[2] + ct[3] * e2) + ct[4] * z if c[5] else x0
-        out = torch.empty(n, device=DEV)
-        a = [dev(x), dev(eps), dev(z)]
-        carr = (C.c_float * 8)(*c)
-        _lib.check(lib.dm_op_sampler_update(kind, _lib.ptr(a[0]), _lib.ptr(a[1]), _lib.ptr(a[2]), carr, _lib.ptr(out),
-                                            n, None))
-        assert torch.equal(out.cpu(), ref), (kind, c)
+    for obj in (0, 1, 2):
+        for kind, c in ((0, [1.7, 1.3, 0.4, 0.6, 0.2, 1.0, 0.59, 0.81]), (0, [1.0, 0.01, 1.0, 0.0, 1e-10, 0.0, 0.99, 0.1]),
+                        (1, [3.5, 3.4, 0.9, 0.43, 0.1, 1.0, 0.28, 0.96]), (1, [1.2, 0.6, 0, 0, 0, 0.0, 0.83, 0.55])):
+            ct = torch.tensor(c, dtype=torch.float32)
+            raw = (ct[0] * x - ct[1] * eps, eps, ct[6] * x - ct[7] * eps)[obj]
+            x0 = raw.clamp(-1.0, 1.0)
+            if kind == 0:
+                mean = ct[2] * x0 + ct[3] * x
+                ref = mean + ct[4] * z if c[5] else mean + ct[4] * 0.0
+            else:
+                e2 = (ct[0] * x - x0) / ct[1]
+                ref = (x0 * ct[2] + ct[3] * e2) + ct[4] * z if c[5] else x0
+            out = torch.empty(n, device=DEV)
+            xs = torch.empty(n, device=DEV)
+            a = [dev(x), dev(eps), dev(z)]
+            carr = (C.c_float * 8)(*c)
+            _lib.check(lib.dm_op_sampler_update(kind, obj, _lib.ptr(a[0]), _lib.ptr(a[1]), _lib.ptr(a[2]), carr,
+                                                _lib.ptr(out), _lib.ptr(xs), n, None))
+            assert torch.equal(out.cpu(), ref), (obj, kind, c)
+            assert torch.equal(xs.cpu(), x0), (obj, kind, c)
 
 
 def test_philox_noise_statistics_and_determinism():

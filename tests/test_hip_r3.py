@@ -1,0 +1,162 @@
+"""GPU parity against the round-3 fixtures generated from the reference (tests/golden/make_golden_r3.py):
+
+* the shapes the reference's own LDM YAMLs produce -- 3x16x16 latents (ldm_cifar.yaml) and 3x8x8 latents
+  (ldm_text_conditional_coco.yaml) through the 4-stage dim-64 U-Net, whose bottleneck is 2x2 / 1x1 (a 3x3 convolution
+  on a 1x1 map, LinearAttention over 4 tokens, full Attention over 1 token + 4 memory keys), and the ch_mult (1,2,4,8)
+  VQModel (decode 3x8x8 -> 3x64x64, encode_to_prequant 3x64x64 -> 3x8x8);
+* objectives pred_x0 / pred_v and self-conditioning through both loops, eager and hipGraph replay.
+
+Everything goes through the C ABI.  Tolerances (rel-L2, fp32): forward <= 1e-4, loops <= 1e-3."""
+import pytest
+import torch
+
+import diffusion_models_amd as dm
+from diffusion_models_amd.spec import DecoderConfig, EncoderConfig, UnetConfig, encoder_param_spec
+from oracle import sampler_oracle as so
+from oracle import unet_oracle as uo
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FWD_TOL = 1e-4
+LOOP_TOL = 1e-3
+
+
+def _unet(cfg: UnetConfig, salt):
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=salt)
+    u = dm.Unet(dim=cfg.dim, dim_mults=cfg.dim_mults, channels=cfg.channels, self_condition=cfg.self_condition,
+                text_condition=cfg.text_condition, use_cross_attn=cfg.use_cross_attn, device=DEV)
+    u.load_state_dict(sd)
+    return u, sd
+
+
+@pytest.fixture(scope="module")
+def full():
+    return _unet(UnetConfig(), 0)
+
+
+def test_ldm_cifar_shapes(golden_r3, full):
+    """ldm_cifar.yaml: latents 3x16x16 and 3x8x8 through the 4-stage U-Net; LatentDiffusion.sample vs the reference's."""
+    u, _ = full
+    for side in (16, 8):
+        b = golden_r3[f"unet_full_{side}"]
+        err = rel_l2(u(b["x"], b["t"]).cpu(), b["y"])
+        print(f"unet_full_{side}", err)
+        assert err < FWD_TOL
+    vae = dm.VQModel(dict(ch=64, out_ch=3, in_channels=3, ch_mult=(1, 2), num_res_blocks=2, attn_resolutions=(),
+                          resolution=32, z_channels=3, double_z=False), n_embed=8192, embed_dim=3, device=DEV)
+    vae.load_state_dict(dm.synth_state_dict(encoder_param_spec(EncoderConfig(n_embed=8192)) +
+                                            dm.decoder_param_spec(DecoderConfig()), salt=21))
+    ld = dm.LatentDiffusion(u, vae, latent_shape=(3, 16, 16), timesteps=1000, sampling_timesteps=5)
+    b = golden_r3["ldm_cifar_ddim5"]
+    img = ld.sample(batch_size=b["B"], noise=so.NoiseStream(b["seed"])).cpu()
+    assert img.shape == (2, 3, 32, 32) and ld.sample_shape() == (3, 32, 32)
+    err = rel_l2(img, b["y"])
+    print("ldm_cifar_ddim5 (reference LatentDiffusion.sample)", err)
+    assert err < LOOP_TOL
+    d8 = dm.DenoisingDiffusion(u, image_size=8, timesteps=1000, sampling_timesteps=5, auto_normalize=False)
+    b = golden_r3["latent8_ddim5"]
+    err = rel_l2(d8.ddim_sample(b["shape"], noise=so.NoiseStream(b["seed"])).cpu(), b["y"])
+    print("latent8_ddim5", err)
+    assert err < LOOP_TOL
+    d50 = dm.DenoisingDiffusion(u, image_size=8, timesteps=50, auto_normalize=False)
+    b = golden_r3["latent8_ddpm50"]
+    err = rel_l2(d50.p_sample_loop(b["shape"], noise=so.NoiseStream(b["seed"])).cpu(), b["y"])
+    print("latent8_ddpm50", err)
+    assert err < LOOP_TOL
+
+
+def test_ldm_cifar_shapes_at_training_batch(full):
+    """The same latent shapes at the batch the YAMLs train / sample with (64 and 16): other tile / split-K plans."""
+    u, sd = full
+    cfg = UnetConfig()
+    for B, side in ((64, 16), (16, 8)):
+        x = torch.randn((B, 3, side, side), generator=torch.Generator().manual_seed(B))
+        t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(side))
+        with torch.inference_mode():
+            want = uo.unet_forward(sd, cfg, x, t)
+        err = rel_l2(u(x, t).cpu(), want)
+        print(f"B={B} {side}x{side} forward vs oracle", err)
+        assert err < FWD_TOL
+
+
+def test_ldm_coco_text_shapes(golden_r3):
+    """ldm_text_conditional_coco.yaml: the text / cross-attention U-Net on 3x8x8 latents (bottleneck 1x1)."""
+    u, _ = _unet(UnetConfig(text_condition=True, use_cross_attn=True), 0)
+    b = golden_r3["unet_text_full_8"]
+    err = rel_l2(u(b["x"], b["t"], text_emb=b["ctx"]).cpu(), b["y"])
+    print("unet_text_full_8", err)
+    assert err < FWD_TOL
+    d = dm.TextConditionalDenoisingDiffusion(model=u, image_size=8, timesteps=1000, sampling_timesteps=4,
+                                             auto_normalize=False)
+    b = golden_r3["text8_ddim4"]
+    err = rel_l2(d.ddim_sample(b["shape"], text_emb=b["ctx"], noise=so.NoiseStream(b["seed"])).cpu(), b["y"])
+    print("text8_ddim4", err)
+    assert err < LOOP_TOL
+
+
+def test_vq_coco(golden_r3):
+    """VQModel with ch_mult (1,2,4,8), z_channels 3, n_embed 8192 at resolution 64 (the coco / edges2shoes VAEs)."""
+    ecfg = EncoderConfig(ch=64, ch_mult=(1, 2, 4, 8), num_res_blocks=2, resolution=64, z_channels=3, embed_dim=3,
+                         n_embed=8192)
+    dcfg = DecoderConfig(ch=64, ch_mult=(1, 2, 4, 8), num_res_blocks=2, resolution=64, z_channels=3, embed_dim=3)
+    vae = dm.VQModel(dict(ch=64, out_ch=3, in_channels=3, ch_mult=(1, 2, 4, 8), num_res_blocks=2, attn_resolutions=(),
+                          resolution=64, z_channels=3, double_z=False), n_embed=8192, embed_dim=3, device=DEV)
+    vae.load_state_dict(dm.synth_state_dict(encoder_param_spec(ecfg) + dm.decoder_param_spec(dcfg), salt=22))
+    b = golden_r3["vq_coco"]
+    dec = vae.decode(b["z"]).cpu()
+    assert dec.shape == (2, 3, 64, 64)
+    err = rel_l2(dec, b["dec"])
+    print("vq_coco decode", err)
+    assert err < FWD_TOL
+    err = rel_l2(vae.encode_to_prequant(b["x"]).cpu(), b["prequant"])
+    print("vq_coco encode_to_prequant", err)
+    assert err < FWD_TOL
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_objectives(golden_r3, use_graph):
+    """pred_x0 / pred_v (DD/denoising_diffusion.py:614-624) through p_sample_loop and ddim_sample."""
+    u, _ = _unet(UnetConfig(dim=64, dim_mults=(1, 2), channels=3), 31)
+    for obj in ("pred_x0", "pred_v"):
+        b = golden_r3[f"{obj}_ddpm50"]
+        d = dm.DenoisingDiffusion(u, image_size=16, timesteps=b["T"], objective=obj, use_graph=use_graph)
+        err = rel_l2(d.p_sample_loop(b["shape"], noise=so.NoiseStream(b["seed"])).cpu(), b["y"])
+        print(obj, "ddpm50", err)
+        assert err < LOOP_TOL
+        b = golden_r3[f"{obj}_ddim4"]
+        d = dm.DenoisingDiffusion(u, image_size=16, timesteps=1000, sampling_timesteps=b["S"], objective=obj,
+                                  ddim_sampling_eta=b["eta"], use_graph=use_graph)
+        err = rel_l2(d.ddim_sample(b["shape"], noise=so.NoiseStream(b["seed"])).cpu(), b["y"])
+        print(obj, "ddim4", err)
+        assert err < LOOP_TOL
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_self_conditioning(golden_r3, use_graph):
+    """Unet(self_condition=True): the U-Net sees [x_start of the previous step | x] (:352-354, :657, :683)."""
+    u, sd = _unet(UnetConfig(dim=64, dim_mults=(1, 2), channels=3, self_condition=True), 32)
+    b = golden_r3["unet_selfcond"]
+    assert rel_l2(u(b["x"], b["t"], b["x_self_cond"]).cpu(), b["y"]) < FWD_TOL
+    assert rel_l2(u(b["x"], b["t"]).cpu(), b["y_none"]) < FWD_TOL
+    b = golden_r3["selfcond_ddpm50"]
+    d = dm.DenoisingDiffusion(u, image_size=16, timesteps=b["T"], use_graph=use_graph)
+    err = rel_l2(d.p_sample_loop(b["shape"], noise=so.NoiseStream(b["seed"])).cpu(), b["y"])
+    print("selfcond_ddpm50", err)
+    assert err < LOOP_TOL
+    b = golden_r3["selfcond_ddim4"]
+    d = dm.DenoisingDiffusion(u, image_size=16, timesteps=1000, sampling_timesteps=b["S"], use_graph=use_graph)
+    err = rel_l2(d.ddim_sample(b["shape"], noise=so.NoiseStream(b["seed"])).cpu(), b["y"])
+    print("selfcond_ddim4", err)
+    assert err < LOOP_TOL
+    # p_sample with an explicit x_self_cond against the oracle's step
+    x = torch.randn((2, 3, 16, 16), generator=torch.Generator().manual_seed(5))
+    sc = torch.randn((2, 3, 16, 16), generator=torch.Generator().manual_seed(6)).clamp(-1, 1)
+    z = torch.randn((2, 3, 16, 16), generator=torch.Generator().manual_seed(7))
+    cfg = UnetConfig(dim=64, dim_mults=(1, 2), channels=3, self_condition=True)
+    with torch.inference_mode():
+        want, want_x0 = so.p_sample(lambda xx, tt, s: uo.unet_forward(sd, cfg, xx, tt, s), dm.make_schedule(1000, "linear"),
+                                    x, 400, z, x_self_cond=sc)
+    got, got_x0 = d.p_sample(x, 400, sc, noise=lambda shape: z)
+    assert rel_l2(got.cpu(), want) < FWD_TOL and rel_l2(got_x0.cpu(), want_x0) < FWD_TOL

@@ -139,5 +139,11 @@ def test_evaluators_end_to_end(tmp_path):
     want_is = io.inception_score(torch.softmax(io.is_logits(sd, fake * 2 - 1), dim=1))
     print("IS", got_is, want_is)
     assert abs(got_is - want_is) <= 1e-3 * want_is
+    with pytest.raises(RuntimeError, match="state_dict"):
+        dm.InceptionV3([0], device=DEV)  # no weights given: refused, as the reference's constructors would fail
     with pytest.warns(UserWarning):
-        dm.InceptionV3([0], device=DEV)  # no weights given: synthetic, loudly
+        dm.InceptionV3([0], device=DEV, allow_synthetic=True)  # explicit opt-in: synthetic, loudly
+    syn = dm.FIDEvaluation(4, iter(real), Sampler(), stats_dir=str(tmp_path / "syn"), device=DEV, num_fid_samples=12,
+                           allow_synthetic=True)
+    syn.fid_score(fake)
+    assert not (tmp_path / "syn" / "dataset_stats.npz").exists()  # statistics of random weights are never cached

@@ -292,3 +292,75 @@ def test_config5_text_64x64(golden_configs):
     model = lambda x, t: uo.unet_forward(sd, cfg, x, t, text_emb=b["ctx"])  # noqa: E731
     y = so.ddim_sample(model, dm.make_schedule(1000, "linear"), b["shape"], so.NoiseStream(b["seed"]), b["S"])
     assert rel_l2(y, b["y"]) < 1e-4
+
+
+# ---- round 3: the reference's own LDM shapes, the other objectives, self-conditioning (tests/golden/r3.pt) ----------
+COCO_ENC = EncoderConfig(ch=64, ch_mult=(1, 2, 4, 8), num_res_blocks=2, resolution=64, z_channels=3, embed_dim=3,
+                         n_embed=8192)
+COCO_DEC = DecoderConfig(ch=64, ch_mult=(1, 2, 4, 8), num_res_blocks=2, resolution=64, z_channels=3, embed_dim=3)
+
+
+def test_r3_ldm_yaml_shapes(golden_r3):
+    """ldm_cifar.yaml (3x16x16 latents) and ldm_text_conditional_coco.yaml (3x8x8 latents): the 4-stage U-Net with a
+    2x2 / 1x1 bottleneck, the reference's LatentDiffusion.sample, and the ch_mult (1,2,4,8) VQModel."""
+    cfg = UnetConfig()
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=0)
+    model = lambda x, t: uo.unet_forward(sd, cfg, x, t)  # noqa: E731
+    for side in (16, 8):
+        b = golden_r3[f"unet_full_{side}"]
+        assert rel_l2(model(b["x"], b["t"]), b["y"]) < TOL
+    sched = dm.make_schedule(1000, "linear")
+    vsd = dm.synth_state_dict(encoder_param_spec(EncoderConfig(n_embed=8192)) + dm.decoder_param_spec(DecoderConfig()),
+                              salt=21)
+    b = golden_r3["ldm_cifar_ddim5"]
+    lat = so.ddim_sample(model, sched, (b["B"], 3, 16, 16), so.NoiseStream(b["seed"]), b["S"], unnormalize=False)
+    assert rel_l2(vo.vq_decode(vsd, DecoderConfig(), lat), b["y"]) < 1e-4
+    b = golden_r3["latent8_ddim5"]
+    assert rel_l2(so.ddim_sample(model, sched, b["shape"], so.NoiseStream(b["seed"]), b["S"], unnormalize=False),
+                  b["y"]) < 1e-4
+    b = golden_r3["latent8_ddpm50"]
+    assert rel_l2(so.p_sample_loop(model, dm.make_schedule(b["T"], "linear"), b["shape"], so.NoiseStream(b["seed"]),
+                                   unnormalize=False), b["y"]) < 1e-4
+    tcfg = UnetConfig(text_condition=True, use_cross_attn=True)
+    tsd = dm.synth_state_dict(dm.unet_param_spec(tcfg), salt=0)
+    b = golden_r3["unet_text_full_8"]
+    assert rel_l2(uo.unet_forward(tsd, tcfg, b["x"], b["t"], text_emb=b["ctx"]), b["y"]) < TOL
+    b = golden_r3["text8_ddim4"]
+    tmodel = lambda x, t: uo.unet_forward(tsd, tcfg, x, t, text_emb=b["ctx"])  # noqa: E731
+    assert rel_l2(so.ddim_sample(tmodel, sched, b["shape"], so.NoiseStream(b["seed"]), b["S"], unnormalize=False),
+                  b["y"]) < 1e-4
+    vsd = dm.synth_state_dict(encoder_param_spec(COCO_ENC) + dm.decoder_param_spec(COCO_DEC), salt=22)
+    b = golden_r3["vq_coco"]
+    assert rel_l2(vo.vq_decode(vsd, COCO_DEC, b["z"]), b["dec"]) < TOL
+    assert rel_l2(vo.vq_encode_to_prequant(vsd, COCO_ENC, b["x"]), b["prequant"]) < TOL
+
+
+def test_r3_objectives_and_self_conditioning(golden_r3):
+    """pred_x0 / pred_v (DD/denoising_diffusion.py:614-624) and self-conditioning (:352-354, :657, :683) through both
+    loops, against the reference's own runs."""
+    cfg = UnetConfig(dim=64, dim_mults=(1, 2), channels=3)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=31)
+    model = lambda x, t: uo.unet_forward(sd, cfg, x, t)  # noqa: E731
+    for obj in ("pred_x0", "pred_v"):
+        b = golden_r3[f"{obj}_ddpm50"]
+        y = so.p_sample_loop(model, dm.make_schedule(b["T"], "linear"), b["shape"], so.NoiseStream(b["seed"]),
+                             objective=obj)
+        assert rel_l2(y, b["y"]) < 1e-4, obj
+        b = golden_r3[f"{obj}_ddim4"]
+        y = so.ddim_sample(model, dm.make_schedule(1000, "linear"), b["shape"], so.NoiseStream(b["seed"]), b["S"],
+                           eta=b["eta"], objective=obj)
+        assert rel_l2(y, b["y"]) < 1e-4, obj
+    scfg = UnetConfig(dim=64, dim_mults=(1, 2), channels=3, self_condition=True)
+    ssd = dm.synth_state_dict(dm.unet_param_spec(scfg), salt=32)
+    b = golden_r3["unet_selfcond"]
+    assert rel_l2(uo.unet_forward(ssd, scfg, b["x"], b["t"], b["x_self_cond"]), b["y"]) < TOL
+    assert rel_l2(uo.unet_forward(ssd, scfg, b["x"], b["t"]), b["y_none"]) < TOL
+    smodel = lambda x, t, sc: uo.unet_forward(ssd, scfg, x, t, sc)  # noqa: E731
+    b = golden_r3["selfcond_ddpm50"]
+    y = so.p_sample_loop(smodel, dm.make_schedule(b["T"], "linear"), b["shape"], so.NoiseStream(b["seed"]),
+                         self_condition=True)
+    assert rel_l2(y, b["y"]) < 1e-4
+    b = golden_r3["selfcond_ddim4"]
+    y = so.ddim_sample(smodel, dm.make_schedule(1000, "linear"), b["shape"], so.NoiseStream(b["seed"]), b["S"],
+                       self_condition=True)
+    assert rel_l2(y, b["y"]) < 1e-4
