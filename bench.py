@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=20, help="DDPM steps of the CPU baseline sample (config 1)")
     return ap.parse_args()
 
@@ -99,6 +100,130 @@ def pmc_traffic(kernel: str):
     if not row:
         return None, f"{os.path.basename(newest)} has no row for {kernel}"
     return row["fetch_bytes_per_launch_corrected"] + row["write_bytes_per_launch"], os.path.basename(newest)
+
+
+def pmc_file():
+    """(doc, name) of the newest committed PMC pass when it was collected on THESE kernel sources, else (None, why)."""
+    import re
+
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json"))
+    if not files:
+        return None, "no profiles/r*_pmc_hbm_traffic.json"
+    newest = max(files, key=lambda p: tuple(int(v) for v in re.findall(r"\d+", os.path.basename(p))))
+    with open(newest) as f:
+        doc = json.load(f)
+    if doc.get("_csrc_sha") != csrc_sha():
+        return None, f"{os.path.basename(newest)} was collected on other kernel sources"
+    return doc, os.path.basename(newest)
+
+
+FAMILIES = (("wino4", "wino4_mfma_kernel"), ("wino", "wino_mfma_kernel"), ("upwino", "upwino_mfma_kernel"),
+            ("pw", "pw_mfma_kernel"), ("linattn", "linattn_"), ("attn16", "attn16_fused_kernel"),
+            ("landing", "norm_act"), ("init7", "init7_mfma_kernel"), ("direct", "conv_mfma_kernel"))
+
+
+def family_of(kernel: str) -> str:
+    for fam, prefix in FAMILIES:
+        if kernel.startswith(prefix):
+            return fam
+    return "other"
+
+
+def step_breakdown(ms_per_denoise_step: float, pmc_steps: int = 50):
+    """Whole-step and per-family MFMA utilisation by EXECUTED FLOPs: SQ_INSTS_VALU_MFMA_MOPS_F32 (x512 FLOPs) per launch
+    x launches per denoise step, from the committed PMC pass of `bench.py --workload ddim50 --steps 1` (50 steps of the
+    same denoise step), over this run's measured step time; a family's share of the step is its kernel time in the
+    committed rocprofv3 --kernel-trace --stats summary of the headline command over that summary's total."""
+    import csv
+    import re
+
+    doc, src = pmc_file()
+    if doc is None:
+        return None, src
+    flops = {}
+    for k, row in doc.items():
+        if not isinstance(row, dict) or "mfma_mops_f32_per_launch" not in row:
+            continue
+        name = k.replace("dm::", "")
+        fam = family_of(name)
+        flops[fam] = flops.get(fam, 0.0) + row["mfma_mops_f32_per_launch"] * 512.0 * row["launches"] / pmc_steps
+    total = sum(flops.values())
+    out = {"step_executed_tflops": total / (ms_per_denoise_step * 1e-3) / 1e12,
+           "step_executed_frac": total / (ms_per_denoise_step * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+           "source": src}
+    stats = glob.glob(os.path.join(ROOT, "profiles", src.replace("_pmc_hbm_traffic.json", "_kernel_stats.csv")))
+    fam_ns, all_ns = {}, 0.0
+    if stats:
+        for r in csv.DictReader(open(stats[0])):
+            name = re.sub(r"^void\s+", "", r["Name"]).replace("dm::", "")
+            ns = float(r["TotalDurationNs"])
+            all_ns += ns
+            fam_ns[family_of(name)] = fam_ns.get(family_of(name), 0.0) + ns
+    fams = {}
+    for fam in sorted(set(flops) | set(fam_ns), key=lambda f: -fam_ns.get(f, 0.0)):
+        share = fam_ns.get(fam, 0.0) / all_ns if all_ns else None
+        row = {"share_of_step": share}
+        if share and flops.get(fam):
+            row["executed_tflops"] = flops[fam] / (share * ms_per_denoise_step * 1e-3) / 1e12
+            row["executed_frac"] = row["executed_tflops"] / PEAK_F32_TFLOPS
+        fams[fam] = row
+    out["families"] = fams
+    return out, src
+
+
+def other_configs(dev, replays: int = 100):
+    """BASELINE configs 3, 4 and 5 on this GPU, timed in this process after the headline region: graph-replayed sampler,
+    synthetic weights, `replays` denoise steps per timing (the per-step cost does not depend on the schedule length)."""
+    import torch
+
+    import diffusion_models_amd as dm
+    from diffusion_models_amd.spec import DecoderConfig
+
+    def unet(**kw):
+        u = dm.Unet(device=dev, **kw)
+        u.load_state_dict(dm.synth_state_dict(u.param_spec(), salt=0))
+        return u
+
+    def timed(fn):
+        fn()  # capture + warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    S = replays
+    out = {}
+    u = unet(dim=64, dim_mults=(1, 2, 4, 8), channels=3)
+    d = dm.DenoisingDiffusion(u, image_size=64, timesteps=1000, sampling_timesteps=S)
+    for B in (32, 8):
+        dt = timed(lambda: d.sample(batch_size=B, seed=1))
+        out[f"config3_64x64_ddpm1000_b{B}_per_gpu"] = {"ms_per_denoise_step": 1e3 * dt / S, "replays": S,
+                                                      "images_per_s_per_gpu": B / (1000 * dt / S)}
+    del d, u
+    u4 = unet(dim=64, dim_mults=(1, 2, 4, 8), channels=4)
+    dcfg = DecoderConfig(ch=64, ch_mult=(1, 2), num_res_blocks=2, attn_resolutions=(), resolution=64, z_channels=4,
+                         embed_dim=4)
+    vae = dm.VQDecoder(dict(ch=64, out_ch=3, ch_mult=(1, 2), num_res_blocks=2, attn_resolutions=(), resolution=64,
+                            z_channels=4), embed_dim=4, device=dev)
+    vae.load_state_dict(dm.synth_state_dict(dm.decoder_param_spec(dcfg), salt=4))
+    ld = dm.LatentDiffusion(u4, vae, latent_shape=(4, 32, 32), timesteps=1000, sampling_timesteps=S)
+    B = 128
+    dt_loop = timed(lambda: ld.ddim_sample((B, 4, 32, 32), seed=1))
+    z = ld.ddim_sample((B, 4, 32, 32), seed=1)
+    dt_dec = timed(lambda: vae.decode(z))
+    out["config4_latent4x32x32_ddim200_b128_with_decode"] = {
+        "ms_per_denoise_step": 1e3 * dt_loop / S, "decode_ms": 1e3 * dt_dec, "replays": S,
+        "images_per_s": B / (200 * dt_loop / S + dt_dec)}
+    del ld, u4, vae
+    ut = unet(dim=64, dim_mults=(1, 2, 4, 8), channels=3, text_condition=True, use_cross_attn=True)
+    d5 = dm.TextConditionalDenoisingDiffusion(model=ut, image_size=64, timesteps=1000, sampling_timesteps=S)
+    B = 32
+    emb = torch.randn(B, 512, device=dev)
+    dt = timed(lambda: d5.sample(batch_size=B, text_emb=emb, seed=1))
+    out["config5_text64x64_ddim100_b32_per_gpu"] = {"ms_per_denoise_step": 1e3 * dt / S, "replays": S,
+                                                    "images_per_s_per_gpu": B / (100 * dt / S)}
+    return out
 
 
 def cpu_baseline(n_steps):
@@ -309,8 +434,19 @@ def main():
         }
         result["kernels"] = kern
         result["conv_ms_per_unet_fwd"] = sum(r["total_ms"] for r in rows) / 4
-        # whole step: algorithmic FLOPs of one U-Net forward (3.651 GFLOP per image) over the graph time
-        result["step_direct_conv_equiv_tflops"] = 3.651e9 * B / (ms_denoise * 1e-3) / 1e12
+        # the unflattering view: the whole step and every kernel family by EXECUTED MFMA FLOPs (PMC) over measured time
+        brk, brk_src = step_breakdown(ms_denoise)
+        if brk is not None:
+            result["roofline"]["step_executed_frac"] = brk["step_executed_frac"]
+            result["roofline"]["step_executed_tflops"] = brk["step_executed_tflops"]
+            result["roofline"]["families"] = brk["families"]
+            result["roofline"]["families_source"] = brk["source"]
+        else:
+            result["roofline"]["step_executed_frac"] = None
+            result["roofline"]["families_source"] = brk_src
+
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        result["other_configs"] = other_configs(dev)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.cpu_steps)
