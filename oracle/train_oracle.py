@@ -1,0 +1,67 @@
+"""ORACLE -- test infrastructure, not product code.
+
+CPU restatement of the reference's training loss and of its gradients: ``q_sample`` and ``p_losses``
+(DD/denoising_diffusion.py:813-821, :823-889; hybrid_loss / offset noise / immiscible assignment off, as in every
+shipped config) over ``oracle.unet_oracle.unet_forward``, differentiated by torch autograd on the CPU.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module.
+
+Pinned by ``tests/golden/train.pt``: loss and parameter-gradient digests of the reference's own
+``p_losses(...).backward()`` (tests/golden/make_golden_train.py); ``tests/test_oracle_golden.py`` holds this module to
+them.
+
+DD = denoising-diffusion-pytorch/denoising_diffusion/ in the reference checkout.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Tuple
+
+import torch
+
+from . import unet_oracle as uo
+
+N_PROJ = 8
+
+
+def directions(name: str, numel: int) -> torch.Tensor:
+    """The fixed random directions the golden digests project a gradient on (make_golden_train.py)."""
+    g = torch.Generator().manual_seed(zlib.crc32(("proj:" + name).encode()) & 0x7FFFFFFF)
+    return torch.randn(N_PROJ, numel, generator=g, dtype=torch.float64)
+
+
+def q_sample(sched, x_start: torch.Tensor, t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """DD/denoising_diffusion.py:813-821 (``extract`` :394-397 = gather + reshape (B,1,1,1))."""
+    a = sched["sqrt_alphas_cumprod"][t].reshape(-1, 1, 1, 1)
+    b = sched["sqrt_one_minus_alphas_cumprod"][t].reshape(-1, 1, 1, 1)
+    return a * x_start + b * noise
+
+
+def target_of(sched, objective: str, x_start, t, noise):
+    """:864-872; predict_v :582-586."""
+    if objective == "pred_noise":
+        return noise
+    if objective == "pred_x0":
+        return x_start
+    if objective == "pred_v":
+        a = sched["sqrt_alphas_cumprod"][t].reshape(-1, 1, 1, 1)
+        b = sched["sqrt_one_minus_alphas_cumprod"][t].reshape(-1, 1, 1, 1)
+        return a * noise - b * x_start
+    raise ValueError(f"unknown objective {objective}")
+
+
+def p_losses(sd: Dict[str, torch.Tensor], cfg, sched, x_start, t, noise, objective: str = "pred_noise", **fwd_kw):
+    """:823-889 with loss_weight from the schedule buffers (ones for the default ``ddpm=True``, :532-533)."""
+    x = q_sample(sched, x_start, t, noise)
+    out = uo.unet_forward(sd, cfg, x, t, **fwd_kw)
+    loss = torch.nn.functional.mse_loss(out, target_of(sched, objective, x_start, t, noise), reduction="none")
+    loss = loss.reshape(loss.shape[0], -1).mean(dim=1) * sched["loss_weight"][t]
+    return loss.mean()
+
+
+def loss_and_grads(sd, cfg, sched, x_start, t, noise, objective: str = "pred_noise",
+                   **fwd_kw) -> Tuple[float, Dict[str, torch.Tensor]]:
+    """(loss, {parameter name: gradient}) of one ``p_losses`` call."""
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    loss = p_losses(leaf, cfg, sched, x_start, t, noise, objective, **fwd_kw)
+    loss.backward()
+    return float(loss.detach()), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}

@@ -79,3 +79,29 @@ def golden_r3():
     """Round-3 fixtures from the reference (tests/golden/make_golden_r3.py): the LDM YAML shapes (3x16x16 / 3x8x8 latents,
     the ch_mult (1,2,4,8) VQModel), objectives pred_x0 / pred_v, self-conditioning."""
     return load_golden("r3.pt")
+
+
+@pytest.fixture(scope="session")
+def golden_train():
+    """Loss + parameter-gradient digests of the reference's own p_losses(...).backward()
+    (tests/golden/make_golden_train.py)."""
+    return load_golden("train.pt")
+
+
+def check_grad_digest(name: str, grad: torch.Tensor, dg: dict, tol: float):
+    """A gradient against its golden digest: norm, 8 random projections, the first elements, the whole tensor if small.
+    Every check is relative to the golden gradient's norm (a projection of a vector of norm n on a unit-variance random
+    direction is ~n, so an error of tol*n in the vector moves it by ~tol*n)."""
+    from oracle.train_oracle import directions
+
+    flat = grad.detach().double().cpu().reshape(-1)
+    n = max(dg["norm"], 1e-30)
+    assert abs(float(flat.norm()) - dg["norm"]) <= tol * n, (name, float(flat.norm()), dg["norm"])
+    proj = directions(name, flat.numel()) @ flat
+    err = float((proj - dg["proj"]).abs().max())
+    assert err <= 4 * tol * n, (name, "projection", err / n)
+    head = dg["head"].double()
+    scale = max(float(head.norm()), n * (head.numel() / flat.numel()) ** 0.5)
+    assert float((flat[: head.numel()] - head).norm()) <= 4 * tol * scale, (name, "head")
+    if "full" in dg:
+        assert float((flat - dg["full"].double().reshape(-1)).norm()) <= tol * n, (name, "full tensor")

@@ -364,3 +364,34 @@ def test_r3_objectives_and_self_conditioning(golden_r3):
     y = so.ddim_sample(smodel, dm.make_schedule(1000, "linear"), b["shape"], so.NoiseStream(b["seed"]), b["S"],
                        self_condition=True)
     assert rel_l2(y, b["y"]) < 1e-4
+
+
+# ---- training step: loss and gradients against the reference's autograd -----------------------
+TRAIN_CASES = {
+    "small_d32": (UnetConfig(dim=32, dim_mults=(1, 2), channels=3), 41),
+    "mid_d64": (UnetConfig(dim=64, dim_mults=(1, 2), channels=3), 42),
+    "mid_d64_pred_x0": (UnetConfig(dim=64, dim_mults=(1, 2), channels=3), 42),
+    "mid_d64_pred_v": (UnetConfig(dim=64, dim_mults=(1, 2), channels=3), 42),
+    "full": (UnetConfig(), 0),
+}
+
+
+@pytest.mark.parametrize("case", list(TRAIN_CASES))
+def test_train_loss_and_gradients(golden_train, case):
+    """oracle/train_oracle.py (autograd through the oracle U-Net) against the reference's p_losses(...).backward():
+    q_sample, the loss, and every one of the parameter gradients."""
+    from conftest import check_grad_digest
+    from oracle import train_oracle as to
+
+    cfg, salt = TRAIN_CASES[case]
+    b = golden_train[case]
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=salt)
+    sched = dm.make_schedule(b["T"], "linear")
+    x_start = b["img"] * 2 - 1
+    assert rel_l2(to.q_sample(sched, x_start, b["t"], b["noise"]), b["x_noisy"]) < 1e-6
+    torch.set_num_threads(8)
+    loss, grads = to.loss_and_grads(sd, cfg, sched, x_start, b["t"], b["noise"], b["objective"])
+    assert abs(loss - b["loss"]) <= 1e-5 * abs(b["loss"]), (loss, b["loss"])
+    assert set(grads) == set(b["grads"])
+    for name, dg in b["grads"].items():
+        check_grad_digest(name, grads[name], dg, 2e-5)
