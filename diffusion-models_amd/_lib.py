@@ -30,6 +30,7 @@ EXPORTS = (
     "dm_op_attention", "dm_op_sampler_update",
     "dm_conv_create", "dm_conv_destroy", "dm_conv_forward", "dm_op_pool2d", "dm_op_resize_bilinear",
     "dm_op_copy_channels_nhwc", "dm_op_global_avgpool", "dm_op_linear",
+    "dm_unet_train_enable", "dm_unet_grad_floats", "dm_unet_get_grad", "dm_unet_loss_backward", "dm_op_q_sample",
     "dm_profile_enable", "dm_profile_read",
 )
 
@@ -138,6 +139,13 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_op_copy_channels_nhwc.argtypes = [fp, i32, fp, i32, i32, i64, vp]
     lib.dm_op_global_avgpool.argtypes = [fp, fp, i32, i32, i32, vp]
     lib.dm_op_linear.argtypes = [fp, fp, fp, fp, i32, i32, i32, vp]
+    lib.dm_unet_train_enable.argtypes = [vp]
+    lib.dm_unet_grad_floats.argtypes = [vp]
+    lib.dm_unet_grad_floats.restype = i64
+    lib.dm_unet_get_grad.argtypes = [vp, C.c_char_p, fp, vp]
+    lib.dm_unet_loss_backward.argtypes = [vp, fp, C.POINTER(i64), C.POINTER(C.c_float), fp, i32, C.POINTER(C.c_float), fp,
+                                          i32, i32, i32, vp]
+    lib.dm_op_q_sample.argtypes = [fp, fp, C.POINTER(C.c_float), fp, i32, i32, vp]
     lib.dm_profile_enable.argtypes = [i32]
     lib.dm_profile_read.argtypes = [C.POINTER(ProfileRow), i32, C.POINTER(i32)]
 

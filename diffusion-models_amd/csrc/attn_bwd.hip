@@ -1,0 +1,349 @@
+// Backward of the two attention cores for the training step (autograd of DD/denoising_diffusion.py:179-192
+// LinearAttention and :221-226 + DD/attend.py:109-124 Attention).  dim_head = 32, 4 learned memory key/values.
+// qkv / dqkv are NHWC token rows [q(h,d) | k(h,d) | v(h,d)]; the cores hold < 2 % of a step's FLOPs, so these are plain
+// LDS-tiled VALU kernels with a fixed summation order (no atomics).
+//
+// LinearAttention:  p = softmax_d(q);  qs = p * scale;  ks = softmax_tokens(k_ext);  ctx[d][e] = sum_j ks[d][j] v_ext[e][j];
+//                   out[e][i] = sum_d ctx[d][e] qs[d][i]
+//   dctx[d][e] = sum_i qs[d][i] dout[e][i]         dqs[d][i] = sum_e ctx[d][e] dout[e][i]
+//   dq[d][i]   = scale p[d][i] (dqs[d][i] - sum_d' p[d'][i] dqs[d'][i])
+//   dks[d][j]  = sum_e dctx[d][e] v[e][j]          dv[e][j] = sum_d ks[d][j] dctx[d][e]
+//   dk[d][j]   = ks[d][j] (dks[d][j] - S[d]),      S[d] = sum_j ks dks = sum_e dctx[d][e] ctx[d][e]
+#include "dm_common.h"
+
+#include <algorithm>
+
+namespace dm {
+
+constexpr int BDH = 32;
+constexpr int NMEM = 4;
+
+// part 1: grid (ceil(n / 64), B), 64 * heads threads (thread = head * 64 + token): dq, and this block's share of dctx
+__global__ void linattn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                     const float* __restrict__ dout, float* __restrict__ dqkv,
+                                     float* __restrict__ dctx_part, int n, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* cs = sm;                                // [heads][32][32] ctx
+    float* ps = cs + heads * BDH * BDH;            // [heads][64][33] scale * p
+    float* ds = ps + heads * 64 * (BDH + 1);       // [heads][64][33] dout
+    const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+    const int tid = threadIdx.x;
+    const int h = tid >> 6, tl = tid & 63;
+    const int tok = blk * 64 + tl;
+    const int ld = 3 * heads * BDH, hid = heads * BDH;
+    for (int i = tid; i < heads * BDH * BDH; i += blockDim.x) cs[i] = ctx[(size_t)b * heads * BDH * BDH + i];
+    float q[BDH], dq[BDH], dov[BDH];
+    const bool ok = tok < n;
+    const float* qp = qkv + ((size_t)b * n + (ok ? tok : 0)) * ld + h * BDH;
+    const float* dp = dout + ((size_t)b * n + (ok ? tok : 0)) * hid + h * BDH;
+    float m = -INFINITY;
+#pragma unroll
+    for (int d = 0; d < BDH; ++d) {
+        q[d] = qp[d];
+        dov[d] = ok ? dp[d] : 0.f;
+        m = fmaxf(m, q[d]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int d = 0; d < BDH; ++d) {
+        q[d] = __expf(q[d] - m);
+        sum += q[d];
+    }
+    const float inv = 1.0f / sum;
+    __syncthreads();
+    float dot = 0.f;
+#pragma unroll
+    for (int d = 0; d < BDH; ++d) {
+        q[d] *= inv;  // p
+        float s = 0.f;
+        const float* cr = cs + (h * BDH + d) * BDH;
+#pragma unroll
+        for (int e = 0; e < BDH; ++e) s += cr[e] * dov[e];
+        dq[d] = s;  // dqs
+        dot += q[d] * s;
+    }
+    if (ok) {
+        float* o = dqkv + ((size_t)b * n + tok) * ld + h * BDH;
+#pragma unroll
+        for (int d = 0; d < BDH; ++d) o[d] = scale * q[d] * (dq[d] - dot);
+    }
+#pragma unroll
+    for (int d = 0; d < BDH; ++d) {
+        ps[(h * 64 + tl) * (BDH + 1) + d] = ok ? scale * q[d] : 0.f;
+        ds[(h * 64 + tl) * (BDH + 1) + d] = dov[d];
+    }
+    __syncthreads();
+    // dctx share of this block: thread -> (head, d, 16 e's)
+    {
+        const int hh = tid >> 6, d = (tid & 63) >> 1, e0 = (tid & 1) * 16;
+        float acc[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int t = 0; t < 64; ++t) {
+            const float pv = ps[(hh * 64 + t) * (BDH + 1) + d];
+            const float* dr = ds + (hh * 64 + t) * (BDH + 1) + e0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += pv * dr[e];
+        }
+        float* o = dctx_part + ((((size_t)b * nblk + blk) * heads + hh) * BDH + d) * BDH + e0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = acc[e];
+    }
+}
+
+// part 2: grid (heads, B), 256 threads: dk, dv (and the memory key/value gradients of this image)
+__global__ __launch_bounds__(256) void linattn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ mem_kv,
+                                                             const float* __restrict__ ctx,
+                                                             const float* __restrict__ dctx_part, int nblk,
+                                                             float* __restrict__ dqkv, float* __restrict__ dmem_part, int n,
+                                                             int heads) {
+    __shared__ float dctx[BDH][BDH + 1];
+    __shared__ float S[BDH], kmax[BDH], kinv[BDH];
+    __shared__ float red[8][BDH];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int ld = 3 * heads * BDH;
+    const float* kbase = qkv + (size_t)b * n * ld + heads * BDH + h * BDH;
+    const float* vbase = qkv + (size_t)b * n * ld + 2 * heads * BDH + h * BDH;
+    const float* mk = mem_kv + (size_t)h * BDH * NMEM;            // [d][j]
+    const float* mv = mem_kv + (size_t)(heads + h) * BDH * NMEM;  // [e][j]
+    const int ntok = n + NMEM;
+    for (int i = tid; i < BDH * BDH; i += 256) {
+        float s = 0.f;
+        for (int k = 0; k < nblk; ++k) s += dctx_part[(((size_t)b * nblk + k) * heads + h) * BDH * BDH + i];
+        dctx[i >> 5][i & 31] = s;
+    }
+    // softmax statistics of k over the tokens (memory tokens first, as the reference concatenates them)
+    {
+        const int d = tid & 31, part = tid >> 5;
+        float m = -INFINITY;
+        for (int t = part; t < ntok; t += 8) m = fmaxf(m, t < NMEM ? mk[d * NMEM + t] : kbase[(size_t)(t - NMEM) * ld + d]);
+        red[part][d] = m;
+        __syncthreads();
+        if (tid < BDH) {
+            float mm = red[0][tid];
+            for (int q = 1; q < 8; ++q) mm = fmaxf(mm, red[q][tid]);
+            kmax[tid] = mm;
+        }
+        __syncthreads();
+        float s = 0.f;
+        const float km = kmax[d];
+        for (int t = part; t < ntok; t += 8)
+            s += __expf((t < NMEM ? mk[d * NMEM + t] : kbase[(size_t)(t - NMEM) * ld + d]) - km);
+        __syncthreads();
+        red[part][d] = s;
+        __syncthreads();
+        if (tid < BDH) {
+            float ss = 0.f;
+            for (int q = 0; q < 8; ++q) ss += red[q][tid];
+            kinv[tid] = 1.0f / ss;
+            const float* cr = ctx + ((size_t)(b * heads + h) * BDH + tid) * BDH;
+            float sd = 0.f;
+            for (int e = 0; e < BDH; ++e) sd += dctx[tid][e] * cr[e];
+            S[tid] = sd;
+        }
+        __syncthreads();
+    }
+    for (int t = tid; t < ntok; t += 256) {
+        float ks[BDH], vv[BDH];
+        const bool mem = t < NMEM;
+#pragma unroll
+        for (int d = 0; d < BDH; ++d) {
+            const float kv = mem ? mk[d * NMEM + t] : kbase[(size_t)(t - NMEM) * ld + d];
+            ks[d] = __expf(kv - kmax[d]) * kinv[d];
+            vv[d] = mem ? mv[d * NMEM + t] : vbase[(size_t)(t - NMEM) * ld + d];
+        }
+        float dk[BDH], dvv[BDH];
+#pragma unroll
+        for (int e = 0; e < BDH; ++e) dvv[e] = 0.f;
+#pragma unroll
+        for (int d = 0; d < BDH; ++d) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < BDH; ++e) {
+                s += dctx[d][e] * vv[e];
+                dvv[e] += ks[d] * dctx[d][e];
+            }
+            dk[d] = ks[d] * (s - S[d]);
+        }
+        if (mem) {
+            float* o = dmem_part + (size_t)b * 2 * heads * BDH * NMEM;
+#pragma unroll
+            for (int d = 0; d < BDH; ++d) {
+                o[((size_t)h * BDH + d) * NMEM + t] = dk[d];
+                o[((size_t)(heads + h) * BDH + d) * NMEM + t] = dvv[d];
+            }
+        } else {
+            float* ok = dqkv + ((size_t)b * n + (t - NMEM)) * ld + heads * BDH + h * BDH;
+            float* ov = ok + heads * BDH;
+#pragma unroll
+            for (int d = 0; d < BDH; ++d) {
+                ok[d] = dk[d];
+                ov[d] = dvv[d];
+            }
+        }
+    }
+}
+
+size_t linattn_bwd_ws_floats(int B, int n, int heads) { return (size_t)B * ((n + 63) / 64) * heads * BDH * BDH; }
+
+// qkv (B, n, 3*heads*32), ctx (B, heads, 32, 32) as the forward core left it, dout (B, n, heads*32) -> dqkv (same shape as
+// qkv), dmem_part (B, 2, heads, 32, 4) per-image memory key/value gradients (the caller sums over B)
+int launch_linear_attention_core_bwd(const float* qkv, const float* mem_kv, const float* ctx, const float* dout, float* ws,
+                                     float* dqkv, float* dmem_part, int B, int n, int heads, int dh, hipStream_t s) {
+    DM_REQUIRE(dh == BDH && heads >= 1 && heads <= 16, "linear attention backward: dim_head 32");
+    const int nblk = (n + 63) / 64;
+    const size_t lds = (size_t)(heads * BDH * BDH + 2 * heads * 64 * (BDH + 1)) * sizeof(float);
+    DM_REQUIRE(lds <= 160 * 1024 && 64 * heads <= 1024, "linear attention backward: too many heads");
+    static LdsOptIn flag;
+    if (lds_opt_in(flag, reinterpret_cast<const void*>(linattn_bwd_q_kernel), 1)) return 1;
+    hipLaunchKernelGGL(linattn_bwd_q_kernel, dim3(nblk, B), dim3(64 * heads), lds, s, qkv, ctx, dout, dqkv, ws, n, heads,
+                       1.0f / sqrtf((float)dh));
+    DM_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(linattn_bwd_kv_kernel, dim3(heads, B), dim3(256), 0, s, qkv, mem_kv, ctx, ws, nblk, dqkv, dmem_part, n,
+                       heads);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Full attention: P = softmax_j(scale q_i k_j), o_i = sum_j P_ij v_j (keys = 4 memory rows, then the tokens)
+//   dP_ij = do_i . v_j;  D_i = do_i . o_i;  dS_ij = P_ij (dP_ij - D_i);  dq_i = scale sum_j dS_ij k_j;
+//   dk_j = scale sum_i dS_ij q_i;  dv_j = sum_i P_ij do_i
+// grid (heads, B); phase 1: thread = query (row statistics, dq); phase 2: thread = key (dk, dv), fixed order over queries.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ mem_kv,
+                                                       const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                       float* __restrict__ dmem_part, int n, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int nk = n + NMEM;
+    float* Ks = sm;                       // [nk][33]
+    float* Vs = Ks + nk * (BDH + 1);      // [nk][33]
+    float* Qs = Vs + nk * (BDH + 1);      // [n][33]
+    float* Ds = Qs + n * (BDH + 1);       // [n][33]  dout
+    float* rm = Ds + n * (BDH + 1);       // [n] row max
+    float* rl = rm + n;                   // [n] 1 / row sum
+    float* rD = rl + n;                   // [n] D_i
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int ld = 3 * heads * BDH, hid = heads * BDH;
+    const float* mk = mem_kv + (size_t)h * NMEM * BDH;            // [j][d]
+    const float* mv = mem_kv + (size_t)(heads + h) * NMEM * BDH;
+    for (int i = tid; i < nk * BDH; i += 256) {
+        const int j = i >> 5, d = i & 31;
+        const size_t row = ((size_t)b * n + (j - NMEM)) * ld + h * BDH + d;
+        Ks[j * (BDH + 1) + d] = j < NMEM ? mk[j * BDH + d] : qkv[row + hid];
+        Vs[j * (BDH + 1) + d] = j < NMEM ? mv[j * BDH + d] : qkv[row + 2 * hid];
+    }
+    for (int i = tid; i < n * BDH; i += 256) {
+        const int t = i >> 5, d = i & 31;
+        Qs[t * (BDH + 1) + d] = qkv[((size_t)b * n + t) * ld + h * BDH + d];
+        Ds[t * (BDH + 1) + d] = dout[((size_t)b * n + t) * hid + h * BDH + d];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        float q[BDH], dov[BDH];
+#pragma unroll
+        for (int d = 0; d < BDH; ++d) {
+            q[d] = Qs[i * (BDH + 1) + d];
+            dov[d] = Ds[i * (BDH + 1) + d];
+        }
+        float m = -INFINITY;
+        for (int j = 0; j < nk; ++j) {
+            float sc = 0.f;
+#pragma unroll
+            for (int d = 0; d < BDH; ++d) sc += q[d] * Ks[j * (BDH + 1) + d];
+            m = fmaxf(m, sc * scale);
+        }
+        float l = 0.f, D = 0.f;
+        for (int j = 0; j < nk; ++j) {
+            float sc = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < BDH; ++d) {
+                sc += q[d] * Ks[j * (BDH + 1) + d];
+                dp += dov[d] * Vs[j * (BDH + 1) + d];
+            }
+            const float e = __expf(sc * scale - m);
+            l += e;
+            D += e * dp;
+        }
+        const float linv = 1.0f / l;
+        D *= linv;
+        float dq[BDH];
+#pragma unroll
+        for (int d = 0; d < BDH; ++d) dq[d] = 0.f;
+        for (int j = 0; j < nk; ++j) {
+            float sc = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < BDH; ++d) {
+                sc += q[d] * Ks[j * (BDH + 1) + d];
+                dp += dov[d] * Vs[j * (BDH + 1) + d];
+            }
+            const float dS = __expf(sc * scale - m) * linv * (dp - D);
+#pragma unroll
+            for (int d = 0; d < BDH; ++d) dq[d] += dS * Ks[j * (BDH + 1) + d];
+        }
+        rm[i] = m;
+        rl[i] = linv;
+        rD[i] = D;
+        float* o = dqkv + ((size_t)b * n + i) * ld + h * BDH;
+#pragma unroll
+        for (int d = 0; d < BDH; ++d) o[d] = scale * dq[d];
+    }
+    __syncthreads();
+    for (int j = tid; j < nk; j += 256) {
+        float kk[BDH], vv[BDH], dk[BDH], dv[BDH];
+#pragma unroll
+        for (int d = 0; d < BDH; ++d) {
+            kk[d] = Ks[j * (BDH + 1) + d];
+            vv[d] = Vs[j * (BDH + 1) + d];
+            dk[d] = 0.f;
+            dv[d] = 0.f;
+        }
+        for (int i = 0; i < n; ++i) {
+            float sc = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < BDH; ++d) {
+                sc += Qs[i * (BDH + 1) + d] * kk[d];
+                dp += Ds[i * (BDH + 1) + d] * vv[d];
+            }
+            const float P = __expf(sc * scale - rm[i]) * rl[i];
+            const float dS = P * (dp - rD[i]);
+#pragma unroll
+            for (int d = 0; d < BDH; ++d) {
+                dk[d] += dS * Qs[i * (BDH + 1) + d];
+                dv[d] += P * Ds[i * (BDH + 1) + d];
+            }
+        }
+        if (j < NMEM) {
+            float* o = dmem_part + (size_t)b * 2 * heads * NMEM * BDH;
+#pragma unroll
+            for (int d = 0; d < BDH; ++d) {
+                o[((size_t)h * NMEM + j) * BDH + d] = scale * dk[d];
+                o[((size_t)(heads + h) * NMEM + j) * BDH + d] = dv[d];
+            }
+        } else {
+            float* ok = dqkv + ((size_t)b * n + (j - NMEM)) * ld + hid + h * BDH;
+            float* ov = ok + hid;
+#pragma unroll
+            for (int d = 0; d < BDH; ++d) {
+                ok[d] = scale * dk[d];
+                ov[d] = dv[d];
+            }
+        }
+    }
+}
+
+// qkv (B, n, 3*heads*32), dout (B, n, heads*32) -> dqkv, dmem_part (B, 2, heads, 4, 32)
+int launch_attention_core_bwd(const float* qkv, const float* mem_kv, const float* dout, float* dqkv, float* dmem_part, int B,
+                              int n, int heads, int dh, hipStream_t s) {
+    DM_REQUIRE(dh == BDH, "attention backward: dim_head 32");
+    const size_t lds = ((size_t)(2 * (n + NMEM) + 2 * n) * (BDH + 1) + 3 * n) * sizeof(float);
+    DM_REQUIRE(lds <= 160 * 1024, "attention backward: sequence too long for the LDS-resident kernel");
+    static LdsOptIn flag;
+    if (lds_opt_in(flag, reinterpret_cast<const void*>(attn_bwd_kernel), 1)) return 1;
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(heads, B), dim3(256), lds, s, qkv, mem_kv, dout, dqkv, dmem_part, n, heads,
+                       1.0f / sqrtf((float)dh));
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dm

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -220,6 +221,8 @@ struct Stage {
     ConvLayer resample;
 };
 
+struct TrainState;  // dm_train.inc
+
 }  // namespace dm
 
 using namespace dm;
@@ -233,6 +236,7 @@ struct dm_unet {
     std::vector<std::string> order;
     bool finalized = false;
     bool poisoned = false;  // a refresh failed half-way: device weights are a mix of old and new values
+    dm::TrainState* train = nullptr;  // dm_unet_train_enable: gradient buffers, dgrad weights, training workspace
     DeviceOwner own;
     // layers
     ConvLayer init_conv, final_conv;
@@ -293,6 +297,9 @@ struct dm_unet {
 };
 
 namespace dm {
+
+void free_train(dm_unet* u);  // dm_train.inc
+static int build_train(dm_unet* u);
 
 static void expect(dm_unet* u, const std::string& name, std::vector<int64_t> shape) {
     HostTensor t;
@@ -1303,6 +1310,7 @@ int dm_unet_create(const dm_unet_cfg* cfg, int device, dm_unet** out) {
 void dm_unet_destroy(dm_unet* u) {
     if (!u) return;
     (void)hipSetDevice(u->device);
+    if (u->train) free_train(u);
     u->drop_graph();
     if (u->cap_stream) (void)hipStreamDestroy(u->cap_stream);
     if (u->done_ev) (void)hipEventDestroy(u->done_ev);
@@ -1400,6 +1408,10 @@ int dm_unet_refresh(dm_unet* u) {
         u->drop_graph();
         u->poisoned = true;
         return rc;
+    }
+    if (u->train && build_train(u)) {  // the input-gradient convolutions are packed from the same parameters
+        u->poisoned = true;
+        return 1;
     }
     u->poisoned = false;
     for (auto& kv : u->params) kv.second.dirty = false;
@@ -1629,3 +1641,4 @@ int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, uint64_t eleme
 #include "dm_ops.inc"
 #include "dm_vae.inc"
 #include "dm_consumer.inc"
+#include "dm_train.inc"

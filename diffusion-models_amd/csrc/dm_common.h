@@ -322,4 +322,48 @@ int launch_linattn_bf16x6(const LinAttnFused& w, const float* x, float* ws, floa
 int launch_linattn_fused(const LinAttnFused& w, const float* x, float* ws, float* y, int B, int n, bool add_x,
                          hipStream_t s);
 
+
+// ---------------------------------------------------------------------------------------
+// Training step (dm_train.inc): weight gradients (wgrad_mfma.hip), norm / activation / loss / optimiser kernels
+// (train_kernels.hip), attention-core backward (attn_bwd.hip)
+// ---------------------------------------------------------------------------------------
+size_t wgrad_ws_floats(int B, int Ho, int Wo, int Cout, int Cin, int T, int* splits_out);
+// mode: 0 3x3 pad 1 (up: nearest x2 source), 1 1x1, 2 2x2 stride 2 (Ho, Wo = OUTPUT size; the source is 2Ho x 2Wo).
+// dw: OIHW (mode 2: the (Cout, 4 C) Downsample layout); ws from wgrad_ws_floats
+int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float* dy, int Cout, int B, int Ho, int Wo,
+                 int mode, int up, float* ws, float* dw, int accumulate, hipStream_t s);
+size_t wgrad_naive_ws_floats(int B, int H, int Cout, int Cin, int KH, int KW, int* splits_out);
+int launch_wgrad_naive(const float* x, int x_nchw, const float* dy, int dy_nchw, int Cin, int Cout, int KH, int KW, int pad,
+                       int B, int H, int W, float* ws, float* dw, int accumulate, hipStream_t s);
+size_t norm_act_bwd_ws_floats(int B, int pix_per_image, int C);
+int launch_norm_act_bwd(const float* dy, const float* u, const float* g, const float* ss, int ss_stride, int pix_per_image,
+                        float* du, float* ws, float* dg, float* dbias, float* dss, int dss_stride, int B, int C, int flags,
+                        int accumulate, hipStream_t s);
+size_t colsum_ws_floats(int64_t rows, int C);
+int launch_colsum(const float* x, int64_t rows, int C, int64_t row_stride, int64_t col_stride, float* ws, float* out,
+                  int accumulate, hipStream_t s);
+int launch_colsum_nchw(const float* dy, int B, int C, int HW, float* out, int accumulate, hipStream_t s);
+int launch_act_fwd(const float* x, float* y, int64_t n, int act, hipStream_t s);  // 1 SiLU, 2 GELU (erf)
+int launch_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, hipStream_t s);
+int launch_add3(const float* a, const float* b, const float* c, float* y, int64_t n, hipStream_t s);
+int launch_depth_to_space(const float* t, const float* add, float* dx, int B, int Ho, int Wo, int C, hipStream_t s);
+int launch_pool2x2_sum(const float* du, const float* add, float* dx, int B, int H, int W, int C, hipStream_t s);
+int launch_pointwise_small_dgrad(const float* dy_nchw, const float* w_oc, float* dx, int64_t pixels, int C, int Cout, int HW,
+                                 hipStream_t s);
+int launch_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, float* dw, int R, int I, int O, int act_in,
+                        int accumulate, hipStream_t s);
+int launch_linear_dgrad(const float* dy, int ldy, const float* W, float* dx, int ldx, int R, int I, int O, hipStream_t s);
+int launch_q_sample(const float* x_start, const float* noise, const float* coef_dev, float* x, int B, int per_sample,
+                    hipStream_t s);
+int launch_mse_loss(const float* out, const float* x_start, const float* noise, const float* coef_dev, float* dout,
+                    float* part, float* loss, int B, int per_sample, int objective, hipStream_t s);
+int launch_grad_norm(const float* grads, int64_t n, double* part_ws, float max_norm, float* out2, hipStream_t s);
+int launch_adam_ema(float* p, const float* g, float* m, float* v, float* ema, const float* clip2, int64_t n, float lr,
+                    float b1, float b2, float eps, int step, float ema_decay, hipStream_t s);
+size_t linattn_bwd_ws_floats(int B, int n, int heads);
+int launch_linear_attention_core_bwd(const float* qkv, const float* mem_kv, const float* ctx, const float* dout, float* ws,
+                                     float* dqkv, float* dmem_part, int B, int n, int heads, int dh, hipStream_t s);
+int launch_attention_core_bwd(const float* qkv, const float* mem_kv, const float* dout, float* dqkv, float* dmem_part, int B,
+                              int n, int heads, int dh, hipStream_t s);
+
 }  // namespace dm

@@ -1,0 +1,554 @@
+// Backward kernels of the training step that are not convolutions (DD/denoising_diffusion.py:805-900 is the loss; the
+// operators differentiated here are Block :113-122 / RMSNorm :66-67, the time MLP :280-285 and ResnetBlock.mlp :127-130,
+// Downsample / Upsample rearrangements :48-58, final_conv, q_sample :813-821 and the weighted MSE :874-878).
+// All activations NHWC fp32 (rows = pixels, C contiguous) unless the name says nchw.  HBM-bound.
+#include "conv_device.h"
+
+#include <algorithm>
+
+namespace dm {
+
+// ---------------------------------------------------------------------------------------
+// Block / RMSNorm backward, one pass over the rows:
+//   forward   n = u / max(||u||, 1e-12);  w = n * g * sqrt(C);  v = w * (scale + 1) + shift;  y = v * sigmoid(v)
+//   backward  dv = dy * silu'(v);  dshift += dv;  dscale += dv * w;  dw = dv * (scale + 1);  dg += dw * n * sqrt(C);
+//             dn = dw * g * sqrt(C);  du = (dn - n * <n, dn>) / max(||u||, 1e-12);  dbias += du
+// A wave works on 64 / LPR rows at a time (LPR lanes of 4 channels per row); per-channel sums are kept in registers over
+// the rows of the workgroup's chunk (one image), combined through LDS in a fixed order, and written as partial sums
+// [image][chunk][4][C]; rowgrad_reduce_kernel finishes them (deterministic: no atomics).
+// ---------------------------------------------------------------------------------------
+struct NormBwdParams {
+    const float* dy;
+    const float* u;
+    const float* g;
+    const float* ss;   // scale = ss[b * ss_stride + c], shift = ss[b * ss_stride + C + c]; nullptr: none
+    float* du;
+    float* part;       // [B][chunks][4][C]: dg, dbias, dscale, dshift
+    int C, C4, LPR, NV, ss_stride, flags;
+    int pix_per_image, rows_per_chunk, chunks;
+};
+
+template <int NV>
+__global__ __launch_bounds__(256) void norm_act_bwd_kernel(const NormBwdParams p) {
+    extern __shared__ float red[];  // [groups][4][C]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int LPR = p.LPR, RPW = 64 / LPR;
+    const int sub = lane % LPR, rg = lane / LPR;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int row_lo = chunk * p.rows_per_chunk, row_hi = min(row_lo + p.rows_per_chunk, p.pix_per_image);
+    const float sqrtC = sqrtf((float)p.C);
+    const bool has_ss = p.ss != nullptr && (p.flags & EPI_SCALE_SHIFT);
+    const bool silu = (p.flags & EPI_SILU) != 0;
+    const bool norm = (p.flags & EPI_NORM) != 0;
+    f32x4 gq[NV], sc[NV], sh[NV];
+    f32x4 a_g[NV], a_b[NV], a_sc[NV], a_sh[NV];
+    bool cv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c4 = sub + LPR * v;
+        cv[v] = c4 < p.C4;
+        const f32x4 z = make_f32x4(0.f, 0.f, 0.f, 0.f), one = make_f32x4(1.f, 1.f, 1.f, 1.f);
+        gq[v] = (cv[v] && p.g) ? *reinterpret_cast<const f32x4*>(p.g + 4 * c4) : one;
+        sc[v] = (cv[v] && has_ss) ? *reinterpret_cast<const f32x4*>(p.ss + (size_t)b * p.ss_stride + 4 * c4) : z;
+        sh[v] = (cv[v] && has_ss) ? *reinterpret_cast<const f32x4*>(p.ss + (size_t)b * p.ss_stride + p.C + 4 * c4) : z;
+        a_g[v] = a_b[v] = a_sc[v] = a_sh[v] = z;
+    }
+    for (int r0 = row_lo + wave * RPW; r0 < row_hi; r0 += 4 * RPW) {
+        const int r = r0 + rg;
+        const bool rv = r < row_hi;
+        const size_t base = ((size_t)b * p.pix_per_image + (rv ? r : row_lo)) * p.C;
+        f32x4 uv[NV], dv[NV];
+        float ssq = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const f32x4 z = make_f32x4(0.f, 0.f, 0.f, 0.f);
+            const int c4 = sub + LPR * v;
+            uv[v] = (cv[v] && rv) ? *reinterpret_cast<const f32x4*>(p.u + base + 4 * c4) : z;
+            dv[v] = (cv[v] && rv) ? *reinterpret_cast<const f32x4*>(p.dy + base + 4 * c4) : z;
+            ssq += uv[v].x * uv[v].x + uv[v].y * uv[v].y + uv[v].z * uv[v].z + uv[v].w * uv[v].w;
+        }
+        for (int m = 1; m < LPR; m <<= 1) ssq += __shfl_xor(ssq, m);
+        const float nrm = sqrtf(ssq);
+        const float rinv = norm ? 1.0f / fmaxf(nrm, 1e-12f) : 1.0f;
+        const bool clamped = nrm < 1e-12f;  // F.normalize divides by the clamp: no projection term
+        f32x4 nn[NV], dn[NV];
+        float dot = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float* un = reinterpret_cast<float*>(&uv[v]);
+            float* dd = reinterpret_cast<float*>(&dv[v]);
+            float* gg = reinterpret_cast<float*>(&gq[v]);
+            float* s1 = reinterpret_cast<float*>(&sc[v]);
+            float* s2 = reinterpret_cast<float*>(&sh[v]);
+            float* ag = reinterpret_cast<float*>(&a_g[v]);
+            float* asc = reinterpret_cast<float*>(&a_sc[v]);
+            float* ash = reinterpret_cast<float*>(&a_sh[v]);
+            float* np = reinterpret_cast<float*>(&nn[v]);
+            float* dnp = reinterpret_cast<float*>(&dn[v]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float n = un[j] * rinv;
+                const float w = norm ? n * gg[j] * sqrtC : un[j];
+                const float val = has_ss ? w * (s1[j] + 1.0f) + s2[j] : w;
+                float d = dd[j];
+                if (silu) {
+                    const float sig = 1.0f / (1.0f + __expf(-val));
+                    d *= sig * (1.0f + val * (1.0f - sig));
+                }
+                ash[j] += d;
+                asc[j] += d * w;
+                const float dw = has_ss ? d * (s1[j] + 1.0f) : d;
+                ag[j] += dw * n * sqrtC;
+                const float dnj = norm ? dw * gg[j] * sqrtC : dw;
+                np[j] = n;
+                dnp[j] = dnj;
+                dot += n * dnj;
+            }
+        }
+        for (int m = 1; m < LPR; m <<= 1) dot += __shfl_xor(dot, m);
+        if (!norm || clamped) dot = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            f32x4 o;
+            float* op = reinterpret_cast<float*>(&o);
+            float* np = reinterpret_cast<float*>(&nn[v]);
+            float* dnp = reinterpret_cast<float*>(&dn[v]);
+            float* ab = reinterpret_cast<float*>(&a_b[v]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                op[j] = (dnp[j] - np[j] * dot) * rinv;
+                ab[j] += op[j];
+            }
+            if (cv[v] && rv) *reinterpret_cast<f32x4*>(p.du + base + 4 * (sub + LPR * v)) = o;
+        }
+    }
+    // ---- combine the row groups of the workgroup in a fixed order
+    const int groups = 4 * RPW, grp = wave * RPW + rg;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c4 = sub + LPR * v;
+        if (!cv[v]) continue;
+        float* dst = red + (size_t)grp * 4 * p.C + 4 * c4;
+        *reinterpret_cast<f32x4*>(dst) = a_g[v];
+        *reinterpret_cast<f32x4*>(dst + p.C) = a_b[v];
+        *reinterpret_cast<f32x4*>(dst + 2 * p.C) = a_sc[v];
+        *reinterpret_cast<f32x4*>(dst + 3 * p.C) = a_sh[v];
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * p.C; i += 256) {
+        float s = 0.f;
+        for (int gi = 0; gi < groups; ++gi) s += red[(size_t)gi * 4 * p.C + i];
+        p.part[((size_t)b * p.chunks + chunk) * 4 * p.C + i] = s;
+    }
+}
+
+// dg[c] (+)= sum over images and chunks; dbias likewise; dss[b][c] / dss[b][C + c] = sum over the chunks of image b
+__global__ void rowgrad_reduce_kernel(const float* __restrict__ part, int B, int chunks, int C, float* __restrict__ dg,
+                                      float* __restrict__ dbias, float* __restrict__ dss, int dss_stride, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sg = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float ssc = 0.f, ssh = 0.f;
+        for (int k = 0; k < chunks; ++k) {
+            const float* q = part + ((size_t)b * chunks + k) * 4 * C;
+            sg += q[c];
+            sb += q[C + c];
+            ssc += q[2 * C + c];
+            ssh += q[3 * C + c];
+        }
+        if (dss) {
+            dss[(size_t)b * dss_stride + c] = ssc;
+            dss[(size_t)b * dss_stride + C + c] = ssh;
+        }
+    }
+    if (dg) dg[c] = accumulate ? dg[c] + sg : sg;
+    if (dbias) dbias[c] = accumulate ? dbias[c] + sb : sb;
+}
+
+static int pow2ceil(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+size_t norm_act_bwd_ws_floats(int B, int pix_per_image, int C) {
+    const int chunks = std::max(1, std::min(pix_per_image / 16, (1024 + B - 1) / B));
+    return (size_t)B * chunks * 4 * C;
+}
+
+// dy, u, du: [B * pix_per_image][C].  dg / dbias: [C] parameter gradients ((+)= with accumulate); dss: [B][dss_stride]
+// receives (dscale | dshift) at columns [0, 2C) of each row when the forward had a scale-shift, else nullptr.
+int launch_norm_act_bwd(const float* dy, const float* u, const float* g, const float* ss, int ss_stride, int pix_per_image,
+                        float* du, float* ws, float* dg, float* dbias, float* dss, int dss_stride, int B, int C, int flags,
+                        int accumulate, hipStream_t s) {
+    DM_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "norm_act_bwd: C must be a multiple of 4, at most 1024");
+    NormBwdParams p{};
+    p.dy = dy; p.u = u; p.g = g; p.ss = ss; p.du = du; p.part = ws;
+    p.C = C; p.C4 = C / 4;
+    p.LPR = std::min(64, pow2ceil(p.C4));
+    p.NV = (p.C4 + p.LPR - 1) / p.LPR;
+    p.ss_stride = ss_stride; p.flags = flags; p.pix_per_image = pix_per_image;
+    p.chunks = std::max(1, std::min(pix_per_image / 16, (1024 + B - 1) / B));
+    p.rows_per_chunk = (pix_per_image + p.chunks - 1) / p.chunks;
+    p.chunks = (pix_per_image + p.rows_per_chunk - 1) / p.rows_per_chunk;
+    const int groups = 4 * (64 / p.LPR);
+    const size_t lds = (size_t)groups * 4 * C * sizeof(float);
+    DM_REQUIRE(lds <= 64 * 1024, "norm_act_bwd: LDS");
+    const dim3 grid(p.chunks, B);
+    switch (p.NV) {
+        case 1: hipLaunchKernelGGL(norm_act_bwd_kernel<1>, grid, dim3(256), lds, s, p); break;
+        case 2: hipLaunchKernelGGL(norm_act_bwd_kernel<2>, grid, dim3(256), lds, s, p); break;
+        case 3: hipLaunchKernelGGL(norm_act_bwd_kernel<3>, grid, dim3(256), lds, s, p); break;
+        default: hipLaunchKernelGGL(norm_act_bwd_kernel<4>, grid, dim3(256), lds, s, p); break;
+    }
+    DM_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rowgrad_reduce_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, B, p.chunks, C, dg, dbias,
+                       (flags & EPI_SCALE_SHIFT) ? dss : nullptr, dss_stride, accumulate);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Column sums (bias gradients of convolutions that have no norm behind them): out[c] (+)= sum_r x[r * ld + c * cs].
+// Two passes: [blocks][C] partial sums, then the finish.
+// ---------------------------------------------------------------------------------------
+__global__ void colsum_partial_kernel(const float* __restrict__ x, int64_t rows, int C, int64_t row_stride, int64_t col_stride,
+                                      int rows_per_block, float* __restrict__ part) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, rows);
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += x[r * row_stride + c * col_stride];
+    part[(size_t)blockIdx.y * C + c] = s;
+}
+__global__ void colsum_finish_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ out,
+                                     int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < blocks; ++b) s += part[(size_t)b * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+size_t colsum_ws_floats(int64_t rows, int C) { return (size_t)std::min<int64_t>(rows, 512) * C; }
+int launch_colsum(const float* x, int64_t rows, int C, int64_t row_stride, int64_t col_stride, float* ws, float* out,
+                  int accumulate, hipStream_t s) {
+    const int blocks = (int)std::min<int64_t>(rows, 512);
+    const int rpb = (int)((rows + blocks - 1) / blocks);
+    const int nb = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, nb), dim3(64), 0, s, x, rows, C, row_stride, col_stride,
+                       rpb, ws);
+    DM_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, nb, C, out, accumulate);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// bias gradient of a convolution whose dY is NCHW (final_conv): sum over b and pixels of dy[b][c][:]
+__global__ void colsum_nchw_kernel(const float* __restrict__ dy, int B, int C, int HW, float* __restrict__ out,
+                                   int accumulate) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < (int64_t)B * HW; i += 256) {
+        const int64_t b = i / HW, q = i - b * HW;
+        s += dy[(b * C + c) * HW + q];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m > 0; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = accumulate ? out[c] + red[0] : red[0];
+}
+int launch_colsum_nchw(const float* dy, int B, int C, int HW, float* out, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_nchw_kernel, dim3(C), dim3(256), 0, s, dy, B, C, HW, out, accumulate);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Elementwise pieces
+// ---------------------------------------------------------------------------------------
+// act: 1 SiLU, 2 GELU (exact erf, nn.GELU default)
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int act) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    y[i] = act == 1 ? v / (1.0f + __expf(-v)) : 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+}
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int64_t n,
+                               int act) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    float d;
+    if (act == 1) {
+        const float sig = 1.0f / (1.0f + __expf(-v));
+        d = sig * (1.0f + v * (1.0f - sig));
+    } else {
+        d = 0.5f * (1.0f + erff(v * 0.70710678118654752f)) + v * 0.39894228040143268f * __expf(-0.5f * v * v);
+    }
+    dx[i] = dy[i] * d;
+}
+int launch_act_fwd(const float* x, float* y, int64_t n, int act, hipStream_t s) {
+    hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n, act);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, hipStream_t s) {
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, x, dx, n, act);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// y = a + b (+ c)
+__global__ void add3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                            float* __restrict__ y, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 v = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+    if (c) v += reinterpret_cast<const f32x4*>(c)[i];
+    reinterpret_cast<f32x4*>(y)[i] = v;
+}
+int launch_add3(const float* a, const float* b, const float* c, float* y, int64_t n, hipStream_t s) {
+    DM_REQUIRE(n % 4 == 0, "add3: length must be a multiple of 4");
+    hipLaunchKernelGGL(add3_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, a, b, c, y, n / 4);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Adjoint of the space-to-depth gather of Downsample: t is (B, Ho, Wo, 4 C) with channel (p1*2 + p2) * C + c
+// (the order the 1x1 kernel's K index runs in); dx (B, 2Ho, 2Wo, C)[2y + p1][2x + p2][c] = t[y][x][(p1*2+p2)*C + c] (+ add)
+__global__ void depth_to_space_kernel(const float* __restrict__ t, const float* __restrict__ add, float* __restrict__ dx,
+                                      int Ho, int Wo, int C, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = (int)(i % (C / 4));
+    int64_t px = i / (C / 4);
+    const int X = (int)(px % (2 * Wo));
+    px /= 2 * Wo;
+    const int Y = (int)(px % (2 * Ho));
+    const int64_t b = px / (2 * Ho);
+    const int sub = (Y & 1) * 2 + (X & 1);
+    f32x4 v = *reinterpret_cast<const f32x4*>(t + (((b * Ho + (Y >> 1)) * Wo + (X >> 1)) * 4 + sub) * (int64_t)C + 4 * c4);
+    if (add) v += reinterpret_cast<const f32x4*>(add)[i];
+    reinterpret_cast<f32x4*>(dx)[i] = v;
+}
+int launch_depth_to_space(const float* t, const float* add, float* dx, int B, int Ho, int Wo, int C, hipStream_t s) {
+    DM_REQUIRE(C % 4 == 0, "depth_to_space: C % 4");
+    const int64_t n4 = (int64_t)B * 4 * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(depth_to_space_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, t, add, dx, Ho, Wo, C, n4);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Adjoint of nearest x2 upsampling: dx (B, H, W, C)[y][x] = sum of the 2x2 block of du (B, 2H, 2W, C) (+ add)
+__global__ void pool2x2_sum_kernel(const float* __restrict__ du, const float* __restrict__ add, float* __restrict__ dx, int H,
+                                   int W, int C, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = (int)(i % (C / 4));
+    int64_t px = i / (C / 4);
+    const int x = (int)(px % W);
+    px /= W;
+    const int y = (int)(px % H);
+    const int64_t b = px / H;
+    const float* q = du + (((b * 2 * H + 2 * y) * 2 * W) + 2 * x) * (int64_t)C + 4 * c4;
+    const int64_t rs = (int64_t)2 * W * C;
+    f32x4 v = *reinterpret_cast<const f32x4*>(q) + *reinterpret_cast<const f32x4*>(q + C) +
+              *reinterpret_cast<const f32x4*>(q + rs) + *reinterpret_cast<const f32x4*>(q + rs + C);
+    if (add) v += reinterpret_cast<const f32x4*>(add)[i];
+    reinterpret_cast<f32x4*>(dx)[i] = v;
+}
+int launch_pool2x2_sum(const float* du, const float* add, float* dx, int B, int H, int W, int C, hipStream_t s) {
+    DM_REQUIRE(C % 4 == 0, "pool2x2_sum: C % 4");
+    const int64_t n4 = (int64_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(pool2x2_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, du, add, dx, H, W, C, n4);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Input gradient of a 1x1 convolution with a handful of outputs whose dY is NCHW (final_conv 64 -> 3):
+// dx[pixel][c] = sum_o w[o][c] * dy[b][o][pixel]
+__global__ void pointwise_small_dgrad_kernel(const float* __restrict__ dy_nchw, const float* __restrict__ w_oc,
+                                             float* __restrict__ dx, int64_t pixels, int C, int Cout, int HW) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pixels * C) return;
+    const int c = (int)(i % C);
+    const int64_t px = i / C, b = px / HW, q = px - b * HW;
+    float s = 0.f;
+    for (int o = 0; o < Cout; ++o) s += w_oc[o * C + c] * dy_nchw[(b * Cout + o) * HW + q];
+    dx[i] = s;
+}
+int launch_pointwise_small_dgrad(const float* dy_nchw, const float* w_oc, float* dx, int64_t pixels, int C, int Cout, int HW,
+                                 hipStream_t s) {
+    const int64_t n = pixels * C;
+    hipLaunchKernelGGL(pointwise_small_dgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy_nchw, w_oc, dx,
+                       pixels, C, Cout, HW);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// nn.Linear weight gradient: dW[o][i] (+)= sum_r dy[r * ldy + o] * act(x[r * ldx + i]);  act_in: 0 none, 1 silu
+__global__ void linear_wgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
+                                    float* __restrict__ dw, int R, int I, int O, int act_in, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int o = blockIdx.y;
+    if (i >= I) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) {
+        float xv = x[(size_t)r * ldx + i];
+        if (act_in == 1) xv = xv / (1.0f + __expf(-xv));
+        s += dy[(size_t)r * ldy + o] * xv;
+    }
+    float* q = dw + (size_t)o * I + i;
+    *q = accumulate ? *q + s : s;
+}
+int launch_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, float* dw, int R, int I, int O, int act_in,
+                        int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(linear_wgrad_kernel, dim3((I + 63) / 64, O), dim3(64), 0, s, dy, ldy, x, ldx, dw, R, I, O, act_in,
+                       accumulate);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// nn.Linear input gradient: dx[r][i] = sum_o dy[r * ldy + o] * W[o][i]   (W as stored: (O, I))
+__global__ void linear_dgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ W, float* __restrict__ dx,
+                                    int ldx, int R, int I, int O) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (i >= I) return;
+    float s = 0.f;
+    for (int o = 0; o < O; ++o) s += dy[(size_t)r * ldy + o] * W[(size_t)o * I + i];
+    dx[(size_t)r * ldx + i] = s;
+}
+int launch_linear_dgrad(const float* dy, int ldy, const float* W, float* dx, int ldx, int R, int I, int O, hipStream_t s) {
+    hipLaunchKernelGGL(linear_dgrad_kernel, dim3((I + 63) / 64, R), dim3(64), 0, s, dy, ldy, W, dx, ldx, R, I, O);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// q_sample (:813-821) and the loss (:864-878): per-sample mean of (out - target)^2 times loss_weight[t], mean over the
+// batch; d(loss)/d(out) in the same pass.  Everything NCHW (the boundary layout).  coef[b] = (sqrt_alphas_cumprod[t_b],
+// sqrt_one_minus_alphas_cumprod[t_b], loss_weight[t_b], 0), gathered on the host exactly as `extract` does.
+// objective: 0 pred_noise (target = noise), 1 pred_x0 (x_start), 2 pred_v (a * noise - b * x_start, :582-586)
+// ---------------------------------------------------------------------------------------
+__global__ void q_sample_kernel(const float* __restrict__ x_start, const float* __restrict__ noise,
+                                const float* __restrict__ coef, float* __restrict__ x, int per_sample, int64_t n) {
+#pragma clang fp contract(off)  // two roundings, like the reference's tensor expression
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* c = coef + 4 * (i / per_sample);
+    x[i] = c[0] * x_start[i] + c[1] * noise[i];
+}
+int launch_q_sample(const float* x_start, const float* noise, const float* coef_dev, float* x, int B, int per_sample,
+                    hipStream_t s) {
+    const int64_t n = (int64_t)B * per_sample;
+    hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x_start, noise, coef_dev, x,
+                       per_sample, n);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// one workgroup per sample: part[b] = loss_weight * mean((out - target)^2); dout = 2 (out - target) * w / (per_sample * B)
+__global__ void mse_loss_kernel(const float* __restrict__ out, const float* __restrict__ x_start, const float* __restrict__ noise,
+                                const float* __restrict__ coef, float* __restrict__ dout, float* __restrict__ part,
+                                int per_sample, int B, int objective) {
+    __shared__ double red[256];
+    const int b = blockIdx.x;
+    const float* c = coef + 4 * b;
+    const float gscale = 2.0f * c[2] / ((float)per_sample * (float)B);
+    double s = 0.0;
+    for (int i = threadIdx.x; i < per_sample; i += 256) {
+        const size_t k = (size_t)b * per_sample + i;
+        float tgt;
+        if (objective == 0) tgt = noise[k];
+        else if (objective == 1) tgt = x_start[k];
+        else tgt = c[0] * noise[k] - c[1] * x_start[k];
+        const float d = out[k] - tgt;
+        s += (double)d * d;
+        dout[k] = d * gscale;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m > 0; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[b] = (float)(red[0] / per_sample) * c[2];
+}
+__global__ void mean_kernel(const float* __restrict__ part, int B, float* __restrict__ loss) {
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) s += part[b];
+    *loss = (float)(s / B);
+}
+int launch_mse_loss(const float* out, const float* x_start, const float* noise, const float* coef_dev, float* dout,
+                    float* part, float* loss, int B, int per_sample, int objective, hipStream_t s) {
+    hipLaunchKernelGGL(mse_loss_kernel, dim3(B), dim3(256), 0, s, out, x_start, noise, coef_dev, dout, part, per_sample, B,
+                       objective);
+    DM_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1), 0, s, part, B, loss);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Optimiser step of the caller of record (Trainer: Adam(lr, betas = (0.9, 0.99)) after clip_grad_norm_(1.0), then
+// ema.update(), DD/denoising_diffusion.py:1006,1180-1190).  One fused pass over a flat parameter tensor:
+//   g = grad * clip;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr * (m / bc1) / (sqrt(v / bc2) + eps)
+//   ema = ema * decay + p * (1 - decay)   (when ema != nullptr)
+// ---------------------------------------------------------------------------------------
+__global__ void sumsq_partial_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ part) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += (double)x[i] * x[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m > 0; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+// total_norm = sqrt(sum); clip coefficient = min(1, max_norm / (total_norm + 1e-6))  (torch.nn.utils.clip_grad_norm_)
+__global__ void clip_coef_kernel(const double* __restrict__ part, int nparts, float max_norm, float* __restrict__ out2) {
+    double s = 0.0;
+    for (int i = 0; i < nparts; ++i) s += part[i];
+    const float norm = (float)sqrt(s);
+    out2[0] = norm;
+    out2[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (norm + 1e-6f)) : 1.0f;
+}
+int launch_grad_norm(const float* grads, int64_t n, double* part_ws /* 1024 doubles */, float max_norm, float* out2,
+                     hipStream_t s) {
+    const int nb = (int)std::min<int64_t>(1024, (n + 255) / 256);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, grads, n, part_ws);
+    DM_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, s, part_ws, nb, max_norm, out2);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+__global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                float* __restrict__ ema, const float* __restrict__ clip2, int64_t n, float lr, float b1, float b2,
+                                float eps, float bc1, float bc2, float ema_decay) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * (clip2 ? clip2[1] : 1.0f);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float pi = p[i] - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    p[i] = pi;
+    if (ema) ema[i] = ema[i] * ema_decay + pi * (1.0f - ema_decay);
+}
+int launch_adam_ema(float* p, const float* g, float* m, float* v, float* ema, const float* clip2, int64_t n, float lr,
+                    float b1, float b2, float eps, int step, float ema_decay, hipStream_t s) {
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+    hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, ema, clip2, n, lr, b1,
+                       b2, eps, bc1, bc2, ema_decay);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dm

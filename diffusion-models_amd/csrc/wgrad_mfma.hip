@@ -1,0 +1,305 @@
+// Weight gradients of the U-Net's convolutions for the training step (DD/denoising_diffusion.py:805-900: autograd's
+// conv2d backward w.r.t. the weight), on v_mfma_f32_32x32x2_f32:
+//     dW[cout][cin][tap] = sum over pixels  dY[pixel][cout] * X[pixel + tap][cin]
+// The reduction runs over PIXELS (B*H*W: 4k .. 260k), the output is small (Cout x Cin x taps), so the roles are the
+// transpose of the forward kernels: couts are the MFMA rows, cins the columns, a pair of neighbouring pixels the K index.
+// Both operands are NHWC, i.e. K-major with the M / N index contiguous -- exactly what the 32x32x2 operand layout wants
+// (lane = (row, k): the 32 lanes of one k read 32 consecutive floats).
+//
+// One workgroup = 4 waves = 64 couts x 64 cins x ALL taps; wave (wo, wc) owns 32 couts x 32 cins and keeps one 32x32
+// accumulator per tap (9 x 16 = 144 registers for a 3x3 kernel): the dY value of a pixel pair is loaded once and meets the
+// nine shifted X values, which all come out of the same LDS window.  Per block of <= 64 pixels (R rows x TW columns of one
+// image) the workgroup stages dY (64 px x 64 couts) and the X window ((R+2) x (TW+2) px x 64 cins) in LDS; two workgroups
+// per CU overlap each other's staging.  The pixel blocks are split over blockIdx.y; every split writes its partial
+// [tap][cout][cin] tile and wgrad_reduce_kernel sums the splits into the OIHW gradient (deterministic, no atomics).
+//
+// Modes: 3x3 / pad 1 (optionally on a nearest-x2 upsampled source: Upsample :48-52), 1x1, and the 2x2 / stride 2 form of
+// Downsample (:54-58; weight index c*4 + p1*2 + p2).  Inputs may be the channel concatenation of two tensors (the up
+// path's torch.cat).  Channel counts must be multiples of 4; everything else (7x7 first conv over the NCHW image,
+// final_conv with 3 outputs) goes through wgrad_naive_kernel.
+#include "conv_device.h"
+
+#include <algorithm>
+#include <cstdio>
+
+namespace dm {
+
+struct WgradParams {
+    const float* in0;
+    const float* in1;
+    const float* dy;
+    float* partial;  // [split][T][Cout][Cin]
+    int C0, C1, Cin, Cout;
+    int B, Ho, Wo;   // size of dY (and of the input the convolution sees, except s2d: input is 2Ho x 2Wo)
+    int up;          // sources are (Ho/2, Wo/2), nearest-upsampled
+    int TW, R;       // pixel block: R rows x TW columns (TW even), R*TW <= 64
+    int tiles_x, tiles_y;
+    int n_blocks, blocks_per_split;
+    int n_ct, n_kt;  // cout / cin tiles of 64
+};
+
+static constexpr int WG_SY = 64;  // floats per staged dY pixel
+static constexpr int WG_SX = 64;  // floats per staged X pixel
+
+template <int MODE>
+struct WgradMode;
+template <>
+struct WgradMode<0> { static constexpr int T = 9, S = 1; };
+template <>
+struct WgradMode<1> { static constexpr int T = 1, S = 1; };
+template <>
+struct WgradMode<2> { static constexpr int T = 4, S = 2; };
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p) {
+    constexpr int T = WgradMode<MODE>::T;
+    constexpr int S = WgradMode<MODE>::S;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sY = smem;                // [64 px][64 couts]
+    float* sX = smem + 64 * WG_SY;   // [WH * WW px][64 cins]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, k = lane >> 5;
+    const int ct = blockIdx.x % p.n_ct, kt = blockIdx.x / p.n_ct;
+    const int split = blockIdx.y;
+    const int TW = p.TW, R = p.R;
+    const int WW = MODE == 0 ? TW + 2 : S * TW;
+    const int WH = MODE == 0 ? R + 2 : S * R;
+    const int Hs = MODE == 2 ? 2 * p.Ho : (p.up ? p.Ho / 2 : p.Ho);  // source tensor size
+    const int Ws = MODE == 2 ? 2 * p.Wo : (p.up ? p.Wo / 2 : p.Wo);
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    const int blk0 = split * p.blocks_per_split;
+    const int blk1 = min(blk0 + p.blocks_per_split, p.n_blocks);
+    for (int blk = blk0; blk < blk1; ++blk) {
+        const int per_img = p.tiles_x * p.tiles_y;
+        const int b = blk / per_img, rem = blk - b * per_img;
+        const int y0 = (rem / p.tiles_x) * R, x0 = (rem % p.tiles_x) * TW;
+        __syncthreads();  // the previous block's MFMA loop is done with the tiles
+        // ---- stage dY: 64 pixels x 16 float4
+        for (int idx = tid; idx < 64 * 16; idx += 256) {
+            const int px = idx >> 4, q = idx & 15;
+            const int r = px / TW, c = px - r * TW;
+            const int y = y0 + r, x = x0 + c, co = ct * 64 + 4 * q;
+            f32x4 v = make_f32x4(0.f, 0.f, 0.f, 0.f);
+            if (r < R && y < p.Ho && x < p.Wo && co < p.Cout)
+                v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)(b * p.Ho + y) * p.Wo + x) * p.Cout + co);
+            *reinterpret_cast<f32x4*>(sY + px * WG_SY + 4 * q) = v;
+        }
+        // ---- stage the X window
+        for (int idx = tid; idx < WH * WW * 16; idx += 256) {
+            const int wp = idx >> 4, q = idx & 15;
+            const int wy = wp / WW, wx = wp - wy * WW;
+            int sy, sx;
+            bool ok;
+            if (MODE == 0) {
+                const int uy = y0 - 1 + wy, ux = x0 - 1 + wx;
+                ok = uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo;
+                sy = p.up ? uy >> 1 : uy;
+                sx = p.up ? ux >> 1 : ux;
+            } else {
+                sy = S * y0 + wy;
+                sx = S * x0 + wx;
+                ok = sy < Hs && sx < Ws;
+            }
+            const int ci = kt * 64 + 4 * q;
+            f32x4 v = make_f32x4(0.f, 0.f, 0.f, 0.f);
+            if (ok && ci < p.Cin) {
+                const size_t spx = (size_t)(b * Hs + sy) * Ws + sx;
+                v = ci < p.C0 ? *reinterpret_cast<const f32x4*>(p.in0 + spx * p.C0 + ci)
+                              : *reinterpret_cast<const f32x4*>(p.in1 + spx * p.C1 + (ci - p.C0));
+            }
+            *reinterpret_cast<f32x4*>(sX + wp * WG_SX + 4 * q) = v;
+        }
+        __syncthreads();
+        // ---- MFMA: K = pixel pairs (2 cp + k) of every row of the block
+        const float* ya = sY + wo * 32 + l31;
+        const float* xb = sX + wc * 32 + l31;
+        for (int r = 0; r < R; ++r) {
+            for (int cp = 0; cp < TW / 2; ++cp) {
+                const int c = 2 * cp + k;
+                const float a = ya[(r * TW + c) * WG_SY];
+                if (MODE == 0) {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const float bv = xb[((r + ky) * WW + c + kx) * WG_SX];
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ky * 3 + kx], 0, 0, 0);
+                        }
+                } else if (MODE == 1) {
+                    const float bv = xb[(r * WW + c) * WG_SX];
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[0], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int p1 = 0; p1 < 2; ++p1)
+#pragma unroll
+                        for (int p2 = 0; p2 < 2; ++p2) {
+                            const float bv = xb[((2 * r + p1) * WW + 2 * c + p2) * WG_SX];
+                            acc[p1 * 2 + p2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[p1 * 2 + p2], 0, 0, 0);
+                        }
+                }
+            }
+        }
+    }
+    // ---- partial tile: D[i][j], j = lane % 32 (cin), i = 8 (v / 4) + 4 (lane / 32) + v % 4 (cout)
+    const int ci = kt * 64 + wc * 32 + l31;
+    if (ci < p.Cin) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int co = ct * 64 + wo * 32 + 8 * (v >> 2) + 4 * k + (v & 3);
+                if (co < p.Cout) p.partial[(((size_t)split * T + t) * p.Cout + co) * p.Cin + ci] = acc[t][v];
+            }
+    }
+}
+
+// out[(o * Cin + c) * T + t] (= | +=) scale * sum_split partial[split][t][o][c]: OIHW for 3x3 / 1x1, and the
+// (Cout, 4 C) layout of the Downsample weight (index c*4 + p1*2 + p2) for T = 4.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int T, int64_t oc, float* __restrict__ out,
+                                    int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= oc) return;
+    for (int t = 0; t < T; ++t) {
+        float s = 0.f;
+        for (int sp = 0; sp < splits; ++sp) s += partial[((int64_t)sp * T + t) * oc + i];
+        float* o = out + i * T + t;
+        *o = accumulate ? *o + s : s;
+    }
+}
+
+size_t wgrad_ws_floats(int B, int Ho, int Wo, int Cout, int Cin, int T, int* splits_out) {
+    int TW = std::min((Wo + 1) & ~1, 64);
+    int R = std::max(1, std::min(64 / TW, Ho));
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + R - 1) / R;
+    const int n_blocks = B * tiles_x * tiles_y;
+    const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
+    int splits = std::max(1, std::min(n_blocks, (512 + tiles - 1) / tiles));
+    const int bps = (n_blocks + splits - 1) / splits;
+    splits = (n_blocks + bps - 1) / bps;
+    if (splits_out) *splits_out = splits;
+    return (size_t)splits * T * Cout * Cin;
+}
+
+// mode: 0 3x3 pad 1 (up: nearest x2 source), 1 1x1, 2 2x2 stride 2 (Ho, Wo = OUTPUT size; the source is 2Ho x 2Wo)
+int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float* dy, int Cout, int B, int Ho, int Wo,
+                 int mode, int up, float* ws, float* dw, int accumulate, hipStream_t s) {
+    DM_REQUIRE(C0 % 4 == 0 && C1 % 4 == 0 && Cout % 4 == 0 && C0 > 0, "wgrad: channel counts must be multiples of 4");
+    DM_REQUIRE(mode >= 0 && mode <= 2 && (!up || (mode == 0 && Ho % 2 == 0 && Wo % 2 == 0)), "wgrad: mode");
+    DM_REQUIRE((size_t)B * Ho * Wo * (size_t)std::max(Cout, C0 + C1) * (mode == 2 ? 4 : 1) < (1ull << 40), "wgrad: size");
+    WgradParams p{};
+    p.in0 = in0; p.in1 = C1 ? in1 : in0; p.dy = dy; p.partial = ws;
+    p.C0 = C0; p.C1 = C1; p.Cin = C0 + C1; p.Cout = Cout;
+    p.B = B; p.Ho = Ho; p.Wo = Wo; p.up = up;
+    p.TW = std::min((Wo + 1) & ~1, 64);
+    p.R = std::max(1, std::min(64 / p.TW, Ho));
+    p.tiles_x = (Wo + p.TW - 1) / p.TW;
+    p.tiles_y = (Ho + p.R - 1) / p.R;
+    p.n_blocks = B * p.tiles_x * p.tiles_y;
+    p.n_ct = (Cout + 63) / 64;
+    p.n_kt = (p.Cin + 63) / 64;
+    const int T = mode == 0 ? 9 : (mode == 1 ? 1 : 4);
+    int splits = 1;
+    (void)wgrad_ws_floats(B, Ho, Wo, Cout, p.Cin, T, &splits);
+    p.blocks_per_split = (p.n_blocks + splits - 1) / splits;
+    const int WW = mode == 0 ? p.TW + 2 : (mode == 2 ? 2 * p.TW : p.TW);
+    const int WH = mode == 0 ? p.R + 2 : (mode == 2 ? 2 * p.R : p.R);
+    const size_t lds = (size_t)(64 * WG_SY + WH * WW * WG_SX) * sizeof(float);
+    DM_REQUIRE(lds <= 160 * 1024, "wgrad: LDS");
+    const dim3 grid(p.n_ct * p.n_kt, splits);
+    const bool timed = prof::enabled();
+    if (timed && prof::begin("wgrad_mfma_kernel", 2.0 * T * p.Cin * Cout * (double)B * Ho * Wo,
+                             4.0 * ((double)B * Ho * Wo * (p.Cin * (mode == 2 ? 4 : 1) + Cout) + (double)T * p.Cin * Cout), s))
+        return 1;
+    static LdsOptIn f0, f1, f2;
+    if (mode == 0) {
+        if (lds_opt_in(f0, reinterpret_cast<const void*>(wgrad_mfma_kernel<0>), 1)) return 1;
+        hipLaunchKernelGGL(wgrad_mfma_kernel<0>, grid, dim3(256), lds, s, p);
+    } else if (mode == 1) {
+        if (lds_opt_in(f1, reinterpret_cast<const void*>(wgrad_mfma_kernel<1>), 1)) return 1;
+        hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), lds, s, p);
+    } else {
+        if (lds_opt_in(f2, reinterpret_cast<const void*>(wgrad_mfma_kernel<2>), 1)) return 1;
+        hipLaunchKernelGGL(wgrad_mfma_kernel<2>, grid, dim3(256), lds, s, p);
+    }
+    DM_CHECK_HIP(hipGetLastError());
+    if (timed && prof::end(s)) return 1;
+    const int64_t oc = (int64_t)Cout * p.Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((oc + 255) / 256)), dim3(256), 0, s, ws, splits, T, oc, dw,
+                       accumulate);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- general (slow) form for the two thin convolutions of the U-Net: init_conv (7x7 over the NCHW image, 3-8 input
+// channels) and final_conv (1x1, 3 outputs, NCHW gradient).  One thread per weight element, pixels split over blockIdx.y.
+struct WgradNaive {
+    const float* x;
+    const float* dy;
+    float* partial;  // [split][n_out]
+    int Cin, Cout, KH, KW, pad;
+    int B, H, W;     // input == output size (stride 1, "same" padding)
+    int64_t xs_b, xs_c, xs_p;     // strides of x: batch, channel, pixel
+    int64_t dys_b, dys_c, dys_p;  // strides of dy
+    int rows_per_split;           // image rows (b * H + y) per split
+};
+
+__global__ void wgrad_naive_kernel(const WgradNaive p) {
+    const int n_out = p.Cout * p.Cin * p.KH * p.KW;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const int kx = i % p.KW, ky = (i / p.KW) % p.KH, c = (i / (p.KW * p.KH)) % p.Cin, o = i / (p.KW * p.KH * p.Cin);
+    const int row0 = blockIdx.y * p.rows_per_split, row1 = min(row0 + p.rows_per_split, p.B * p.H);
+    float s = 0.f;
+    for (int row = row0; row < row1; ++row) {
+        const int b = row / p.H, y = row - b * p.H;
+        const int sy = y + ky - p.pad;
+        if (sy < 0 || sy >= p.H) continue;
+        const float* xr = p.x + b * p.xs_b + c * p.xs_c + (int64_t)sy * p.W * p.xs_p;
+        const float* dr = p.dy + b * p.dys_b + o * p.dys_c + (int64_t)y * p.W * p.dys_p;
+        const int xlo = max(0, p.pad - kx), xhi = min(p.W, p.W + p.pad - kx);
+        for (int x = xlo; x < xhi; ++x) s += dr[x * p.dys_p] * xr[(x + kx - p.pad) * p.xs_p];
+    }
+    p.partial[(size_t)blockIdx.y * n_out + i] = s;
+}
+
+size_t wgrad_naive_ws_floats(int B, int H, int Cout, int Cin, int KH, int KW, int* splits_out) {
+    const int rows = B * H;
+    int splits = std::min(rows, 256);
+    const int rps = (rows + splits - 1) / splits;
+    splits = (rows + rps - 1) / rps;
+    if (splits_out) *splits_out = splits;
+    return (size_t)splits * Cout * Cin * KH * KW;
+}
+
+// x: NCHW when x_nchw else NHWC; dy likewise
+int launch_wgrad_naive(const float* x, int x_nchw, const float* dy, int dy_nchw, int Cin, int Cout, int KH, int KW, int pad,
+                       int B, int H, int W, float* ws, float* dw, int accumulate, hipStream_t s) {
+    DM_REQUIRE(KH == 2 * pad + 1 && KW == 2 * pad + 1, "naive wgrad: same-size convolutions only");
+    WgradNaive p{};
+    p.x = x; p.dy = dy; p.partial = ws;
+    p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.pad = pad; p.B = B; p.H = H; p.W = W;
+    const int64_t HW = (int64_t)H * W;
+    if (x_nchw) { p.xs_b = Cin * HW; p.xs_c = HW; p.xs_p = 1; } else { p.xs_b = HW * Cin; p.xs_c = 1; p.xs_p = Cin; }
+    if (dy_nchw) { p.dys_b = Cout * HW; p.dys_c = HW; p.dys_p = 1; } else { p.dys_b = HW * Cout; p.dys_c = 1; p.dys_p = Cout; }
+    int splits = 1;
+    (void)wgrad_naive_ws_floats(B, H, Cout, Cin, KH, KW, &splits);
+    p.rows_per_split = (B * H + splits - 1) / splits;
+    const int n_out = Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(wgrad_naive_kernel, dim3((n_out + 127) / 128, splits), dim3(128), 0, s, p);
+    DM_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, ws, splits, 1, (int64_t)n_out, dw,
+                       accumulate);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dm

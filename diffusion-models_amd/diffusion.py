@@ -61,7 +61,12 @@ class DenoisingDiffusion:
         ddim_sampling_eta=0.0,
         auto_normalize=True,
         use_graph=True,
-        **_training_only,  # offset_noise_strength, min_snr_*, immiscible, ddpm, hybrid_loss: training half
+        offset_noise_strength=0.0,
+        min_snr_loss_weight=False,
+        min_snr_gamma=5,
+        immiscible=False,
+        ddpm=True,
+        hybrid_loss=False,
     ):
         assert not (type(self) == DenoisingDiffusion and model.channels != model.out_dim)
         assert not getattr(model, "random_or_learned_sinusoidal_cond", False)
@@ -83,6 +88,18 @@ class DenoisingDiffusion:
         assert self.sampling_timesteps <= self.num_timesteps
         self.is_ddim_sampling = self.sampling_timesteps < self.num_timesteps
         self.ddim_sampling_eta = ddim_sampling_eta
+        if not ddpm:  # loss weight from the signal-to-noise ratio (:535-549); ddpm=True keeps ones (:532-533)
+            ac = sched["alphas_cumprod"].double()
+            snr = ac / (1 - ac)
+            clipped = snr.clone()
+            if min_snr_loss_weight:
+                clipped.clamp_(max=min_snr_gamma)
+            lw = {"pred_noise": clipped / snr, "pred_x0": clipped, "pred_v": clipped / (snr + 1)}[objective]
+            sched["loss_weight"] = lw.to(torch.float32)
+        # training options the HIP training step does not implement are refused where they would change the result
+        assert not immiscible and not hybrid_loss, "immiscible noise assignment / hybrid loss are not on the HIP path"
+        self.offset_noise_strength = offset_noise_strength
+        self.immiscible, self.hybrid_loss = immiscible, hybrid_loss
         self._sched = sched  # fp32 CPU tensors; the per-step scalars are derived from them on the host
         for k, v in sched.items():
             setattr(self, k, v)
@@ -191,6 +208,66 @@ class DenoisingDiffusion:
             return out
         ret = all_steps.permute(1, 0, 2, 3, 4).contiguous()  # (B, n_steps+1, C, H, W) like torch.stack(imgs, dim=1)
         return self.unnormalize(ret)
+
+    # -- training half (denoising_diffusion.py:805-900): loss and gradients in libdm_hip.so --------------------------
+    def train(self, mode: bool = True):
+        self.model.train(mode)
+        return self
+
+    def _tcoef(self, t: torch.Tensor) -> torch.Tensor:
+        """(B, 4): what `extract` gathers for q_sample / predict_v / the loss weight at each sample's timestep."""
+        t = t.detach().to("cpu", torch.long)
+        s = self._sched
+        return torch.stack([s["sqrt_alphas_cumprod"][t], s["sqrt_one_minus_alphas_cumprod"][t], s["loss_weight"][t],
+                            torch.zeros(t.shape[0])], dim=1).to(torch.float32).contiguous()
+
+    def q_sample(self, x_start, t, noise=None):
+        """:813-821 (immiscible noise assignment off, the reference default)."""
+        x_start = x_start.to(self.device, torch.float32).contiguous()
+        noise = (noise.to(self.device, torch.float32).contiguous() if noise is not None
+                 else self._randn(x_start.shape, _default_seed(), 0))
+        coef = self._tcoef(t)
+        out = torch.empty_like(x_start)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.dm_op_q_sample(_lib.ptr(x_start), _lib.ptr(noise), C.cast(coef.data_ptr(), C.POINTER(C.c_float)),
+                                            _lib.ptr(out), x_start.shape[0], x_start[0].numel(), stream))
+        return out
+
+    def p_losses(self, x_start, t, noise=None, offset_noise_strength=None, *, return_model_out=False):
+        """:823-889: returns the loss (0-dim CPU tensor); the parameter gradients stay on the model
+        (``self.model.grad(name)`` / ``.grads()``) -- loss and backward are one call of the library, there is no autograd
+        graph to keep.  Offset noise, the hybrid (KL) loss and self-conditioning are not on this path."""
+        if offset_noise_strength is None:
+            offset_noise_strength = self.offset_noise_strength
+        assert not offset_noise_strength, "offset noise is not on the HIP training path"
+        assert not self.self_condition, "self-conditioning is not on the HIP training path"
+        if not getattr(self.model, "_training", False):
+            self.model.train()
+        x_start = x_start.to(self.device, torch.float32).contiguous()
+        b, c, h, w = x_start.shape
+        noise = (noise.to(self.device, torch.float32).contiguous() if noise is not None
+                 else self._randn(x_start.shape, _default_seed(), 0))
+        t_cpu = t.detach().to("cpu", torch.long).contiguous()
+        coef = self._tcoef(t_cpu)
+        loss = C.c_float(0.0)
+        out = torch.empty_like(x_start) if return_model_out else None
+        t_arr = (C.c_int64 * b)(*[int(v) for v in t_cpu.tolist()])
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.dm_unet_loss_backward(
+            self.model._handle, _lib.ptr(x_start), C.cast(t_arr, C.POINTER(C.c_int64)),
+            C.cast(coef.data_ptr(), C.POINTER(C.c_float)), _lib.ptr(noise), self._objective_id, C.byref(loss), _lib.ptr(out),
+            b, h, w, stream))
+        val = torch.tensor(loss.value, dtype=torch.float32)
+        return (val, out) if return_model_out else val
+
+    def forward(self, img, *args, **kwargs):
+        """:892-899: random timesteps, normalise, p_losses."""
+        b, c, h, w = img.shape
+        assert (h, w) == tuple(self.image_size), f"height and width of image must be {self.image_size}"
+        t = torch.randint(0, self.num_timesteps, (b,)).long()
+        return self.p_losses(self.normalize(img.to(self.device, torch.float32)), t, *args, **kwargs)
+
+    __call__ = forward
 
     @torch.inference_mode()
     def p_sample_loop(self, shape, return_all_timesteps=False, *, noise=None, seed=None, max_steps=None, text_emb=None,

@@ -151,6 +151,29 @@ class Unet:
         """How many times a denoise-step graph was captured on this handle (one per sampled shape)."""
         return int(self._lib.dm_unet_graph_captures(self._handle))
 
+    # -- training (SURVEY.md 8(f) rank 4) ----------------------------------------------------
+    def train(self, mode: bool = True):
+        """``model.train()``: allocate the gradient buffers and pack the input-gradient convolutions (once)."""
+        if mode:
+            if not self._loaded:
+                raise RuntimeError("load_state_dict() must be called before train()")
+            if self.text_condition or self.self_condition or self.cfg.cond_channels:
+                raise NotImplementedError("the HIP training step covers the unconditional U-Net")
+            _lib.check(self._lib.dm_unet_train_enable(self._handle))
+            self._training = True
+        return self
+
+    def grad(self, name: str) -> torch.Tensor:
+        """Gradient of one parameter (reference name and shape) left by the last loss / backward call."""
+        shape = dict(self.param_spec())[name]
+        out = torch.empty(tuple(shape), device=self.device, dtype=torch.float32)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.dm_unet_get_grad(self._handle, name.encode(), _lib.ptr(out), stream))
+        return out
+
+    def grads(self) -> Dict[str, torch.Tensor]:
+        return {name: self.grad(name) for name, _ in self.param_spec()}
+
     # -- forward ---------------------------------------------------------------------------
     def _ctx(self, text_emb: Optional[torch.Tensor], batch: int):
         if text_emb is None or not self.text_condition:

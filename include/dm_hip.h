@@ -293,6 +293,32 @@ int dm_op_global_avgpool(const float* in_nhwc, float* out, int B, int HW, int C,
 /* nn.Linear: y (R, O) = x (R, I) W^T + b; weight (O, I) and bias on the device */
 int dm_op_linear(const float* x, const float* weight, const float* bias, float* y, int R, int I, int O, void* stream);
 
+/* ---- training step: DenoisingDiffusion.forward / p_losses, DD/denoising_diffusion.py:805-900, and
+ *      the backward pass of the same U-Net (what `accelerator.backward(loss)` computes in Trainer.train, :1162-1176).
+ *      Unconditional U-Net (no text / image condition, no self-conditioning), dropout 0, loss_weight from the caller.
+ *      Gradients are kept on the handle in the reference's parameter layouts (state_dict() shapes). ------------------- */
+
+/* allocate the gradient buffers and pack the input-gradient convolutions (the forward kernels run on 180-degree rotated,
+ * Cin<->Cout transposed weights); dm_unet_refresh re-packs them together with the forward weights afterwards */
+int dm_unet_train_enable(dm_unet* u);
+/* total floats of the flat gradient buffer (parameters in state-dict order, each padded to a multiple of 4), or -1 */
+int64_t dm_unet_grad_floats(dm_unet* u);
+/* copy the gradient of one parameter (names as in dm_unet_set_param) into a DEVICE buffer of the parameter's size */
+int dm_unet_get_grad(dm_unet* u, const char* name, float* out_dev, void* stream);
+/* One p_losses call (:823-889) + backward:
+ *   x = q_sample(x_start, t, noise) (:813-821);  out = Unet(x, t);  target per `objective` (DM_OBJ_*, :864-872);
+ *   loss = mean_b( loss_weight[t_b] * mean((out - target)^2) ) (:874-878, :889);  every parameter gradient of the loss.
+ * x_start, noise: (B, C, H, W) device, x_start already normalised to [-1, 1];  t_host: (B) timesteps;
+ * coef_host: (B, 4) = sqrt_alphas_cumprod[t_b], sqrt_one_minus_alphas_cumprod[t_b], loss_weight[t_b], 0 -- the values
+ * `extract` gathers (:394-397);  loss_out_host receives the scalar loss;  model_out (optional, device) the U-Net output.
+ * The call synchronises the stream. */
+int dm_unet_loss_backward(dm_unet* u, const float* x_start, const int64_t* t_host, const float* coef_host,
+                          const float* noise, int objective, float* loss_out_host, float* model_out, int B, int H, int W,
+                          void* stream);
+/* q_sample (:813-821) on its own: out = coef[b][0] * x_start + coef[b][1] * noise, coef_host (B, 4) as above */
+int dm_op_q_sample(const float* x_start, const float* noise, const float* coef_host, float* out, int B, int per_sample,
+                   void* stream);
+
 /* ---- measurement (bench.py's roofline leg; not part of the reference surface) -------------
  * While enabled, every convolution / fused-attention launch is bracketed by two HIP events recorded on
  * the stream the kernel is launched on.  Do not combine with use_graph.  dm_profile_enable(1) first
