@@ -31,6 +31,8 @@ EXPORTS = (
     "dm_conv_create", "dm_conv_destroy", "dm_conv_forward", "dm_op_pool2d", "dm_op_resize_bilinear",
     "dm_op_copy_channels_nhwc", "dm_op_global_avgpool", "dm_op_linear",
     "dm_unet_train_enable", "dm_unet_grad_floats", "dm_unet_get_grad", "dm_unet_loss_backward", "dm_op_q_sample",
+    "dm_op_conv2d_bwd", "dm_op_downsample_bwd", "dm_op_block_bwd", "dm_op_rmsnorm_bwd", "dm_op_linear_attention_bwd",
+    "dm_op_attention_bwd",
     "dm_profile_enable", "dm_profile_read",
 )
 
@@ -146,6 +148,12 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_unet_loss_backward.argtypes = [vp, fp, C.POINTER(i64), C.POINTER(C.c_float), fp, i32, C.POINTER(C.c_float), fp,
                                           i32, i32, i32, vp]
     lib.dm_op_q_sample.argtypes = [fp, fp, C.POINTER(C.c_float), fp, i32, i32, vp]
+    lib.dm_op_conv2d_bwd.argtypes = [fp, i32, fp, i32, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.dm_op_downsample_bwd.argtypes = [fp, i32, fp, fp, fp, fp, fp, i32, i32, i32, i32, vp]
+    lib.dm_op_block_bwd.argtypes = [fp, i32] + [fp] * 12 + [i32, i32, i32, i32, vp]
+    lib.dm_op_rmsnorm_bwd.argtypes = [fp, fp, fp, fp, fp, i32, i32, i32, i32, vp]
+    lib.dm_op_linear_attention_bwd.argtypes = [fp] * 15 + [i32] * 6 + [vp]
+    lib.dm_op_attention_bwd.argtypes = [fp] * 13 + [i32] * 6 + [vp]
     lib.dm_profile_enable.argtypes = [i32]
     lib.dm_profile_read.argtypes = [C.POINTER(ProfileRow), i32, C.POINTER(i32)]
 

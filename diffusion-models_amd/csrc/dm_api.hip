@@ -80,6 +80,24 @@ struct HostTensor {
     }
 };
 
+// Recipe of one packed weight buffer (recorded while the host packs it): which parameter it comes from and which packer
+// made it, so that the training loop can re-pack it on the DEVICE from the flat master parameters (pack_kernels.hip).
+struct PackSrc {
+    int kind = 0;  // 0: the parameter as stored; 1: rotated / transposed rows [c_lo, c_lo + c_n) of a (sCout, sCin, sK, sK)
+                   // parameter (input-gradient convolution); 2: Downsample input-gradient transpose of a (sCout, 4 sCin) parameter
+    std::string wname, bname;
+    int sCout = 0, sCin = 0, sK = 0, c_lo = 0, c_n = 0;
+};
+enum PackKind { PK_RAW_W, PK_RAW_B, PK_RAW_NAME, PK_DIRECT, PK_FOLD, PK_WINO, PK_WINO4, PK_UPWINO, PK_PW, PK_PW_S2D, PK_INIT7 };
+struct PackOp {
+    int kind;
+    float* dst;
+    size_t n;          // floats of dst written by this op
+    int Cout, C0, C1, KH, KW;
+    PackSrc src;
+    std::string name;  // PK_RAW_NAME: the parameter copied to dst
+};
+
 // Owner of every repacked weight buffer of a handle.  The first build allocates one buffer per upload; a REFRESH
 // (dm_unet_refresh: new values for parameters of the same shapes) replays the same upload sequence into the same
 // buffers, so every device pointer -- and with them a captured step graph -- stays valid.
@@ -88,6 +106,14 @@ struct DeviceOwner {
     std::vector<size_t> sizes;
     bool refreshing = false;
     size_t cursor = 0;
+    std::vector<PackOp>* rec = nullptr;  // when set, make_conv / up1 append the recipe of every buffer they upload
+    PackSrc src;                         // the source of the convolution being packed (set by the caller of make_conv)
+    void record(int kind, float* dst, size_t n, int Cout, int C0, int C1, int KH, int KW) {
+        if (rec && !refreshing) rec->push_back(PackOp{kind, dst, n, Cout, C0, C1, KH, KW, src, std::string()});
+    }
+    void record_raw(const std::string& name, float* dst, size_t n) {
+        if (rec && !refreshing) rec->push_back(PackOp{PK_RAW_NAME, dst, n, 0, 0, 0, 0, 0, PackSrc(), name});
+    }
     ~DeviceOwner() {
         for (void* p : ptrs) (void)hipFree(p);
     }
@@ -237,6 +263,8 @@ struct dm_unet {
     bool finalized = false;
     bool poisoned = false;  // a refresh failed half-way: device weights are a mix of old and new values
     dm::TrainState* train = nullptr;  // dm_unet_train_enable: gradient buffers, dgrad weights, training workspace
+    std::vector<dm::PackOp> pack_ops;  // recipe of every buffer the convolutions / norms read (device-side re-packing)
+    bool infer_stale = false;          // device-side optimiser steps since the fused inference-only packs were built
     DeviceOwner own;
     // layers
     ConvLayer init_conv, final_conv;
@@ -395,47 +423,58 @@ static int make_conv(DeviceOwner& own, ConvLayer& L, const float* oihw, const fl
         conv_pack_weights(oihw, packed.data(), Cout, C0, C1, KH, KW);
     }
     if (own.upload(packed.data(), packed.size(), &L.w)) return 1;
+    own.record(L.fold ? PK_FOLD : PK_DIRECT, L.w, packed.size(), Cout, C0, C1, KH, KW);
     L.ww = nullptr;
     if (wino_eligible(Cout, C0, C1, KH, KW, stride, pad, up)) {
         std::vector<float> wp(wino_packed_floats(Cout, C0, C1));
         wino_pack_weights(oihw, wp.data(), Cout, C0, C1);
         if (own.upload(wp.data(), wp.size(), &L.ww)) return 1;
+        own.record(PK_WINO, L.ww, wp.size(), Cout, C0, C1, KH, KW);
     }
     L.ww4 = nullptr;
     if (wino4_eligible(Cout, C0, C1, KH, KW, stride, pad, up)) {
         std::vector<float> wp(wino4_packed_floats(Cout, C0, C1));
         wino4_pack_weights(oihw, wp.data(), Cout, C0, C1);
         if (own.upload(wp.data(), wp.size(), &L.ww4)) return 1;
+        own.record(PK_WINO4, L.ww4, wp.size(), Cout, C0, C1, KH, KW);
     }
     L.wwu = nullptr;
     if (upwino_eligible(Cout, C0, C1, KH, KW, stride, pad, up)) {
         std::vector<float> wp(upwino_packed_floats(Cout, C0, C1));
         upwino_pack_weights(oihw, wp.data(), Cout, C0, C1);
         if (own.upload(wp.data(), wp.size(), &L.wwu)) return 1;
+        own.record(PK_UPWINO, L.wwu, wp.size(), Cout, C0, C1, KH, KW);
     }
     L.wpw = nullptr;
     if (pw_eligible(Cout, C0, C1, KH, KW, stride, pad, up)) {
         std::vector<float> wp(pw_packed_floats(Cout, C0, C1));
         pw_pack_weights(oihw, wp.data(), Cout, C0, C1);
         if (own.upload(wp.data(), wp.size(), &L.wpw)) return 1;
+        own.record(PK_PW, L.wpw, wp.size(), Cout, C0, C1, KH, KW);
     }
     if (pw_s2d_eligible(Cout, C0, C1, KH, KW, stride, pad, up)) {
         std::vector<float> wp((size_t)4 * C0 * Cout);
         pw_pack_weights_s2d(oihw, wp.data(), Cout, C0);
         if (own.upload(wp.data(), wp.size(), &L.wpw)) return 1;
+        own.record(PK_PW_S2D, L.wpw, wp.size(), Cout, C0, C1, KH, KW);
     }
     L.wi7 = nullptr;
     if (init7_eligible(Cout, C0, C1, KH, KW, stride, pad, up)) {
         std::vector<float> wp(init7_packed_floats(C0));
         init7_pack_weights(oihw, wp.data(), C0);
         if (own.upload(wp.data(), wp.size(), &L.wi7)) return 1;
+        own.record(PK_INIT7, L.wi7, wp.size(), Cout, C0, C1, KH, KW);
     }
     L.wraw = nullptr;
-    if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && !up && Cout <= 4 && C1 == 0 && C0 % 4 == 0 &&
-        own.upload(oihw, (size_t)Cout * C0, &L.wraw))
-        return 1;
+    if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && !up && Cout <= 4 && C1 == 0 && C0 % 4 == 0) {
+        if (own.upload(oihw, (size_t)Cout * C0, &L.wraw)) return 1;
+        own.record(PK_RAW_W, L.wraw, (size_t)Cout * C0, Cout, C0, C1, KH, KW);
+    }
     L.bias = nullptr;
-    if (bias && own.upload(bias, Cout, &L.bias)) return 1;
+    if (bias) {
+        if (own.upload(bias, Cout, &L.bias)) return 1;
+        own.record(PK_RAW_B, L.bias, Cout, Cout, C0, C1, KH, KW);
+    }
     return 0;
 }
 
@@ -443,7 +482,15 @@ static const HostTensor& P(dm_unet* u, const std::string& n) { return u->params.
 
 static int up1(dm_unet* u, const std::string& n, float** out) {
     const HostTensor& t = P(u, n);
-    return u->own.upload(t.data.data(), t.data.size(), out);
+    if (u->own.upload(t.data.data(), t.data.size(), out)) return 1;
+    u->own.record_raw(n, *out, t.data.size());
+    return 0;
+}
+// the parameters make_conv is about to pack (for the device-side re-packing recipe)
+static void conv_src(dm_unet* u, const std::string& wname, const std::string& bname) {
+    u->own.src = PackSrc();
+    u->own.src.wname = wname;
+    u->own.src.bname = bname;
 }
 
 // One weight group = everything packed from the parameters under one name prefix.  First build: run `build` and
@@ -486,13 +533,16 @@ static int build_resnet(dm_unet* u, ResBlock& R, const std::string& p, int C0, i
     if (!u->own.refreshing) u->resnets.emplace_back(p, &R);
     return weight_group(u, p, [&]() -> int {
         int din = C0 + C1;
+        conv_src(u, p + ".block1.proj.weight", p + ".block1.proj.bias");
         if (make_conv(u->own, R.c1, P(u, p + ".block1.proj.weight").data.data(), P(u, p + ".block1.proj.bias").data.data(),
                       dout, C0, C1, 3, 3, 1, 1, false)) return 1;
+        conv_src(u, p + ".block2.proj.weight", p + ".block2.proj.bias");
         if (make_conv(u->own, R.c2, P(u, p + ".block2.proj.weight").data.data(), P(u, p + ".block2.proj.bias").data.data(),
                       dout, dout, 0, 3, 3, 1, 1, false)) return 1;
         if (up1(u, p + ".block1.norm.g", &R.g1) || up1(u, p + ".block2.norm.g", &R.g2)) return 1;
         R.has_res = din != dout;
         if (R.has_res) {
+            conv_src(u, p + ".res_conv.weight", p + ".res_conv.bias");
             if (make_conv(u->own, R.res, P(u, p + ".res_conv.weight").data.data(), P(u, p + ".res_conv.bias").data.data(),
                           dout, C0, C1, 1, 1, 1, 0, false)) return 1;
         }
@@ -514,7 +564,17 @@ static int build_scale_shift(dm_unet* u) {
         ssw.insert(ssw.end(), mw.data.begin(), mw.data.end());
         ssb.insert(ssb.end(), mb.data.begin(), mb.data.end());
     }
-    return u->own.upload(ssw.data(), ssw.size(), &u->ss_w) || u->own.upload(ssb.data(), ssb.size(), &u->ss_b);
+    if (u->own.upload(ssw.data(), ssw.size(), &u->ss_w) || u->own.upload(ssb.data(), ssb.size(), &u->ss_b)) return 1;
+    size_t ow = 0, ob = 0;  // recipe: every ResnetBlock.mlp is a row block of the concatenated matrix
+    for (auto& pr : u->resnets) {
+        const HostTensor& mw = P(u, pr.first + ".mlp.1.weight");
+        const HostTensor& mb = P(u, pr.first + ".mlp.1.bias");
+        u->own.record_raw(pr.first + ".mlp.1.weight", u->ss_w + ow, mw.data.size());
+        u->own.record_raw(pr.first + ".mlp.1.bias", u->ss_b + ob, mb.data.size());
+        ow += mw.data.size();
+        ob += mb.data.size();
+    }
+    return 0;
 }
 
 static int build_attn_body(dm_unet* u, AttnLayer& A, const std::string& p, int dim, bool full) {
@@ -522,9 +582,11 @@ static int build_attn_body(dm_unet* u, AttnLayer& A, const std::string& p, int d
     A.dim = dim;
     int hidden = u->heads * u->dh;
     if (up1(u, p + ".norm.g", &A.norm_g) || up1(u, p + ".mem_kv", &A.mem_kv)) return 1;
+    conv_src(u, p + ".to_qkv.weight", "");
     if (make_conv(u->own, A.qkv, P(u, p + ".to_qkv.weight").data.data(), nullptr, 3 * hidden, dim, 0, 1, 1, 1, 0, false))
         return 1;
     if (full) {
+        conv_src(u, p + ".to_out.weight", p + ".to_out.bias");
         if (make_conv(u->own, A.out, P(u, p + ".to_out.weight").data.data(), P(u, p + ".to_out.bias").data.data(), dim,
                       hidden, 0, 1, 1, 1, 0, false)) return 1;
         A.has16 = false;
@@ -538,6 +600,7 @@ static int build_attn_body(dm_unet* u, AttnLayer& A, const std::string& p, int d
             A.has16 = true;
         }
     } else {
+        conv_src(u, p + ".to_out.0.weight", p + ".to_out.0.bias");
         if (make_conv(u->own, A.out, P(u, p + ".to_out.0.weight").data.data(), P(u, p + ".to_out.0.bias").data.data(),
                       dim, hidden, 0, 1, 1, 1, 0, false)) return 1;
         if (up1(u, p + ".to_out.1.g", &A.out_g)) return 1;
@@ -618,6 +681,7 @@ static int build_all(dm_unet* u) {
         }))
         return 1;
     if (weight_group(u, "init_conv", [&]() -> int {
+            conv_src(u, "init_conv.weight", "init_conv.bias");
             return make_conv(u->own, u->init_conv, P(u, "init_conv.weight").data.data(), P(u, "init_conv.bias").data.data(),
                              u->init_dim, cfg.input_channels, 0, 7, 7, 1, 3, false);
         }))
@@ -633,6 +697,7 @@ static int build_all(dm_unet* u) {
         if (build_resnet(u, S.b2, q + ".1", din, 0, din, ss_off)) return 1;
         if (build_attn(u, S.attn, q + ".2", din, cfg.full_attn[i] != 0)) return 1;
         if (weight_group(u, q + ".3", [&]() -> int {
+                conv_src(u, i < n - 1 ? q + ".3.1.weight" : q + ".3.weight", i < n - 1 ? q + ".3.1.bias" : q + ".3.bias");
                 if (i < n - 1) {
                     // pixel-unshuffle + 1x1  ==  2x2 stride-2 conv: W'[o][c][p1][p2] = W[o][c*4 + p1*2 + p2]
                     return make_conv(u->own, S.resample, P(u, q + ".3.1.weight").data.data(),
@@ -655,6 +720,7 @@ static int build_all(dm_unet* u) {
         if (build_resnet(u, S.b2, q + ".1", dout, din, dout, ss_off)) return 1;
         if (build_attn(u, S.attn, q + ".2", dout, cfg.full_attn[n - 1 - j] != 0)) return 1;
         if (weight_group(u, q + ".3", [&]() -> int {
+                conv_src(u, j < n - 1 ? q + ".3.1.weight" : q + ".3.weight", j < n - 1 ? q + ".3.1.bias" : q + ".3.bias");
                 if (j < n - 1)
                     return make_conv(u->own, S.resample, P(u, q + ".3.1.weight").data.data(),
                                      P(u, q + ".3.1.bias").data.data(), din, dout, 0, 3, 3, 1, 1, /*up=*/true);
@@ -665,6 +731,7 @@ static int build_all(dm_unet* u) {
     }
     if (build_resnet(u, u->final_res, "final_res_block", u->init_dim, u->init_dim, u->init_dim, ss_off)) return 1;
     if (weight_group(u, "final_conv", [&]() -> int {
+            conv_src(u, "final_conv.weight", "final_conv.bias");
             return make_conv(u->own, u->final_conv, P(u, "final_conv.weight").data.data(),
                              P(u, "final_conv.bias").data.data(), u->out_dim, u->init_dim, 0, 1, 1, 1, 0, false);
         }))
@@ -1359,6 +1426,7 @@ int dm_unet_finalize(dm_unet* u) {
     DM_REQUIRE(!u->finalized, "already finalized");
     if (dm_unet_missing_params(u) != 0) return 1;
     DM_CHECK_HIP(hipSetDevice(u->device));
+    u->own.rec = &u->pack_ops;
     if (build_all(u)) return 1;
     // the host copies stay: dm_unet_update_param / dm_unet_refresh re-pack from them
     u->finalized = true;
@@ -1426,6 +1494,8 @@ int dm_unet_forward(dm_unet* u, const float* x, const int64_t* time, const float
     DM_REQUIRE(u && x && time && out, "null argument");
     DM_REQUIRE(u->finalized, "dm_unet_finalize has not been called");
     DM_REQUIRE(!u->poisoned, "the last dm_unet_refresh failed: refresh again before running the model");
+    DM_REQUIRE(!u->infer_stale, "parameters were updated on the device (dm_unet_optimizer_step): call dm_unet_train_sync "
+                                "before sampling from this handle");
     DM_REQUIRE(B > 0, "empty batch");
     if (check_hw(u, H, W)) return 1;
     DM_CHECK_HIP(hipSetDevice(u->device));
@@ -1461,6 +1531,8 @@ static int sample_impl(dm_unet* u, int kind, int n_steps, const int64_t* times_h
     DM_REQUIRE(u && times_host && coefs_host && x_T && out, "null argument");
     DM_REQUIRE(u->finalized, "dm_unet_finalize has not been called");
     DM_REQUIRE(!u->poisoned, "the last dm_unet_refresh failed: refresh again before running the model");
+    DM_REQUIRE(!u->infer_stale, "parameters were updated on the device (dm_unet_optimizer_step): call dm_unet_train_sync "
+                                "before sampling from this handle");
     DM_REQUIRE(kind == DM_SAMPLER_DDPM || kind == DM_SAMPLER_DDIM, "unknown sampler kind");
     DM_REQUIRE(n_steps > 0 && B > 0, "empty run");
     DM_REQUIRE(u->out_dim == u->cfg.channels, "sampler needs out_dim == channels (DD/denoising_diffusion.py:456)");
@@ -1642,3 +1714,4 @@ int dm_randn(float* out, int64_t n, uint64_t seed, uint64_t draw, uint64_t eleme
 #include "dm_vae.inc"
 #include "dm_consumer.inc"
 #include "dm_train.inc"
+#include "dm_train_ops.inc"

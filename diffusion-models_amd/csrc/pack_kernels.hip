@@ -1,0 +1,217 @@
+// Device-side weight packing for the training loop: after every optimiser step the master parameters (reference
+// layouts, one flat device buffer) are re-packed into the layouts the convolution kernels read -- the same layouts the
+// host packers produce at dm_unet_finalize (conv_pack_weights, wino_pack_weights, wino4_pack_weights,
+// upwino_pack_weights, pw_pack_weights[_s2d], init7_pack_weights, the four parity convolutions of a folded upsample conv)
+// -- without a device -> host -> device round trip of 143 MB of weights.  Each kernel mirrors its host packer line by line
+// (same double-precision Winograd transforms, same index arithmetic); dm_unet_check_device_pack compares every buffer
+// against the host packer bit for bit.  The input-gradient convolutions read rotated / transposed weights: those are
+// materialised first (rot_transpose_kernel, s2d_transpose_kernel) and go through the same packers.
+#include "dm_common.h"
+
+namespace dm {
+
+static __device__ __forceinline__ int d_pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+// conv_pack_weights: OIHW (Cout, C0 + C1, KH, KW) -> [chunk][ky][kx][CoutP][CK], zero filled; one thread per packed float
+__global__ void pack_direct_kernel(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int C0, int C1, int KH,
+                                   int KW, int CK, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int CoutP = d_pad_to(Cout, 256);
+    const int chunks0 = d_pad_to(C0, CK) / CK;
+    const int Cin = C0 + C1;
+    const int kk = (int)(i % CK);
+    int64_t r = i / CK;
+    const int co = (int)(r % CoutP);
+    r /= CoutP;
+    const int kx = (int)(r % KW);
+    r /= KW;
+    const int ky = (int)(r % KH);
+    const int ch = (int)(r / KH);
+    float v = 0.f;
+    if (co < Cout) {
+        int cin = -1;
+        if (ch < chunks0) {
+            const int c = ch * CK + kk;
+            if (c < C0) cin = c;
+        } else {
+            const int c = (ch - chunks0) * CK + kk;
+            if (c < C1) cin = C0 + c;
+        }
+        if (cin >= 0) v = oihw[(((size_t)co * Cin + cin) * KH + ky) * KW + kx];
+    }
+    packed[i] = v;
+}
+
+// the 2x2 parity convolution (py, px) of nearest-x2 + conv3x3: W'[o][c][a][b] = sum of the 3x3 taps that hit source offset (a, b)
+__global__ void fold_taps_kernel(const float* __restrict__ oihw, float* __restrict__ w2, int64_t oc, int py, int px) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= oc) return;
+    const float* g = oihw + i * 9;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            int y0, y1, x0, x1;
+            if (py == 0) { y0 = a == 0 ? 0 : 1; y1 = a == 0 ? 0 : 2; } else { y0 = a == 0 ? 0 : 2; y1 = a == 0 ? 1 : 2; }
+            if (px == 0) { x0 = b == 0 ? 0 : 1; x1 = b == 0 ? 0 : 2; } else { x0 = b == 0 ? 0 : 2; x1 = b == 0 ? 1 : 2; }
+            float s = 0.f;
+            for (int dy = y0; dy <= y1; ++dy)
+                for (int dx = x0; dx <= x1; ++dx) s += g[dy * 3 + dx];
+            w2[i * 4 + a * 2 + b] = s;
+        }
+}
+
+// wino_pack_weights: U = G g G^T (4x4) -> [chunk of 8 cin][xi 16][Cout][8]; one thread per (cout, cin)
+__global__ void pack_wino_kernel(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Cout * Cin) return;
+    const int co = (int)(i / Cin), ci = (int)(i % Cin);
+    const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const float* gk = oihw + i * 9;
+    double Gg[4][3];
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 3; ++b) Gg[a][b] = G[a][0] * gk[b] + G[a][1] * gk[3 + b] + G[a][2] * gk[6 + b];
+    const int chunk = ci / 8, cc = ci % 8;
+    for (int a = 0; a < 4; ++a)
+        for (int j = 0; j < 4; ++j) {
+            const double u = Gg[a][0] * G[j][0] + Gg[a][1] * G[j][1] + Gg[a][2] * G[j][2];
+            packed[(((size_t)chunk * 16 + a * 4 + j) * Cout + co) * 8 + cc] = (float)u;
+        }
+}
+
+// wino4_pack_weights: U = G g G^T (6x6) -> [chunk][wave 4][slot 9][cout tile][kq 4][n 16][gq 4][st 2]
+__global__ void pack_wino4_kernel(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Cout * Cin) return;
+    const int co = (int)(i / Cin), ci = (int)(i % Cin);
+    const double G[6][3] = {{0.25, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const int lo[3] = {0, 1, 2}, hi[3] = {5, 3, 4};
+    const float* gk = oihw + i * 9;
+    double Gg[6][3];
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 3; ++b) Gg[a][b] = G[a][0] * gk[b] + G[a][1] * gk[3 + b] + G[a][2] * gk[6 + b];
+    double U[6][6];
+    for (int a = 0; a < 6; ++a)
+        for (int j = 0; j < 6; ++j) U[a][j] = Gg[a][0] * G[j][0] + Gg[a][1] * G[j][1] + Gg[a][2] * G[j][2];
+    const int chunk = ci / 8, cc = ci % 8;
+    const int ct = co / 64, gq = (co % 64) / 16, n = co % 16, kq = cc / 2, st = cc % 2;
+    for (int g = 0; g < 4; ++g)
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                const int ii = (g >> 1) ? hi[a] : lo[a], jj = (g & 1) ? hi[b] : lo[b];
+                packed[(((((size_t)chunk * 4 + g) * 9 + a * 3 + b) * (Cout / 64) + ct) * 4 + kq) * 128 + n * 8 + gq * 2 + st] =
+                    (float)U[ii][jj];
+            }
+}
+
+// upwino_pack_weights: G = [1 0 0; 1 1 1; 0 0 1] -> [chunk][xi 9][cout tile][kq 4][n 16][gq 4][st 2]
+__global__ void pack_upwino_kernel(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Cout * Cin) return;
+    const int co = (int)(i / Cin), ci = (int)(i % Cin);
+    const double G[3][3] = {{1, 0, 0}, {1, 1, 1}, {0, 0, 1}};
+    const float* gk = oihw + i * 9;
+    double Gg[3][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) Gg[a][b] = G[a][0] * gk[b] + G[a][1] * gk[3 + b] + G[a][2] * gk[6 + b];
+    const int chunk = ci / 8, cc = ci % 8;
+    const int ct = co / 64, gq = (co % 64) / 16, n = co % 16, kq = cc / 2, st = cc % 2;
+    for (int a = 0; a < 3; ++a)
+        for (int j = 0; j < 3; ++j) {
+            const double u = Gg[a][0] * G[j][0] + Gg[a][1] * G[j][1] + Gg[a][2] * G[j][2];
+            packed[((((size_t)chunk * 9 + 3 * a + j) * (Cout / 64) + ct) * 4 + kq) * 128 + n * 8 + gq * 2 + st] = (float)u;
+        }
+}
+
+// pw_pack_weights: (Cout, Cin) -> [chunk of 16][cout tile of 16][lane = 16 kq + l15][j 4];  s2d: the (Cout, C0, 2, 2)
+// Downsample weight read as (Cout, 4 C0) with K index sub * C0 + c
+__global__ void pack_pw_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin, int s2d_C0) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Cout * Cin) return;
+    const int co = (int)(i / Cin), ci = (int)(i % Cin);
+    float v;
+    if (s2d_C0) {
+        const int sub = ci / s2d_C0, c = ci % s2d_C0;
+        v = w[((size_t)co * s2d_C0 + c) * 4 + sub];
+    } else {
+        v = w[i];
+    }
+    const int chunk = ci / 16, cc = ci % 16, kq = cc / 4, j = cc % 4;
+    const int t = co / 16, l15 = co % 16;
+    packed[(((size_t)chunk * (Cout / 16) + t) * 64 + kq * 16 + l15) * 4 + j] = v;
+}
+
+// init7_pack_weights: (64, Cin, 7, 7) -> [k padded to a multiple of 4][l15][t]
+__global__ void pack_init7_kernel(const float* __restrict__ oihw, float* __restrict__ packed, int Cin, int KP) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= KP * 64) return;
+    const int k = i / 64, co = i % 64, K = 49 * Cin;
+    packed[((size_t)k * 16 + (co & 15)) * 4 + (co >> 4)] = k < K ? oihw[(size_t)co * K + k] : 0.f;
+}
+
+// (c_n, Cout, K, K) <- 180-degree rotation + channel-role swap of rows [c_lo, c_lo + c_n) of an OIHW (Cout, Cin, K, K)
+__global__ void rot_transpose_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int K, int c_lo,
+                                     int c_n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)c_n * Cout * K * K) return;
+    const int kx = (int)(i % K), ky = (int)((i / K) % K), o = (int)((i / (K * K)) % Cout), c = (int)(i / ((int64_t)K * K * Cout));
+    out[i] = w[(((size_t)o * Cin + c_lo + c) * K + (K - 1 - ky)) * K + (K - 1 - kx)];
+}
+// Downsample input gradient as a 1x1 convolution Cout -> 4C: out[(sub * C + c)][o] = w[o][c * 4 + sub]
+__global__ void s2d_transpose_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)4 * C * Cout) return;
+    const int o = (int)(i % Cout), c = (int)((i / Cout) % C), sub = (int)(i / ((int64_t)Cout * C));
+    out[i] = w[(size_t)o * 4 * C + c * 4 + sub];
+}
+
+#define DM_PK_LAUNCH(kernel, n, ...)                                                                     \
+    do {                                                                                                   \
+        const int64_t n_ = (n);                                                                            \
+        if (n_ > 0) hipLaunchKernelGGL(kernel, dim3((unsigned)((n_ + 255) / 256)), dim3(256), 0, s, __VA_ARGS__); \
+        DM_CHECK_HIP(hipGetLastError());                                                                   \
+    } while (0)
+
+int launch_pack_direct(const float* oihw, float* packed, int Cout, int C0, int C1, int KH, int KW, hipStream_t s) {
+    const int CK = conv_ck_for(C0, C1);
+    const int64_t n = (int64_t)conv_packed_floats(Cout, C0, C1, KH, KW);
+    DM_PK_LAUNCH(pack_direct_kernel, n, oihw, packed, Cout, C0, C1, KH, KW, CK, n);
+    return 0;
+}
+int launch_fold_taps(const float* oihw, float* w2, int Cout, int Cin, int py, int px, hipStream_t s) {
+    DM_PK_LAUNCH(fold_taps_kernel, (int64_t)Cout * Cin, oihw, w2, (int64_t)Cout * Cin, py, px);
+    return 0;
+}
+int launch_pack_wino(const float* oihw, float* packed, int Cout, int Cin, hipStream_t s) {
+    DM_PK_LAUNCH(pack_wino_kernel, (int64_t)Cout * Cin, oihw, packed, Cout, Cin);
+    return 0;
+}
+int launch_pack_wino4(const float* oihw, float* packed, int Cout, int Cin, hipStream_t s) {
+    DM_PK_LAUNCH(pack_wino4_kernel, (int64_t)Cout * Cin, oihw, packed, Cout, Cin);
+    return 0;
+}
+int launch_pack_upwino(const float* oihw, float* packed, int Cout, int Cin, hipStream_t s) {
+    DM_PK_LAUNCH(pack_upwino_kernel, (int64_t)Cout * Cin, oihw, packed, Cout, Cin);
+    return 0;
+}
+int launch_pack_pw(const float* w, float* packed, int Cout, int Cin, int s2d_C0, hipStream_t s) {
+    DM_PK_LAUNCH(pack_pw_kernel, (int64_t)Cout * Cin, w, packed, Cout, Cin, s2d_C0);
+    return 0;
+}
+int launch_pack_init7(const float* oihw, float* packed, int Cin, hipStream_t s) {
+    const int KP = (int)(init7_packed_floats(Cin) / 64);
+    DM_PK_LAUNCH(pack_init7_kernel, (int64_t)KP * 64, oihw, packed, Cin, KP);
+    return 0;
+}
+int launch_rot_transpose(const float* w, float* out, int Cout, int Cin, int K, int c_lo, int c_n, hipStream_t s) {
+    DM_PK_LAUNCH(rot_transpose_kernel, (int64_t)c_n * Cout * K * K, w, out, Cout, Cin, K, c_lo, c_n);
+    return 0;
+}
+int launch_s2d_transpose(const float* w, float* out, int Cout, int C, hipStream_t s) {
+    DM_PK_LAUNCH(s2d_transpose_kernel, (int64_t)4 * C * Cout, w, out, Cout, C);
+    return 0;
+}
+
+}  // namespace dm

@@ -142,25 +142,35 @@ __global__ __launch_bounds__(256) void norm_act_bwd_kernel(const NormBwdParams p
     }
 }
 
-// dg[c] (+)= sum over images and chunks; dbias likewise; dss[b][c] / dss[b][C + c] = sum over the chunks of image b
-__global__ void rowgrad_reduce_kernel(const float* __restrict__ part, int B, int chunks, int C, float* __restrict__ dg,
-                                      float* __restrict__ dbias, float* __restrict__ dss, int dss_stride, int accumulate) {
+// stage 1, grid (ceil(C / 64), B): sums over the chunks of one image: dss[b][c] / dss[b][C + c] (the image's scale / shift
+// gradient) and img[b][2][C] (its share of dg / dbias);  stage 2: dg[c] (+)= sum_b, dbias likewise.  Fixed order throughout.
+__global__ void rowgrad_image_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ dss,
+                                     int dss_stride, float* __restrict__ img) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
+    float sg = 0.f, sb = 0.f, ssc = 0.f, ssh = 0.f;
+    for (int k = 0; k < chunks; ++k) {
+        const float* q = part + ((size_t)b * chunks + k) * 4 * C;
+        sg += q[c];
+        sb += q[C + c];
+        ssc += q[2 * C + c];
+        ssh += q[3 * C + c];
+    }
+    if (dss) {
+        dss[(size_t)b * dss_stride + c] = ssc;
+        dss[(size_t)b * dss_stride + C + c] = ssh;
+    }
+    img[((size_t)b * 2) * C + c] = sg;
+    img[((size_t)b * 2 + 1) * C + c] = sb;
+}
+__global__ void rowgrad_finish_kernel(const float* __restrict__ img, int B, int C, float* __restrict__ dg,
+                                      float* __restrict__ dbias, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float sg = 0.f, sb = 0.f;
     for (int b = 0; b < B; ++b) {
-        float ssc = 0.f, ssh = 0.f;
-        for (int k = 0; k < chunks; ++k) {
-            const float* q = part + ((size_t)b * chunks + k) * 4 * C;
-            sg += q[c];
-            sb += q[C + c];
-            ssc += q[2 * C + c];
-            ssh += q[3 * C + c];
-        }
-        if (dss) {
-            dss[(size_t)b * dss_stride + c] = ssc;
-            dss[(size_t)b * dss_stride + C + c] = ssh;
-        }
+        sg += img[((size_t)b * 2) * C + c];
+        sb += img[((size_t)b * 2 + 1) * C + c];
     }
     if (dg) dg[c] = accumulate ? dg[c] + sg : sg;
     if (dbias) dbias[c] = accumulate ? dbias[c] + sb : sb;
@@ -174,7 +184,7 @@ static int pow2ceil(int v) {
 
 size_t norm_act_bwd_ws_floats(int B, int pix_per_image, int C) {
     const int chunks = std::max(1, std::min(pix_per_image / 16, (1024 + B - 1) / B));
-    return (size_t)B * chunks * 4 * C;
+    return (size_t)B * chunks * 4 * C + (size_t)B * 2 * C;  // chunk partials + per-image dg / dbias
 }
 
 // dy, u, du: [B * pix_per_image][C].  dg / dbias: [C] parameter gradients ((+)= with accumulate); dss: [B][dss_stride]
@@ -203,8 +213,11 @@ int launch_norm_act_bwd(const float* dy, const float* u, const float* g, const f
         default: hipLaunchKernelGGL(norm_act_bwd_kernel<4>, grid, dim3(256), lds, s, p); break;
     }
     DM_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(rowgrad_reduce_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, B, p.chunks, C, dg, dbias,
-                       (flags & EPI_SCALE_SHIFT) ? dss : nullptr, dss_stride, accumulate);
+    float* img = ws + (size_t)B * p.chunks * 4 * C;
+    hipLaunchKernelGGL(rowgrad_image_kernel, dim3((C + 63) / 64, B), dim3(64), 0, s, ws, p.chunks, C,
+                       (flags & EPI_SCALE_SHIFT) ? dss : nullptr, dss_stride, img);
+    DM_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rowgrad_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, s, img, B, C, dg, dbias, accumulate);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -230,10 +243,26 @@ __global__ void colsum_finish_kernel(const float* __restrict__ part, int blocks,
     for (int b = 0; b < blocks; ++b) s += part[(size_t)b * C + c];
     out[c] = accumulate ? out[c] + s : s;
 }
-size_t colsum_ws_floats(int64_t rows, int C) { return (size_t)std::min<int64_t>(rows, 512) * C; }
+// few rows (a batch of per-image vectors): one pass, thread per column
+__global__ void colsum_small_kernel(const float* __restrict__ x, int rows, int C, int64_t row_stride, int64_t col_stride,
+                                    float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += x[r * row_stride + c * col_stride];
+    out[c] = accumulate ? out[c] + s : s;
+}
+static int colsum_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(64, rows / 128)); }
+size_t colsum_ws_floats(int64_t rows, int C) { return (size_t)colsum_blocks(rows) * C; }
 int launch_colsum(const float* x, int64_t rows, int C, int64_t row_stride, int64_t col_stride, float* ws, float* out,
                   int accumulate, hipStream_t s) {
-    const int blocks = (int)std::min<int64_t>(rows, 512);
+    if (rows <= 512) {
+        hipLaunchKernelGGL(colsum_small_kernel, dim3((C + 63) / 64), dim3(64), 0, s, x, (int)rows, C, row_stride, col_stride,
+                           out, accumulate);
+        DM_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    const int blocks = colsum_blocks(rows);
     const int rpb = (int)((rows + blocks - 1) / blocks);
     const int nb = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, nb), dim3(64), 0, s, x, rows, C, row_stride, col_stride,
@@ -412,18 +441,27 @@ int launch_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, float
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
-// nn.Linear input gradient: dx[r][i] = sum_o dy[r * ldy + o] * W[o][i]   (W as stored: (O, I))
-__global__ void linear_dgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ W, float* __restrict__ dx,
-                                    int ldx, int R, int I, int O) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (i >= I) return;
+// nn.Linear input gradient: dx[r][i] = sum_o dy[r * ldy + o] * W[o][i]   (W as stored: (O, I)).
+// grid (ceil(I / 64), R), 1024 threads = 64 columns x 16 slices of the O range, combined through LDS in a fixed order.
+__global__ __launch_bounds__(1024) void linear_dgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ W,
+                                                            float* __restrict__ dx, int ldx, int R, int I, int O) {
+    __shared__ float red[16][64];
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + li, r = blockIdx.y;
     float s = 0.f;
-    for (int o = 0; o < O; ++o) s += dy[(size_t)r * ldy + o] * W[(size_t)o * I + i];
-    dx[(size_t)r * ldx + i] = s;
+    if (i < I)
+        for (int o = q; o < O; o += 16) s += dy[(size_t)r * ldy + o] * W[(size_t)o * I + i];
+    red[q][li] = s;
+    __syncthreads();
+    if (q == 0 && i < I) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][li];
+        dx[(size_t)r * ldx + i] = v;
+    }
 }
 int launch_linear_dgrad(const float* dy, int ldy, const float* W, float* dx, int ldx, int R, int I, int O, hipStream_t s) {
-    hipLaunchKernelGGL(linear_dgrad_kernel, dim3((I + 63) / 64, R), dim3(64), 0, s, dy, ldy, W, dx, ldx, R, I, O);
+    hipLaunchKernelGGL(linear_dgrad_kernel, dim3((I + 63) / 64, R), dim3(1024), 0, s, dy, ldy, W, dx, ldx, R, I, O);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }

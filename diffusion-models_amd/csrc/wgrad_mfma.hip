@@ -162,17 +162,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p)
     }
 }
 
-// out[(o * Cin + c) * T + t] (= | +=) scale * sum_split partial[split][t][o][c]: OIHW for 3x3 / 1x1, and the
-// (Cout, 4 C) layout of the Downsample weight (index c*4 + p1*2 + p2) for T = 4.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int T, int64_t oc, float* __restrict__ out,
-                                    int accumulate) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= oc) return;
-    for (int t = 0; t < T; ++t) {
-        float s = 0.f;
-        for (int sp = 0; sp < splits; ++sp) s += partial[((int64_t)sp * T + t) * oc + i];
+// out[(o * Cin + c) * T + t] (= | +=) sum_split partial[split][t][o][c]: OIHW for 3x3 / 1x1, and the (Cout, 4 C) layout of
+// the Downsample weight (index c*4 + p1*2 + p2) for T = 4.  grid (ceil(oc / 64), T), 256 threads = 64 elements x 4 split
+// lanes: lane q sums the splits q, q + 4, ... (128 consecutive bytes per split row), the four meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int T, int64_t oc,
+                                                           float* __restrict__ out, int accumulate) {
+    __shared__ float red[4][64];
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6, t = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 64 + li;
+    float s = 0.f;
+    if (i < oc)
+        for (int sp = q; sp < splits; sp += 4) s += partial[((int64_t)sp * T + t) * oc + i];
+    red[q][li] = s;
+    __syncthreads();
+    if (q == 0 && i < oc) {
+        const float v = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
         float* o = out + i * T + t;
-        *o = accumulate ? *o + s : s;
+        *o = accumulate ? *o + v : v;
     }
 }
 
@@ -182,7 +188,9 @@ size_t wgrad_ws_floats(int B, int Ho, int Wo, int Cout, int Cin, int T, int* spl
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + R - 1) / R;
     const int n_blocks = B * tiles_x * tiles_y;
     const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
-    int splits = std::max(1, std::min(n_blocks, (512 + tiles - 1) / tiles));
+    // enough workgroups to fill the chip twice, but at least 4 pixel blocks per split: every split writes a full
+    // [T][Cout][Cin] partial tile that the reduce kernel reads back
+    int splits = std::max(1, std::min((n_blocks + 3) / 4, (512 + tiles - 1) / tiles));
     const int bps = (n_blocks + splits - 1) / splits;
     splits = (n_blocks + bps - 1) / bps;
     if (splits_out) *splits_out = splits;
@@ -233,7 +241,7 @@ int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float
     DM_CHECK_HIP(hipGetLastError());
     if (timed && prof::end(s)) return 1;
     const int64_t oc = (int64_t)Cout * p.Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((oc + 255) / 256)), dim3(256), 0, s, ws, splits, T, oc, dw,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((oc + 63) / 64), T), dim3(256), 0, s, ws, splits, T, oc, dw,
                        accumulate);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
@@ -296,7 +304,7 @@ int launch_wgrad_naive(const float* x, int x_nchw, const float* dy, int dy_nchw,
     const int n_out = Cout * Cin * KH * KW;
     hipLaunchKernelGGL(wgrad_naive_kernel, dim3((n_out + 127) / 128, splits), dim3(128), 0, s, p);
     DM_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, ws, splits, 1, (int64_t)n_out, dw,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 63) / 64, 1), dim3(256), 0, s, ws, splits, 1, (int64_t)n_out, dw,
                        accumulate);
     DM_CHECK_HIP(hipGetLastError());
     return 0;

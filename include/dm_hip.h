@@ -319,6 +319,32 @@ int dm_unet_loss_backward(dm_unet* u, const float* x_start, const int64_t* t_hos
 int dm_op_q_sample(const float* x_start, const float* noise, const float* coef_host, float* out, int B, int per_sample,
                    void* stream);
 
+/* Backward of the single operators above (what autograd computes for the reference module), for parity tests of each
+ * piece of the training step.  All tensors NCHW fp32 device pointers; gradient outputs have the shape of the tensor they
+ * differentiate; optional outputs may be NULL. */
+/* nn.Conv2d backward: 3x3 / pad 1 (up2: the conv ran on the nearest-x2 upsampled cat(in0, in1)) or 1x1; dy (B,Cout,Ho,Wo) */
+int dm_op_conv2d_bwd(const float* in0, int C0, const float* in1, int C1, const float* weight, const float* dy, float* d_in0,
+                     float* d_in1, float* d_weight, float* d_bias, int B, int H, int W, int Cout, int ksize, int pad, int up2,
+                     void* stream);
+/* Downsample backward (DD/denoising_diffusion.py:54-58) */
+int dm_op_downsample_bwd(const float* in, int C, const float* weight, const float* dy, float* d_in, float* d_weight,
+                         float* d_bias, int B, int H, int W, int Cout, void* stream);
+/* Block backward (:113-122); d_scale / d_shift (B, Cout) */
+int dm_op_block_bwd(const float* x, int Cin, const float* weight, const float* bias, const float* g, const float* scale,
+                    const float* shift, const float* dy, float* dx, float* d_weight, float* d_bias, float* d_g,
+                    float* d_scale, float* d_shift, int B, int H, int W, int Cout, void* stream);
+/* RMSNorm backward (:66-67) */
+int dm_op_rmsnorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* dg, int B, int C, int H, int W,
+                      void* stream);
+/* LinearAttention / Attention backward (:173-193, :215-229) */
+int dm_op_linear_attention_bwd(const float* x, const float* norm_g, const float* mem_kv, const float* w_qkv,
+                               const float* w_out, const float* b_out, const float* out_g, const float* dy, float* dx,
+                               float* d_norm_g, float* d_mem_kv, float* d_w_qkv, float* d_w_out, float* d_b_out,
+                               float* d_out_g, int B, int C, int H, int W, int heads, int dim_head, void* stream);
+int dm_op_attention_bwd(const float* x, const float* norm_g, const float* mem_kv, const float* w_qkv, const float* w_out,
+                        const float* b_out, const float* dy, float* dx, float* d_norm_g, float* d_mem_kv, float* d_w_qkv,
+                        float* d_w_out, float* d_b_out, int B, int C, int H, int W, int heads, int dim_head, void* stream);
+
 /* ---- measurement (bench.py's roofline leg; not part of the reference surface) -------------
  * While enabled, every convolution / fused-attention launch is bracketed by two HIP events recorded on
  * the stream the kernel is launched on.  Do not combine with use_graph.  dm_profile_enable(1) first
