@@ -31,6 +31,7 @@ EXPORTS = (
     "dm_conv_create", "dm_conv_destroy", "dm_conv_forward", "dm_op_pool2d", "dm_op_resize_bilinear",
     "dm_op_copy_channels_nhwc", "dm_op_global_avgpool", "dm_op_linear",
     "dm_unet_train_enable", "dm_unet_grad_floats", "dm_unet_get_grad", "dm_unet_loss_backward", "dm_op_q_sample",
+    "dm_unet_optimizer_step", "dm_unet_ema_update", "dm_unet_get_param", "dm_unet_train_sync", "dm_unet_check_device_pack",
     "dm_op_conv2d_bwd", "dm_op_downsample_bwd", "dm_op_block_bwd", "dm_op_rmsnorm_bwd", "dm_op_linear_attention_bwd",
     "dm_op_attention_bwd",
     "dm_profile_enable", "dm_profile_read",
@@ -145,8 +146,13 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_unet_grad_floats.argtypes = [vp]
     lib.dm_unet_grad_floats.restype = i64
     lib.dm_unet_get_grad.argtypes = [vp, C.c_char_p, fp, vp]
-    lib.dm_unet_loss_backward.argtypes = [vp, fp, C.POINTER(i64), C.POINTER(C.c_float), fp, i32, C.POINTER(C.c_float), fp,
-                                          i32, i32, i32, vp]
+    lib.dm_unet_loss_backward.argtypes = [vp, fp, C.POINTER(i64), C.POINTER(C.c_float), fp, i32, C.c_float, i32,
+                                          C.POINTER(C.c_float), fp, i32, i32, i32, vp]
+    lib.dm_unet_optimizer_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), vp]
+    lib.dm_unet_ema_update.argtypes = [vp, C.c_float, i32, vp]
+    lib.dm_unet_get_param.argtypes = [vp, C.c_char_p, i32, fp, vp]
+    lib.dm_unet_train_sync.argtypes = [vp]
+    lib.dm_unet_check_device_pack.argtypes = [vp]
     lib.dm_op_q_sample.argtypes = [fp, fp, C.POINTER(C.c_float), fp, i32, i32, vp]
     lib.dm_op_conv2d_bwd.argtypes = [fp, i32, fp, i32, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.dm_op_downsample_bwd.argtypes = [fp, i32, fp, fp, fp, fp, fp, i32, i32, i32, i32, vp]

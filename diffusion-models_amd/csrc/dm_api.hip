@@ -328,6 +328,7 @@ namespace dm {
 
 void free_train(dm_unet* u);  // dm_train.inc
 static int build_train(dm_unet* u);
+static int upload_master_if_resident(dm_unet* u);
 
 static void expect(dm_unet* u, const std::string& name, std::vector<int64_t> shape) {
     HostTensor t;
@@ -1477,7 +1478,8 @@ int dm_unet_refresh(dm_unet* u) {
         u->poisoned = true;
         return rc;
     }
-    if (u->train && build_train(u)) {  // the input-gradient convolutions are packed from the same parameters
+    // the input-gradient convolutions are packed from the same parameters; a device-resident master copy follows the host
+    if (u->train && (build_train(u) || upload_master_if_resident(u))) {
         u->poisoned = true;
         return 1;
     }

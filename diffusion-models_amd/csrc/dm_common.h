@@ -356,7 +356,18 @@ int launch_linear_dgrad(const float* dy, int ldy, const float* W, float* dx, int
 int launch_q_sample(const float* x_start, const float* noise, const float* coef_dev, float* x, int B, int per_sample,
                     hipStream_t s);
 int launch_mse_loss(const float* out, const float* x_start, const float* noise, const float* coef_dev, float* dout,
-                    float* part, float* loss, int B, int per_sample, int objective, hipStream_t s);
+                    float* part, float* loss, int B, int per_sample, int objective, float loss_scale, hipStream_t s);
+int launch_lerp(float* ema, const float* p, int64_t n, float decay, hipStream_t s);
+// device mirrors of the host weight packers (pack_kernels.hip)
+int launch_pack_direct(const float* oihw, float* packed, int Cout, int C0, int C1, int KH, int KW, hipStream_t s);
+int launch_fold_taps(const float* oihw, float* w2, int Cout, int Cin, int py, int px, hipStream_t s);
+int launch_pack_wino(const float* oihw, float* packed, int Cout, int Cin, hipStream_t s);
+int launch_pack_wino4(const float* oihw, float* packed, int Cout, int Cin, hipStream_t s);
+int launch_pack_upwino(const float* oihw, float* packed, int Cout, int Cin, hipStream_t s);
+int launch_pack_pw(const float* w, float* packed, int Cout, int Cin, int s2d_C0, hipStream_t s);
+int launch_pack_init7(const float* oihw, float* packed, int Cin, hipStream_t s);
+int launch_rot_transpose(const float* w, float* out, int Cout, int Cin, int K, int c_lo, int c_n, hipStream_t s);
+int launch_s2d_transpose(const float* w, float* out, int Cout, int C, hipStream_t s);
 int launch_grad_norm(const float* grads, int64_t n, double* part_ws, float max_norm, float* out2, hipStream_t s);
 int launch_adam_ema(float* p, const float* g, float* m, float* v, float* ema, const float* clip2, int64_t n, float lr,
                     float b1, float b2, float eps, int step, float ema_decay, hipStream_t s);

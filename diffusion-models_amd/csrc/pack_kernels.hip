@@ -64,6 +64,7 @@ __global__ void fold_taps_kernel(const float* __restrict__ oihw, float* __restri
 
 // wino_pack_weights: U = G g G^T (4x4) -> [chunk of 8 cin][xi 16][Cout][8]; one thread per (cout, cin)
 __global__ void pack_wino_kernel(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin) {
+#pragma clang fp contract(off)  // the host packer (x86-64 baseline) rounds every product and sum separately
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)Cout * Cin) return;
     const int co = (int)(i / Cin), ci = (int)(i % Cin);
@@ -82,6 +83,7 @@ __global__ void pack_wino_kernel(const float* __restrict__ oihw, float* __restri
 
 // wino4_pack_weights: U = G g G^T (6x6) -> [chunk][wave 4][slot 9][cout tile][kq 4][n 16][gq 4][st 2]
 __global__ void pack_wino4_kernel(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin) {
+#pragma clang fp contract(off)  // the host packer (x86-64 baseline) rounds every product and sum separately
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)Cout * Cin) return;
     const int co = (int)(i / Cin), ci = (int)(i % Cin);
@@ -108,6 +110,7 @@ __global__ void pack_wino4_kernel(const float* __restrict__ oihw, float* __restr
 
 // upwino_pack_weights: G = [1 0 0; 1 1 1; 0 0 1] -> [chunk][xi 9][cout tile][kq 4][n 16][gq 4][st 2]
 __global__ void pack_upwino_kernel(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin) {
+#pragma clang fp contract(off)  // the host packer (x86-64 baseline) rounds every product and sum separately
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)Cout * Cin) return;
     const int co = (int)(i / Cin), ci = (int)(i % Cin);

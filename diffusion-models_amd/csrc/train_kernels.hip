@@ -492,11 +492,11 @@ int launch_q_sample(const float* x_start, const float* noise, const float* coef_
 // one workgroup per sample: part[b] = loss_weight * mean((out - target)^2); dout = 2 (out - target) * w / (per_sample * B)
 __global__ void mse_loss_kernel(const float* __restrict__ out, const float* __restrict__ x_start, const float* __restrict__ noise,
                                 const float* __restrict__ coef, float* __restrict__ dout, float* __restrict__ part,
-                                int per_sample, int B, int objective) {
+                                int per_sample, int B, int objective, float loss_scale) {
     __shared__ double red[256];
     const int b = blockIdx.x;
     const float* c = coef + 4 * b;
-    const float gscale = 2.0f * c[2] / ((float)per_sample * (float)B);
+    const float gscale = loss_scale * 2.0f * c[2] / ((float)per_sample * (float)B);
     double s = 0.0;
     for (int i = threadIdx.x; i < per_sample; i += 256) {
         const size_t k = (size_t)b * per_sample + i;
@@ -516,17 +516,18 @@ __global__ void mse_loss_kernel(const float* __restrict__ out, const float* __re
     }
     if (threadIdx.x == 0) part[b] = (float)(red[0] / per_sample) * c[2];
 }
-__global__ void mean_kernel(const float* __restrict__ part, int B, float* __restrict__ loss) {
+__global__ void mean_kernel(const float* __restrict__ part, int B, float* __restrict__ loss, float loss_scale) {
     double s = 0.0;
     for (int b = 0; b < B; ++b) s += part[b];
-    *loss = (float)(s / B);
+    *loss = (float)(s / B) * loss_scale;
 }
+// loss_scale: 1 / gradient_accumulate_every of Trainer.train (:1171) -- scales the reported loss and every gradient
 int launch_mse_loss(const float* out, const float* x_start, const float* noise, const float* coef_dev, float* dout,
-                    float* part, float* loss, int B, int per_sample, int objective, hipStream_t s) {
+                    float* part, float* loss, int B, int per_sample, int objective, float loss_scale, hipStream_t s) {
     hipLaunchKernelGGL(mse_loss_kernel, dim3(B), dim3(256), 0, s, out, x_start, noise, coef_dev, dout, part, per_sample, B,
-                       objective);
+                       objective, loss_scale);
     DM_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1), 0, s, part, B, loss);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1), 0, s, part, B, loss, loss_scale);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -579,6 +580,18 @@ __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__
     const float pi = p[i] - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
     p[i] = pi;
     if (ema) ema[i] = ema[i] * ema_decay + pi * (1.0f - ema_decay);
+}
+// ema = ema * decay + p * (1 - decay)   (ema_pytorch: ema.lerp_(online, 1 - decay))
+__global__ void lerp_kernel(float* __restrict__ ema, const float* __restrict__ p, int64_t n, float decay) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float e = ema[i];
+    ema[i] = e + (p[i] - e) * (1.0f - decay);
+}
+int launch_lerp(float* ema, const float* p, int64_t n, float decay, hipStream_t s) {
+    hipLaunchKernelGGL(lerp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ema, p, n, decay);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 int launch_adam_ema(float* p, const float* g, float* m, float* v, float* ema, const float* clip2, int64_t n, float lr,
                     float b1, float b2, float eps, int step, float ema_decay, hipStream_t s) {

@@ -233,10 +233,13 @@ class DenoisingDiffusion:
                                             _lib.ptr(out), x_start.shape[0], x_start[0].numel(), stream))
         return out
 
-    def p_losses(self, x_start, t, noise=None, offset_noise_strength=None, *, return_model_out=False):
+    def p_losses(self, x_start, t, noise=None, offset_noise_strength=None, *, return_model_out=False, loss_scale=1.0,
+                 accumulate=False):
         """:823-889: returns the loss (0-dim CPU tensor); the parameter gradients stay on the model
         (``self.model.grad(name)`` / ``.grads()``) -- loss and backward are one call of the library, there is no autograd
-        graph to keep.  Offset noise, the hybrid (KL) loss and self-conditioning are not on this path."""
+        graph to keep.  ``loss_scale`` / ``accumulate`` are the micro-batch loop of ``Trainer.train`` (:1164-1176):
+        ``loss / gradient_accumulate_every`` with the gradients added up.  Offset noise, the hybrid (KL) loss and
+        self-conditioning are not on this path."""
         if offset_noise_strength is None:
             offset_noise_strength = self.offset_noise_strength
         assert not offset_noise_strength, "offset noise is not on the HIP training path"
@@ -255,8 +258,8 @@ class DenoisingDiffusion:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self._lib.dm_unet_loss_backward(
             self.model._handle, _lib.ptr(x_start), C.cast(t_arr, C.POINTER(C.c_int64)),
-            C.cast(coef.data_ptr(), C.POINTER(C.c_float)), _lib.ptr(noise), self._objective_id, C.byref(loss), _lib.ptr(out),
-            b, h, w, stream))
+            C.cast(coef.data_ptr(), C.POINTER(C.c_float)), _lib.ptr(noise), self._objective_id, float(loss_scale),
+            int(bool(accumulate)), C.byref(loss), _lib.ptr(out), b, h, w, stream))
         val = torch.tensor(loss.value, dtype=torch.float32)
         return (val, out) if return_model_out else val
 

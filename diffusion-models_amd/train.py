@@ -1,0 +1,94 @@
+"""Host-side mirror of one iteration of ``Trainer.train`` (denoising-diffusion-pytorch/denoising_diffusion/
+denoising_diffusion.py:1162-1190) on the HIP training step: the micro-batch loop with ``loss / gradient_accumulate_every``,
+``clip_grad_norm_(max_grad_norm)``, ``Adam.step()``, ``ema.update()`` -- every FLOP in libdm_hip.so, the parameters, Adam
+moments and the EMA copy resident on the device.
+
+``EMA`` restates the schedule of ``ema_pytorch.EMA`` as the reference configures it (``EMA(diffusion_model, beta=ema_decay,
+update_every=ema_update_every)``, :1017): ema-pytorch is not in the reference tree nor in this image, so the schedule is
+restated from its published source (ema-pytorch 0.7.x: ``update_after_step=100``, ``inv_gamma=1``, ``power=2/3``,
+``min_value=0``) -- parity unpinned, the arithmetic itself (copy / lerp) is tested against torch.
+
+The reference's ``Trainer`` (datasets, accelerate, checkpoints, tensorboard, FID hooks) is outside the scope of this
+package; INTEGRATION.md shows the three lines its loop changes.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+
+
+class EMA:
+    """``ema = EMA(diffusion, beta=0.995, update_every=10); ema.update(); ema.ema_model.sample(...)``."""
+
+    def __init__(self, model, beta=0.9999, update_after_step=100, update_every=10, inv_gamma=1.0, power=2 / 3,
+                 min_value=0.0):
+        self.online_model = model
+        self.beta, self.update_after_step, self.update_every = beta, update_after_step, update_every
+        self.inv_gamma, self.power, self.min_value = inv_gamma, power, min_value
+        self.step = 0
+        self.initted = False
+        self._ema_model = None
+        self._ema_model_step = -1
+
+    def get_current_decay(self) -> float:
+        epoch = max(self.step - self.update_after_step - 1, 0)
+        if epoch <= 0:
+            return 0.0
+        value = 1 - (1 + epoch / self.inv_gamma) ** -self.power
+        return min(max(value, self.min_value), self.beta)
+
+    def update(self):
+        step = self.step
+        self.step += 1
+        if step % self.update_every != 0:
+            return
+        unet = self.online_model.model
+        if step <= self.update_after_step or not self.initted:
+            unet.ema_update(0.0, copy=True)
+            self.initted = self.initted or step > self.update_after_step
+            return
+        unet.ema_update(self.get_current_decay(), copy=False)
+
+    @property
+    def ema_model(self):
+        """A sampler holding the EMA weights (a second U-Net handle, refreshed when the EMA state has moved on)."""
+        from .diffusion import DenoisingDiffusion
+        from .unet import Unet
+
+        d = self.online_model
+        if self._ema_model is None:
+            cfg = d.model.cfg
+            unet = Unet(dim=cfg.dim, init_dim=cfg.init_dim, out_dim=cfg.out_dim, dim_mults=cfg.dim_mults, channels=cfg.channels,
+                        sinusoidal_pos_emb_theta=cfg.sinusoidal_pos_emb_theta, attn_dim_head=cfg.attn_dim_head,
+                        attn_heads=cfg.attn_heads, full_attn=cfg.full_attn, device=d.device)
+            self._ema_model = DenoisingDiffusion(
+                unet, image_size=d.image_size, timesteps=d.num_timesteps,
+                sampling_timesteps=d.sampling_timesteps if d.is_ddim_sampling else None, objective=d.objective,
+                ddim_sampling_eta=d.ddim_sampling_eta, auto_normalize=bool(d._unnormalize_flag), use_graph=d.use_graph)
+            self._ema_model._sched = d._sched
+        if self._ema_model_step != self.step:
+            if self.step == 0:
+                raise RuntimeError("EMA.update() has not run yet")
+            self._ema_model.model.load_state_dict(d.model.state_dict(ema=True))
+            self._ema_model_step = self.step
+        return self._ema_model
+
+
+def train_step(diffusion, micro_batches: Iterable[torch.Tensor], *, lr=1e-4, betas=(0.9, 0.99), eps=1e-8,
+               max_grad_norm=1.0, ema: Optional[EMA] = None, t=None, noise=None):
+    """One iteration of ``Trainer.train`` (:1164-1190).  ``micro_batches``: the ``gradient_accumulate_every`` image batches
+    (in [0, 1]) of the iteration.  ``t`` / ``noise`` (lists, one per micro-batch) inject the random draws for tests.
+    Returns (total_loss, grad_norm)."""
+    batches = list(micro_batches)
+    k = len(batches)
+    total = 0.0
+    for i, data in enumerate(batches):
+        x = diffusion.normalize(data.to(diffusion.device, torch.float32))
+        ti = t[i] if t is not None else torch.randint(0, diffusion.num_timesteps, (x.shape[0],)).long()
+        ni = noise[i] if noise is not None else None
+        total += float(diffusion.p_losses(x, ti, noise=ni, loss_scale=1.0 / k, accumulate=i > 0))
+    norm = diffusion.model.optimizer_step(lr=lr, betas=betas, eps=eps, max_grad_norm=max_grad_norm)
+    if ema is not None:
+        ema.update()
+    return total, norm

@@ -174,6 +174,47 @@ class Unet:
     def grads(self) -> Dict[str, torch.Tensor]:
         return {name: self.grad(name) for name, _ in self.param_spec()}
 
+    def optimizer_step(self, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=1.0) -> float:
+        """``clip_grad_norm_(max_grad_norm)`` + ``Adam(lr, betas).step()`` of ``Trainer.train``
+        (denoising_diffusion.py:1006, :1178-1183) on the device-resident parameters; every packed weight buffer is then
+        rebuilt on the device.  Returns the total gradient norm (before clipping)."""
+        norm = C.c_float(0.0)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.dm_unet_optimizer_step(self._handle, lr, betas[0], betas[1], eps,
+                                                    max_grad_norm if max_grad_norm else 0.0, C.byref(norm), stream))
+        return float(norm.value)
+
+    def ema_update(self, decay: float, copy: bool = False):
+        """``ema = ema * decay + online * (1 - decay)`` (or a copy) on the device-resident EMA parameters."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.dm_unet_ema_update(self._handle, float(decay), int(bool(copy)), stream))
+
+    def state_dict(self, ema: bool = False) -> Dict[str, torch.Tensor]:
+        """The trained parameters (reference names / shapes) from the device-resident state; ``ema=True``: the EMA copy."""
+        if not getattr(self, "_training", False):
+            raise RuntimeError("state_dict() reads the device-resident training state: call train() first")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        out = {}
+        for name, shape in self.param_spec():
+            t = torch.empty(tuple(shape), device=self.device, dtype=torch.float32)
+            _lib.check(self._lib.dm_unet_get_param(self._handle, name.encode(), 1 if ema else 0, _lib.ptr(t), stream))
+            out[name] = t
+        return out
+
+    def sync(self):
+        """Make the sampling path of THIS handle see the trained weights (device -> host -> re-pack)."""
+        _lib.check(self._lib.dm_unet_train_sync(self._handle))
+        return self
+
+    def check_device_pack(self) -> int:
+        """Self-check of the device-side weight packers against the host packers: number of differing buffers."""
+        n = self._lib.dm_unet_check_device_pack(self._handle)
+        if n < 0:
+            _lib.check(1)
+        if n > 0:
+            print(self._lib.dm_last_error().decode(errors="replace"))
+        return n
+
     # -- forward ---------------------------------------------------------------------------
     def _ctx(self, text_emb: Optional[torch.Tensor], batch: int):
         if text_emb is None or not self.text_condition:

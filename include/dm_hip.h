@@ -307,14 +307,31 @@ int64_t dm_unet_grad_floats(dm_unet* u);
 int dm_unet_get_grad(dm_unet* u, const char* name, float* out_dev, void* stream);
 /* One p_losses call (:823-889) + backward:
  *   x = q_sample(x_start, t, noise) (:813-821);  out = Unet(x, t);  target per `objective` (DM_OBJ_*, :864-872);
- *   loss = mean_b( loss_weight[t_b] * mean((out - target)^2) ) (:874-878, :889);  every parameter gradient of the loss.
+ *   loss = loss_scale * mean_b( loss_weight[t_b] * mean((out - target)^2) ) (:874-878, :889);  every parameter gradient.
  * x_start, noise: (B, C, H, W) device, x_start already normalised to [-1, 1];  t_host: (B) timesteps;
  * coef_host: (B, 4) = sqrt_alphas_cumprod[t_b], sqrt_one_minus_alphas_cumprod[t_b], loss_weight[t_b], 0 -- the values
- * `extract` gathers (:394-397);  loss_out_host receives the scalar loss;  model_out (optional, device) the U-Net output.
- * The call synchronises the stream. */
+ * `extract` gathers (:394-397).  loss_scale = 1 / gradient_accumulate_every and accumulate != 0 adds the gradients to
+ * what the buffers hold (the micro-batch loop of Trainer.train, :1164-1176).  loss_out_host receives the scalar loss;
+ * model_out (optional, device) the U-Net output.  The call synchronises the stream. */
 int dm_unet_loss_backward(dm_unet* u, const float* x_start, const int64_t* t_host, const float* coef_host,
-                          const float* noise, int objective, float* loss_out_host, float* model_out, int B, int H, int W,
-                          void* stream);
+                          const float* noise, int objective, float loss_scale, int accumulate, float* loss_out_host,
+                          float* model_out, int B, int H, int W, void* stream);
+/* The rest of one Trainer.train iteration (:1178-1190) on device-resident state: the master parameters, the Adam moments and
+ * the EMA copy live in flat device buffers in the reference layouts; after the update every packed weight buffer the
+ * kernels read is rebuilt on the device (pack_kernels.hip, bit-identical to the host packers).
+ *   dm_unet_optimizer_step: clip_grad_norm_(max_grad_norm; <= 0: off), Adam(lr, (beta1, beta2), eps) step; the total
+ *                           gradient norm (before clipping) goes to grad_norm_out_host when given.
+ *   dm_unet_ema_update:     copy != 0: ema <- online;  else ema <- ema * decay + online * (1 - decay)
+ *   dm_unet_get_param:      one parameter of the online (which = 0) or EMA (which = 1) state into a device buffer
+ *   dm_unet_train_sync:     device -> host copies + dm_unet_refresh, after which the handle samples with the trained weights
+ *                           (the sampling entry points refuse to run on stale fused packs until then)
+ *   dm_unet_check_device_pack: self-check, number of packed buffers whose device packer differs from the host packer */
+int dm_unet_optimizer_step(dm_unet* u, float lr, float beta1, float beta2, float eps, float max_grad_norm,
+                           float* grad_norm_out_host, void* stream);
+int dm_unet_ema_update(dm_unet* u, float decay, int copy, void* stream);
+int dm_unet_get_param(dm_unet* u, const char* name, int which, float* out_dev, void* stream);
+int dm_unet_train_sync(dm_unet* u);
+int dm_unet_check_device_pack(dm_unet* u);
 /* q_sample (:813-821) on its own: out = coef[b][0] * x_start + coef[b][1] * noise, coef_host (B, 4) as above */
 int dm_op_q_sample(const float* x_start, const float* noise, const float* coef_host, float* out, int B, int per_sample,
                    void* stream);

@@ -68,3 +68,96 @@ def test_forward_draws_t_and_noise(golden_train):
     torch.manual_seed(3)
     l2 = float(d(b["img"]))
     assert l1 == l2 and 0.0 < l1 < 10.0  # reproducible under torch.manual_seed, like the reference
+
+
+def test_device_packers_match_host_packers():
+    """The training loop re-packs every weight buffer on the device after an optimiser step (pack_kernels.hip); each device
+    packer must reproduce its host packer bit for bit, for the forward layers and the input-gradient layers."""
+    for cfg, salt in ((UnetConfig(), 0), (UnetConfig(dim=32, dim_mults=(1, 2), channels=3), 41)):
+        d = _model(cfg, salt, "pred_noise", 1000)
+        assert d.model.check_device_pack() == 0
+
+
+def _oracle_steps(cfg, sd, sched, batches, ts, noises, lr, n_steps, accumulate):
+    """The reference loop on the CPU: autograd through the oracle, clip_grad_norm_(1.0), torch.optim.Adam."""
+    from oracle import train_oracle as to
+
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(params.values()), lr=lr, betas=(0.9, 0.99))
+    losses, norms = [], []
+    for s in range(n_steps):
+        opt.zero_grad()
+        total = 0.0
+        for i in range(accumulate):
+            j = s * accumulate + i
+            loss = to.p_losses(params, cfg, sched, batches[j] * 2 - 1, ts[j], noises[j]) / accumulate
+            loss.backward()
+            total += float(loss)
+        norms.append(float(torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)))
+        opt.step()
+        losses.append(total)
+    return {k: v.detach() for k, v in params.items()}, losses, norms
+
+
+@pytest.mark.parametrize("accumulate", [1, 2])
+def test_training_steps_vs_torch_adam(accumulate):
+    """Three iterations of Trainer.train's loop (:1164-1183) -- micro-batches, clip_grad_norm_(1.0), Adam(lr, (0.9, 0.99)) --
+    on the device-resident state, against the same loop in torch on the CPU (oracle autograd): losses, gradient norms and
+    every parameter after the last step.  Exercises the device-side re-packing between steps."""
+    cfg = UnetConfig(dim=64, dim_mults=(1, 2), channels=3)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=42)
+    n_steps, B, lr = 3, 4, 1e-3
+    g = torch.Generator().manual_seed(77)
+    n = n_steps * accumulate
+    batches = [torch.rand((B, 3, 16, 16), generator=g) for _ in range(n)]
+    ts = [torch.randint(0, 1000, (B,), generator=g) for _ in range(n)]
+    noises = [torch.randn((B, 3, 16, 16), generator=g) for _ in range(n)]
+    torch.set_num_threads(8)
+    want, want_losses, want_norms = _oracle_steps(cfg, sd, dm.make_schedule(1000, "linear"), batches, ts, noises, lr, n_steps,
+                                                  accumulate)
+    d = _model(cfg, 42, "pred_noise", 1000)
+    for s in range(n_steps):
+        sl = slice(s * accumulate, (s + 1) * accumulate)
+        loss, norm = dm.train_step(d, batches[sl], lr=lr, t=ts[sl], noise=noises[sl])
+        print("step", s, "loss", loss, want_losses[s], "grad norm", norm, want_norms[s])
+        assert abs(loss - want_losses[s]) <= 2e-4 * abs(want_losses[s])
+        assert abs(norm - want_norms[s]) <= 1e-3 * want_norms[s]
+    got = d.model.state_dict()
+    worst = max((rel_l2(got[k].cpu(), want[k]), k) for k in want)
+    print("worst parameter after", n_steps, "steps:", worst)
+    # Adam divides by sqrt(v): where a gradient is ~0 the update direction is ill-conditioned, so the bound is on the
+    # parameter (which moved by ~lr per step), not on the update
+    assert worst[0] < 2e-4
+
+
+def test_ema_and_sync_and_sampling_from_trained_weights():
+    """EMA copy / lerp on the device, dm_unet_train_sync, and sampling with the trained weights: the handle that trained
+    and a fresh handle loaded with its state_dict() give the same DDIM samples."""
+    from oracle import sampler_oracle as so
+
+    cfg = UnetConfig(dim=64, dim_mults=(1, 2), channels=3)
+    d = _model(cfg, 42, "pred_noise", 1000)
+    ema = dm.EMA(d, beta=0.995, update_every=1, update_after_step=1)
+    g = torch.Generator().manual_seed(5)
+    hist = []
+    for s in range(4):
+        dm.train_step(d, [torch.rand((4, 3, 16, 16), generator=g)], lr=1e-3, ema=ema)
+        hist.append({k: v.clone() for k, v in d.model.state_dict().items()})
+    # ema_pytorch schedule: steps 0, 1 copy (step <= update_after_step), step 2 copies once more (first update after the
+    # threshold initialises), step 3 lerps with decay(step=4) = 1 - (1 + 2)^(-2/3)
+    decay = 1 - (1 + 2) ** (-2 / 3)
+    got = d.model.state_dict(ema=True)
+    k = "downs.0.0.block1.proj.weight"
+    want = hist[2][k] * decay + hist[3][k] * (1 - decay)
+    assert rel_l2(got[k], want) < 1e-6
+    with pytest.raises(RuntimeError, match="dm_unet_train_sync"):
+        d.ddim_sample((2, 3, 16, 16), sampling_timesteps=2, noise=so.NoiseStream(3))
+    d.model.sync()
+    a = d.ddim_sample((2, 3, 16, 16), sampling_timesteps=2, noise=so.NoiseStream(3))
+    fresh = dm.Unet(dim=64, dim_mults=(1, 2), channels=3, device=DEV)
+    fresh.load_state_dict(d.model.state_dict())
+    b = dm.DenoisingDiffusion(fresh, image_size=16, timesteps=1000).ddim_sample((2, 3, 16, 16), sampling_timesteps=2,
+                                                                                noise=so.NoiseStream(3))
+    assert torch.equal(a, b)
+    e = ema.ema_model.ddim_sample((2, 3, 16, 16), sampling_timesteps=2, noise=so.NoiseStream(3))
+    assert e.shape == a.shape and bool(torch.isfinite(e).all()) and not torch.equal(e, a)
