@@ -313,6 +313,23 @@ struct dm_unet {
         done_recorded = true;
         return 0;
     }
+    // Independent branches of a step (res_conv next to block1, the time MLP next to init_conv) are enqueued on a second
+    // stream between a fork and a join event, eagerly and inside the captured step graph alike: at small per-GPU batches no
+    // kernel fills the chip and the branch costs nothing.  Events come from a pool (distinct objects within one capture).
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_next = 0;
+    int next_event(hipEvent_t* e) {
+        if (ev_pool.size() < 64) {
+            hipEvent_t n = nullptr;
+            DM_CHECK_HIP(hipEventCreateWithFlags(&n, hipEventDisableTiming));
+            ev_pool.push_back(n);
+            *e = n;
+            return 0;
+        }
+        *e = ev_pool[ev_next++ % ev_pool.size()];
+        return 0;
+    }
     hipStream_t cap_stream = nullptr;  // capture / replay stream when the caller passes the legacy default stream
     int graph_captures = 0;            // diagnostics (dm_unet_graph_captures)
     void drop_graph() {
@@ -764,8 +781,40 @@ struct Ctx {
     int B;
     const float* ss;   // [Bt][ss_total]
     int ss_stride;     // 0 when one row serves the whole batch
+    bool par = false;  // independent branches go to the handle's second stream (fork / join below)
     bool dry() const { return A->dry; }
 };
+
+// fork: everything enqueued on the side stream from here on runs after what `c.s` holds now, next to what `c.s` gets next
+static int fork_side(Ctx& c, hipStream_t* side) {
+    dm_unet* u = c.u;
+    if (!u->side) DM_CHECK_HIP(hipStreamCreateWithFlags(&u->side, hipStreamNonBlocking));
+    hipEvent_t e;
+    if (u->next_event(&e)) return 1;
+    DM_CHECK_HIP(hipEventRecord(e, c.s));
+    DM_CHECK_HIP(hipStreamWaitEvent(u->side, e, 0));
+    *side = u->side;
+    return 0;
+}
+// join: what `c.s` gets next runs after everything the side stream holds
+static int join_side(Ctx& c) {
+    dm_unet* u = c.u;
+    hipEvent_t e;
+    if (u->next_event(&e)) return 1;
+    DM_CHECK_HIP(hipEventRecord(e, u->side));
+    DM_CHECK_HIP(hipStreamWaitEvent(c.s, e, 0));
+    return 0;
+}
+// Which steps fork.  Measured on MI355X (profiles/r3_fork_join_ab.txt, hipGraph replay): forking makes every batch SLOWER
+// -- B=8 @64x64 1.669 -> 1.753 ms per step, B=32 2.858 -> 2.924, B=64 @32x32 1.984 -> 2.042, B=256 4.551 -> 4.608 -- the
+// cross-queue dependencies of a forked graph (one signal wait per fork and per join, ~20 per step) cost more than the
+// overlap of a 17 us res_conv or the 20 us time-MLP chain buys.  So the default is OFF; DM_PAR=1 switches it on (the tests
+// run one model with it), DM_PAR_MAX_PIXELS limits it to small steps.
+static bool par_policy(int B, int H, int W) {
+    static const int mode = env_int("DM_PAR", 0);
+    static const int max_px = env_int("DM_PAR_MAX_PIXELS", 1 << 30);
+    return mode != 0 && (int64_t)B * H * W <= max_px;
+}
 
 // policy: which eligible layers take the Winograd kernel (DM_WINO=0 none, 1 all)
 static bool wino_use(int B, int Ho, int Wo, int Cout, int C0, int C1) {
@@ -985,29 +1034,43 @@ static int run_block(Ctx& c, const ConvLayer& L, const float* in0, const float* 
 // ResnetBlock.forward (DD/denoising_diffusion.py:136-148); x = cat(x0, x1)
 static int run_resnet(Ctx& c, const ResBlock& R, const float* x0, const float* x1, int H, int W, float** out) {
     size_t n = (size_t)c.B * H * W * R.dout;
+    const float* scale = c.ss ? c.ss + R.ss_off : nullptr;
+    // block2(h1) + res_conv(x).  When both convolutions leave partial sums for a landing pass anyway (several cout
+    // tiles under one RMSNorm, or K splits), one landing serves both: it finishes block2 and adds the res_conv partials.
+    static const bool merge = std::getenv("DM_NO_RES_MERGE") == nullptr;
+    PlannedConv P2, Pr;
+    bool merged = false;
+    if (R.has_res) {
+        if (plan_conv(c, R.c2, false, H, W, EPI_NORM | EPI_SILU, false, false, P2)) return 1;
+        if (plan_conv(c, R.res, x1 != nullptr, H, W, EPI_RESIDUAL, false, false, Pr)) return 1;
+        merged = merge && !P2.in_kernel && !Pr.in_kernel && Pr.kind != 4;
+    }
+    ResParts rp{};
+    float* rpart = nullptr;
+    bool forked = false;
+    if (merged) {
+        // res_conv reads only x: its partial sums are produced next to block1 (second stream) when the step forks
+        Ctx cs = c;
+        if (c.par && !c.dry()) {
+            if (fork_side(c, &cs.s)) return 1;
+            forked = true;
+        }
+        if (run_conv_partial(cs, R.res, x0, x1, H, W, &rpart, &rp.nsplit)) return 1;
+        rp.part = rpart;
+        rp.stride = (int64_t)n;
+        rp.bias = R.res.bias;
+    }
     float* h1 = c.A->alloc(n);
     float* h2 = c.A->alloc(n);
-    const float* scale = c.ss ? c.ss + R.ss_off : nullptr;
     if (run_block(c, R.c1, x0, x1, H, W, R.g1, scale, nullptr, h1)) return 1;
+    if (forked && join_side(c)) return 1;
     if (!R.has_res) {
         if (run_block(c, R.c2, h1, nullptr, H, W, R.g2, nullptr, x0, h2)) return 1;
         c.A->release(h1);
         *out = h2;
         return 0;
     }
-    // block2(h1) + res_conv(x).  When both convolutions leave partial sums for a landing pass anyway (several cout
-    // tiles under one RMSNorm, or K splits), one landing serves both: it finishes block2 and adds the res_conv partials.
-    static const bool merge = std::getenv("DM_NO_RES_MERGE") == nullptr;
-    PlannedConv P2, Pr;
-    if (plan_conv(c, R.c2, false, H, W, EPI_NORM | EPI_SILU, false, false, P2)) return 1;
-    if (plan_conv(c, R.res, x1 != nullptr, H, W, EPI_RESIDUAL, false, false, Pr)) return 1;
-    if (merge && !P2.in_kernel && !Pr.in_kernel && Pr.kind != 4) {
-        ResParts rp{};
-        float* rpart = nullptr;
-        if (run_conv_partial(c, R.res, x0, x1, H, W, &rpart, &rp.nsplit)) return 1;
-        rp.part = rpart;
-        rp.stride = (int64_t)n;
-        rp.bias = R.res.bias;
+    if (merged) {
         if (run_block(c, R.c2, h1, nullptr, H, W, R.g2, nullptr, nullptr, h2, &rp)) return 1;
         c.A->release(rpart);
         c.A->release(h1);
@@ -1145,49 +1208,56 @@ static int unet_forward_impl(dm_unet* u, Arena& A, const float* x_nchw, const in
     float* e1 = A.alloc((size_t)Rt * td);
     float* temb = A.alloc((size_t)B * td);
     float* ss = A.alloc((size_t)Bt * u->ss_total);
+    // The time embedding (sinusoid, time_mlp, every ResnetBlock.mlp: 4+ dependent launches) does not depend on x: when the
+    // step forks it runs on the second stream next to init_conv.  Nothing it allocates is released before the join.
+    c.par = !A.dry && par_policy(B, H, W);
+    hipStream_t ts = s;
+    if (c.par && fork_side(c, &ts)) return 1;
     if (!A.dry) {
-        if (launch_sinusoid(t_dev, step_times, step_dev, u->freqs, e0, Rt, cfg.dim / 2, s)) return 1;
-        if (launch_linear_rows(e0, cfg.dim, u->tw1, u->tb1, e1, td, Rt, cfg.dim, td, 0, 2, s)) return 1;
-        if (launch_linear_rows(e1, td, u->tw2, u->tb2, temb, td, Rt, td, td, 0, 0, s)) return 1;
+        if (launch_sinusoid(t_dev, step_times, step_dev, u->freqs, e0, Rt, cfg.dim / 2, ts)) return 1;
+        if (launch_linear_rows(e0, cfg.dim, u->tw1, u->tb1, e1, td, Rt, cfg.dim, td, 0, 2, ts)) return 1;
+        if (launch_linear_rows(e1, td, u->tw2, u->tb2, temb, td, Rt, td, td, 0, 0, ts)) return 1;
     }
     const float* tfinal = temb;
+    float *cat = nullptr, *tf0 = nullptr;
     if (text_concat) {
         // t = text_concat_proj(cat(t, text_proj(text_emb)))  (:146-152); ctx is (B, 1, E) or (B, E)
         DM_REQUIRE(ctx_tokens == 1, "text concat conditioning takes one pooled embedding per sample");
-        float* cat = A.alloc((size_t)B * 2 * td);
-        float* tf0 = A.alloc((size_t)B * td);
+        cat = A.alloc((size_t)B * 2 * td);
+        tf0 = A.alloc((size_t)B * td);
         float* t2 = A.alloc((size_t)B * td);
         if (!A.dry) {
             // left half: the time embedding of every row (one broadcast launch when the batch shares t)
             if (Rt == 1) {
-                if (launch_broadcast_rows(temb, cat, B, td, 2 * td, s)) return 1;
+                if (launch_broadcast_rows(temb, cat, B, td, 2 * td, ts)) return 1;
             } else {
                 DM_CHECK_HIP(hipMemcpy2DAsync(cat, 2 * td * sizeof(float), temb, td * sizeof(float),
-                                              td * sizeof(float), B, hipMemcpyDeviceToDevice, s));
+                                              td * sizeof(float), B, hipMemcpyDeviceToDevice, ts));
             }
-            if (launch_linear_rows(ctx, cfg.text_emb_dim, u->tp_w0, u->tp_b0, tf0, td, B, cfg.text_emb_dim, td, 0, 2, s))
+            if (launch_linear_rows(ctx, cfg.text_emb_dim, u->tp_w0, u->tp_b0, tf0, td, B, cfg.text_emb_dim, td, 0, 2, ts))
                 return 1;
-            if (launch_linear_rows(tf0, td, u->tp_w2, u->tp_b2, cat + td, 2 * td, B, td, td, 0, 0, s)) return 1;
-            if (launch_linear_rows(cat, 2 * td, u->tc_w, u->tc_b, t2, td, B, 2 * td, td, 0, 0, s)) return 1;
+            if (launch_linear_rows(tf0, td, u->tp_w2, u->tp_b2, cat + td, 2 * td, B, td, td, 0, 0, ts)) return 1;
+            if (launch_linear_rows(cat, 2 * td, u->tc_w, u->tc_b, t2, td, B, 2 * td, td, 0, 0, ts)) return 1;
         }
         tfinal = t2;
-        A.release(cat);
-        A.release(tf0);
     }
     if (!A.dry) {
         // every ResnetBlock.mlp (SiLU -> Linear) in one launch
-        if (launch_linear_rows(tfinal, td, u->ss_w, u->ss_b, ss, u->ss_total, Bt, td, u->ss_total, 1, 0, s)) return 1;
+        if (launch_linear_rows(tfinal, td, u->ss_w, u->ss_b, ss, u->ss_total, Bt, td, u->ss_total, 1, 0, ts)) return 1;
     }
-    if (tfinal != temb) A.release(tfinal);
-    A.release(e0);
-    A.release(e1);
-    A.release(temb);
     c.ss = A.dry ? reinterpret_cast<const float*>(16) : ss;  // non-null marker in dry mode
     c.ss_stride = Bt == 1 ? 0 : u->ss_total;
 
     const int n_st = cfg.n_stages;
     float* x = A.alloc((size_t)B * H * W * u->init_dim);
     if (run_conv(c, u->init_conv, x_nchw, nullptr, H, W, x, 0, nullptr, nullptr, nullptr, /*in_nchw=*/true)) return 1;
+    if (c.par && join_side(c)) return 1;
+    if (cat) A.release(cat);
+    if (tf0) A.release(tf0);
+    if (tfinal != temb) A.release(tfinal);
+    A.release(e0);
+    A.release(e1);
+    A.release(temb);
     const float* r = x;  // Unet.forward's `r = x.clone()`: read again by final_res_block, never released before
     auto rel = [&](const float* t) {
         if (t != r) A.release(t);
@@ -1381,6 +1451,8 @@ void dm_unet_destroy(dm_unet* u) {
     if (u->train) free_train(u);
     u->drop_graph();
     if (u->cap_stream) (void)hipStreamDestroy(u->cap_stream);
+    if (u->side) (void)hipStreamDestroy(u->side);
+    for (hipEvent_t e : u->ev_pool) (void)hipEventDestroy(e);
     if (u->done_ev) (void)hipEventDestroy(u->done_ev);
     if (u->ws) (void)hipFree(u->ws);
     if (u->state_dev) (void)hipFree(u->state_dev);

@@ -346,6 +346,9 @@ int launch_colsum_nchw(const float* dy, int B, int C, int HW, float* out, int ac
 int launch_act_fwd(const float* x, float* y, int64_t n, int act, hipStream_t s);  // 1 SiLU, 2 GELU (erf)
 int launch_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, hipStream_t s);
 int launch_add3(const float* a, const float* b, const float* c, float* y, int64_t n, hipStream_t s);
+// out = x * mask / (1 - p) [+ add], mask from Philox (seed, stream, element / 4); x == nullptr: the mask factor itself
+int launch_dropout(const float* x, const float* add, float* out, int64_t n, float p, uint64_t seed, uint64_t stream,
+                   hipStream_t s);
 int launch_depth_to_space(const float* t, const float* add, float* dx, int B, int Ho, int Wo, int C, hipStream_t s);
 int launch_pool2x2_sum(const float* du, const float* add, float* dx, int B, int H, int W, int C, hipStream_t s);
 int launch_pointwise_small_dgrad(const float* dy_nchw, const float* w_oc, float* dx, int64_t pixels, int C, int Cout, int HW,

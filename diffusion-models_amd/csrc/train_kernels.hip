@@ -331,6 +331,43 @@ int launch_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int ac
     return 0;
 }
 
+// nn.Dropout(p) of Block.forward in training mode (DD/denoising_diffusion.py:111,121): out = x * keep / (1 - p) [+ add],
+// keep ~ Bernoulli(1 - p) from Philox4x32-10 keyed by (seed, stream, element index / 4).  The backward pass applies the
+// SAME mask to the gradient, recomputed from the key (nothing is stored).  x == nullptr writes the mask factor itself.
+__device__ __forceinline__ void philox4(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+__global__ void dropout_kernel(const float* __restrict__ x, const float* __restrict__ add, float* __restrict__ out, int64_t n4,
+                               float p, float inv_keep, uint64_t seed, uint64_t stream) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+    philox4(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    f32x4 v = x ? reinterpret_cast<const f32x4*>(x)[i] : make_f32x4(1.f, 1.f, 1.f, 1.f);
+    float* q = reinterpret_cast<float*>(&v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = ((float)c[j] * 2.3283064365386963e-10f >= p) ? q[j] * inv_keep : 0.f;
+    if (add) v += reinterpret_cast<const f32x4*>(add)[i];
+    reinterpret_cast<f32x4*>(out)[i] = v;
+}
+int launch_dropout(const float* x, const float* add, float* out, int64_t n, float p, uint64_t seed, uint64_t stream,
+                   hipStream_t s) {
+    DM_REQUIRE(n % 4 == 0 && p >= 0.f && p < 1.f, "dropout: length must be a multiple of 4, 0 <= p < 1");
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, add, out, n / 4, p,
+                       1.0f / (1.0f - p), seed, stream);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // y = a + b (+ c)
 __global__ void add3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
                             float* __restrict__ y, int64_t n4) {

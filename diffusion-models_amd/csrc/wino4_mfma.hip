@@ -45,7 +45,7 @@ namespace dm {
 
 static constexpr int W4CK = 8;      // input channels per K chunk
 static constexpr int W4TILES = 16;  // 4x4-pixel tiles per workgroup
-static constexpr int W4WTS = 64;    // row stride (floats) of the epilogue staging tiles
+static constexpr int W4WTS = 68;    // row stride (floats) of the epilogue staging tiles: 4 rows = 16 banks, so the two kq of a 32-lane pass hit different banks
 
 
 // geometry classes: LTW = log2(tiles across); whole images per workgroup below 16 pixels across

@@ -72,6 +72,7 @@ class Unet:
         )
         cfg = self.cfg
         self.channels = channels
+        self.dropout = float(dropout)  # nn.Dropout(p) of every Block: training mode only (eval / sampling: identity)
         self.self_condition = self_condition
         self.out_dim = cfg.out_dim_
         self.text_condition = text_condition
@@ -160,7 +161,17 @@ class Unet:
             if self.text_condition or self.self_condition or self.cfg.cond_channels:
                 raise NotImplementedError("the HIP training step covers the unconditional U-Net")
             _lib.check(self._lib.dm_unet_train_enable(self._handle))
+            if not getattr(self, "_training", False):
+                self.set_dropout_seed(int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()))
             self._training = True
+        return self
+
+    def set_dropout_seed(self, seed: int, p: Optional[float] = None):
+        """Philox key of the dropout masks of the training step (default: drawn from torch's global generator at the first
+        ``train()``); ``p`` overrides the constructor's ``dropout``.  Every loss / backward call draws fresh masks."""
+        if p is not None:
+            self.dropout = float(p)
+        _lib.check(self._lib.dm_unet_train_dropout(self._handle, self.dropout, C.c_uint64(int(seed))))
         return self
 
     def grad(self, name: str) -> torch.Tensor:

@@ -332,6 +332,14 @@ int dm_unet_ema_update(dm_unet* u, float decay, int copy, void* stream);
 int dm_unet_get_param(dm_unet* u, const char* name, int which, float* out_dev, void* stream);
 int dm_unet_train_sync(dm_unet* u);
 int dm_unet_check_device_pack(dm_unet* u);
+/* nn.Dropout(p) of the Blocks in training mode (Unet(dropout = p), :111,121; the shipped ddpm_cifar.yaml trains with 0.1).
+ * Masks are Philox4x32-10 draws keyed by (seed, call, block index): every dm_unet_loss_backward call after this one draws
+ * fresh masks; the backward pass re-creates the masks of its forward from the key.  The VALUES differ from torch's
+ * generator, the semantics (Bernoulli(1 - p) keep, scale 1 / (1 - p), after the activation, before the residual add) do not.
+ * dm_op_dropout_mask writes the factor (0 or 1 / (1 - p)) the block_index-th Block (forward order) of call number `call`
+ * applies, n elements in (B, H, W, C) order -- parity tests hand these masks to the oracle. */
+int dm_unet_train_dropout(dm_unet* u, float p, uint64_t seed);
+int dm_op_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t call, int block_index, void* stream);
 /* q_sample (:813-821) on its own: out = coef[b][0] * x_start + coef[b][1] * noise, coef_host (B, 4) as above */
 int dm_op_q_sample(const float* x_start, const float* noise, const float* coef_host, float* out, int B, int per_sample,
                    void* stream);

@@ -52,25 +52,28 @@ def time_mlp(sd: SD, p: str, t: torch.Tensor, dim: int, theta: float) -> torch.T
     return F.linear(e, sd[p + "time_mlp.3.weight"], sd[p + "time_mlp.3.bias"])
 
 
-def block(sd: SD, p: str, x: torch.Tensor, scale_shift=None) -> torch.Tensor:
-    """DD/denoising_diffusion.py:113-122: conv3x3 -> RMSNorm -> x*(scale+1)+shift -> SiLU."""
+def block(sd: SD, p: str, x: torch.Tensor, scale_shift=None, drop=None) -> torch.Tensor:
+    """DD/denoising_diffusion.py:113-122: conv3x3 -> RMSNorm -> x*(scale+1)+shift -> SiLU -> dropout.
+    ``drop`` (training mode only): the dropout factor per element, 0 or 1 / (1 - p), injected so that two
+    implementations can be compared on the same mask (nn.Dropout draws it from torch's generator)."""
     x = F.conv2d(x, sd[p + ".proj.weight"], sd[p + ".proj.bias"], padding=1)
     x = rms_norm(x, sd[p + ".norm.g"])
     if scale_shift is not None:
         scale, shift = scale_shift
         x = x * (scale + 1) + shift
-    return F.silu(x)
+    x = F.silu(x)
+    return x if drop is None else x * drop
 
 
-def resnet_block(sd: SD, p: str, x: torch.Tensor, t_emb: Optional[torch.Tensor]) -> torch.Tensor:
-    """DD/denoising_diffusion.py:136-148."""
+def resnet_block(sd: SD, p: str, x: torch.Tensor, t_emb: Optional[torch.Tensor], drops=None) -> torch.Tensor:
+    """DD/denoising_diffusion.py:136-148.  ``drops``: iterator of dropout factors, one per Block in forward order."""
     ss = None
     if t_emb is not None and (p + ".mlp.1.weight") in sd:
         e = F.linear(F.silu(t_emb), sd[p + ".mlp.1.weight"], sd[p + ".mlp.1.bias"])
         e = e[:, :, None, None]
         ss = e.chunk(2, dim=1)
-    h = block(sd, p + ".block1", x, ss)
-    h = block(sd, p + ".block2", h)
+    h = block(sd, p + ".block1", x, ss, next(drops) if drops is not None else None)
+    h = block(sd, p + ".block2", h, None, next(drops) if drops is not None else None)
     if (p + ".res_conv.weight") in sd:
         x = F.conv2d(x, sd[p + ".res_conv.weight"], sd[p + ".res_conv.bias"])
     return h + x
@@ -173,8 +176,12 @@ def unet_forward(
     text_emb: Optional[torch.Tensor] = None,
     cond: Optional[torch.Tensor] = None,
     prefix: str = "",
+    dropout_masks=None,
 ) -> torch.Tensor:
-    """DD/denoising_diffusion.py:349-390; text hooks
+    """``dropout_masks`` (training mode): an iterable of dropout factors, one (B, C, H, W) tensor per Block in forward
+    order, injected instead of nn.Dropout's own draws.
+
+    DD/denoising_diffusion.py:349-390; text hooks
     DD/denoising_diffusion_text_conditional.py:131-214; the image-conditional
     variant concatenates ``cond`` in front of init_conv
     (DD/denoising_diffusion_image_conditional.py:51-55).
@@ -182,6 +189,7 @@ def unet_forward(
     ``cfg`` is a ``UnetConfig``-like object (dim, dim_mults, attn_heads, ...).
     """
     p = prefix
+    drops = iter(dropout_masks) if dropout_masks is not None else None
     f = cfg.downsample_factor
     assert all(d % f == 0 for d in x.shape[-2:]), (
         f"your input dimensions {tuple(x.shape[-2:])} need to be divisible by {f}, given the unet"
@@ -214,9 +222,9 @@ def unet_forward(
     for i in range(n):
         last = i >= n - 1
         q = f"{p}downs.{i}"
-        x = resnet_block(sd, q + ".0", x, t)
+        x = resnet_block(sd, q + ".0", x, t, drops)
         skips.append(x)
-        x = resnet_block(sd, q + ".1", x, t)
+        x = resnet_block(sd, q + ".1", x, t, drops)
         a = full_attention if full[i] else linear_attention
         x = a(sd, q + ".2", x, heads, dh) + x
         skips.append(x)
@@ -227,11 +235,11 @@ def unet_forward(
 
     if use_text and cfg.use_cross_attn:
         x = _apply_cross(sd, p + "cross_attn_down", x, text_emb)
-    x = resnet_block(sd, p + "mid_block1", x, t)
+    x = resnet_block(sd, p + "mid_block1", x, t, drops)
     if use_text and cfg.use_cross_attn:
         x = _apply_cross(sd, p + "cross_attn", x, text_emb)
     x = full_attention(sd, p + "mid_attn", x, heads, dh) + x
-    x = resnet_block(sd, p + "mid_block2", x, t)
+    x = resnet_block(sd, p + "mid_block2", x, t, drops)
     if use_text and cfg.use_cross_attn:
         x = _apply_cross(sd, p + "cross_attn_up", x, text_emb)
 
@@ -239,9 +247,9 @@ def unet_forward(
         last = j == n - 1
         q = f"{p}ups.{j}"
         x = torch.cat((x, skips.pop()), dim=1)
-        x = resnet_block(sd, q + ".0", x, t)
+        x = resnet_block(sd, q + ".0", x, t, drops)
         x = torch.cat((x, skips.pop()), dim=1)
-        x = resnet_block(sd, q + ".1", x, t)
+        x = resnet_block(sd, q + ".1", x, t, drops)
         a = full_attention if full[n - 1 - j] else linear_attention
         x = a(sd, q + ".2", x, heads, dh) + x
         if not last:
@@ -250,5 +258,5 @@ def unet_forward(
             x = F.conv2d(x, sd[q + ".3.weight"], sd[q + ".3.bias"], padding=1)
 
     x = torch.cat((x, r), dim=1)
-    x = resnet_block(sd, p + "final_res_block", x, t)
+    x = resnet_block(sd, p + "final_res_block", x, t, drops)
     return F.conv2d(x, sd[p + "final_conv.weight"], sd[p + "final_conv.bias"])

@@ -44,6 +44,12 @@ def test_model_goldens_with_the_alternative_kernels():
                      DM_NO_FUSED_LINATTN="1", DM_NO_ATTN16="1", DM_NO_INIT7="1"))
 
 
+def test_model_goldens_with_the_forked_step():
+    """... and with the second-stream fork of the step switched on (res_conv next to block1, the time MLP next to
+    init_conv; off by default because it measured slower, dm_api.hip: par_policy): eager and graph-replayed loops."""
+    _run_models(dict(DM_PAR="1"))
+
+
 def test_model_goldens_without_any_winograd():
     """... and with every Winograd-family kernel off (the direct implicit-GEMM kernel takes all 3x3 layers)."""
     _run_models(dict(DM_NO_WINOGRAD="1"))

@@ -161,3 +161,74 @@ def test_ema_and_sync_and_sampling_from_trained_weights():
     assert torch.equal(a, b)
     e = ema.ema_model.ddim_sample((2, 3, 16, 16), sampling_timesteps=2, noise=so.NoiseStream(3))
     assert e.shape == a.shape and bool(torch.isfinite(e).all()) and not torch.equal(e, a)
+
+
+def _block_shapes(cfg, side):
+    """(C, H, W) of every Block output in the order Unet.forward runs them (two per ResnetBlock)."""
+    dims = cfg.dims
+    n = cfg.num_stages
+    out = []
+    h = side
+    for i in range(n):
+        out += [(dims[i], h, h)] * 4
+        if i < n - 1:
+            h //= 2
+    out += [(dims[-1], h, h)] * 4  # mid_block1, mid_block2
+    for j in range(n):
+        out += [(dims[n - j], h, h)] * 4
+        if j < n - 1:
+            h *= 2
+    out += [(dims[0], h, h)] * 2  # final_res_block
+    return out
+
+
+def test_dropout_training_step_with_the_same_masks_as_the_oracle():
+    """Unet(dropout=0.1) as ddpm_cifar.yaml trains it: the library's Philox masks are exported (dm_op_dropout_mask) and
+    injected into the oracle's Blocks; loss and every gradient must then agree.  Also: a new call draws new masks, the same
+    seed reproduces a call, sampling (eval mode) ignores dropout."""
+    import ctypes as C
+
+    from diffusion_models_amd import _lib
+    from oracle import train_oracle as to
+
+    cfg = UnetConfig(dim=64, dim_mults=(1, 2), channels=3)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=42)
+    u = dm.Unet(dim=64, dim_mults=(1, 2), channels=3, dropout=0.1, device=DEV)
+    u.load_state_dict(sd)
+    d = dm.DenoisingDiffusion(u, image_size=16, timesteps=1000).train()
+    p, seed, B = 0.1, 987654321, 4
+    u.set_dropout_seed(seed)
+    g = torch.Generator().manual_seed(9)
+    x_start = torch.rand((B, 3, 16, 16), generator=g) * 2 - 1
+    t = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.randn((B, 3, 16, 16), generator=g)
+    loss0 = float(d.p_losses(x_start, t, noise=noise))
+    grads = d.model.grads()
+    lib = _lib.load()
+    masks = []
+    for k, (c, h, w) in enumerate(_block_shapes(cfg, 16)):
+        m = torch.empty((B, h, w, c), device=DEV)
+        _lib.check(lib.dm_op_dropout_mask(_lib.ptr(m), m.numel(), p, C.c_uint64(seed), C.c_uint64(0), k, None))
+        masks.append(m.permute(0, 3, 1, 2).contiguous().cpu())
+    keep = torch.cat([m.reshape(-1) for m in masks])
+    frac = float((keep > 0).float().mean())
+    assert abs(frac - 0.9) < 0.01 and bool(((keep == 0) | ((keep - 1 / 0.9).abs() < 1e-6)).all()), frac
+    torch.set_num_threads(8)
+    want_loss, want = to.loss_and_grads(sd, cfg, dm.make_schedule(1000, "linear"), x_start, t, noise, dropout_masks=masks)
+    print("dropout loss", loss0, want_loss)
+    assert abs(loss0 - want_loss) <= 1e-5 * abs(want_loss)
+    worst = max((rel_l2(grads[k].cpu(), want[k]), k) for k in want)
+    print("worst gradient with dropout", worst)
+    assert worst[0] < GRAD_TOL
+    loss1 = float(d.p_losses(x_start, t, noise=noise))      # next call: other masks
+    assert loss1 != loss0
+    u.set_dropout_seed(seed)
+    assert float(d.p_losses(x_start, t, noise=noise)) == loss0  # same key: same masks
+    from oracle import sampler_oracle as so
+
+    plain = dm.Unet(dim=64, dim_mults=(1, 2), channels=3, device=DEV)
+    plain.load_state_dict(sd)
+    a = d.ddim_sample((2, 3, 16, 16), sampling_timesteps=2, noise=so.NoiseStream(1))
+    b = dm.DenoisingDiffusion(plain, image_size=16, timesteps=1000).ddim_sample((2, 3, 16, 16), sampling_timesteps=2,
+                                                                                noise=so.NoiseStream(1))
+    assert torch.equal(a, b)  # eval-mode sampling: dropout is the identity
