@@ -163,17 +163,27 @@ __global__ void rowgrad_image_kernel(const float* __restrict__ part, int chunks,
     img[((size_t)b * 2) * C + c] = sg;
     img[((size_t)b * 2 + 1) * C + c] = sb;
 }
-__global__ void rowgrad_finish_kernel(const float* __restrict__ img, int B, int C, float* __restrict__ dg,
-                                      float* __restrict__ dbias, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// 256 threads = 64 channels x 4 lanes over the images, combined through LDS in a fixed order
+__global__ __launch_bounds__(256) void rowgrad_finish_kernel(const float* __restrict__ img, int B, int C, float* __restrict__ dg,
+                                                             float* __restrict__ dbias, int accumulate) {
+    __shared__ float red[2][4][64];
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + li;
     float sg = 0.f, sb = 0.f;
-    for (int b = 0; b < B; ++b) {
-        sg += img[((size_t)b * 2) * C + c];
-        sb += img[((size_t)b * 2 + 1) * C + c];
+    if (c < C)
+        for (int b = q; b < B; b += 4) {
+            sg += img[((size_t)b * 2) * C + c];
+            sb += img[((size_t)b * 2 + 1) * C + c];
+        }
+    red[0][q][li] = sg;
+    red[1][q][li] = sb;
+    __syncthreads();
+    if (q == 0 && c < C) {
+        sg = (red[0][0][li] + red[0][1][li]) + (red[0][2][li] + red[0][3][li]);
+        sb = (red[1][0][li] + red[1][1][li]) + (red[1][2][li] + red[1][3][li]);
+        if (dg) dg[c] = accumulate ? dg[c] + sg : sg;
+        if (dbias) dbias[c] = accumulate ? dbias[c] + sb : sb;
     }
-    if (dg) dg[c] = accumulate ? dg[c] + sg : sg;
-    if (dbias) dbias[c] = accumulate ? dbias[c] + sb : sb;
 }
 
 static int pow2ceil(int v) {
@@ -217,7 +227,7 @@ int launch_norm_act_bwd(const float* dy, const float* u, const float* g, const f
     hipLaunchKernelGGL(rowgrad_image_kernel, dim3((C + 63) / 64, B), dim3(64), 0, s, ws, p.chunks, C,
                        (flags & EPI_SCALE_SHIFT) ? dss : nullptr, dss_stride, img);
     DM_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(rowgrad_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, s, img, B, C, dg, dbias, accumulate);
+    hipLaunchKernelGGL(rowgrad_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, s, img, B, C, dg, dbias, accumulate);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -226,14 +236,19 @@ int launch_norm_act_bwd(const float* dy, const float* u, const float* g, const f
 // Column sums (bias gradients of convolutions that have no norm behind them): out[c] (+)= sum_r x[r * ld + c * cs].
 // Two passes: [blocks][C] partial sums, then the finish.
 // ---------------------------------------------------------------------------------------
-__global__ void colsum_partial_kernel(const float* __restrict__ x, int64_t rows, int C, int64_t row_stride, int64_t col_stride,
-                                      int rows_per_block, float* __restrict__ part) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// 256 threads = 64 columns x 4 row lanes
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t rows, int C, int64_t row_stride,
+                                                             int64_t col_stride, int rows_per_block, float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + li;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, rows);
     float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += x[r * row_stride + c * col_stride];
-    part[(size_t)blockIdx.y * C + c] = s;
+    if (c < C)
+        for (int64_t r = r0 + q; r < r1; r += 4) s += x[r * row_stride + c * col_stride];
+    red[q][li] = s;
+    __syncthreads();
+    if (q == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
 }
 __global__ void colsum_finish_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ out,
                                      int accumulate) {
@@ -265,7 +280,7 @@ int launch_colsum(const float* x, int64_t rows, int C, int64_t row_stride, int64
     const int blocks = colsum_blocks(rows);
     const int rpb = (int)((rows + blocks - 1) / blocks);
     const int nb = (int)((rows + rpb - 1) / rpb);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, nb), dim3(64), 0, s, x, rows, C, row_stride, col_stride,
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, nb), dim3(256), 0, s, x, rows, C, row_stride, col_stride,
                        rpb, ws);
     DM_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, nb, C, out, accumulate);

@@ -279,6 +279,62 @@ __global__ void wgrad_naive_kernel(const WgradNaive p) {
     p.partial[(size_t)blockIdx.y * n_out + i] = s;
 }
 
+// init_conv (DD/denoising_diffusion.py:262): x NCHW with a handful of channels, dy NHWC.  One workgroup = one kernel ROW
+// (c, ky) for a slice of the image rows; thread = output channel, KW accumulators: a dy value is loaded once (coalesced
+// over the channels) and meets the KW neighbouring x values (same address for all lanes).
+template <int KW>
+__global__ void wgrad_rows_nchw_kernel(const WgradNaive p) {
+    const int c = blockIdx.x / p.KH, ky = blockIdx.x % p.KH;
+    const int row0 = blockIdx.y * p.rows_per_split, row1 = min(row0 + p.rows_per_split, p.B * p.H);
+    for (int o = threadIdx.x; o < p.Cout; o += blockDim.x) {
+        float acc[KW];
+#pragma unroll
+        for (int k = 0; k < KW; ++k) acc[k] = 0.f;
+        for (int row = row0; row < row1; ++row) {
+            const int b = row / p.H, y = row - b * p.H;
+            const int sy = y + ky - p.pad;
+            if (sy < 0 || sy >= p.H) continue;
+            const float* xr = p.x + b * p.xs_b + c * p.xs_c + (int64_t)sy * p.W;
+            const float* dr = p.dy + ((int64_t)row * p.W) * p.Cout + o;
+            for (int x = 0; x < p.W; ++x) {
+                const float d = dr[(int64_t)x * p.Cout];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    const int sx = x + k - p.pad;
+                    acc[k] += d * ((sx >= 0 && sx < p.W) ? xr[sx] : 0.f);
+                }
+            }
+        }
+        float* q = p.partial + (size_t)blockIdx.y * p.Cout * p.Cin * p.KH * KW + (((size_t)o * p.Cin + c) * p.KH + ky) * KW;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) q[k] = acc[k];
+    }
+}
+// final_conv (:343): 1x1 with a handful of outputs, x NHWC, dy NCHW.  256 threads = 64 input channels x 4 pixel lanes.
+__global__ __launch_bounds__(256) void wgrad_thin_out_kernel(const WgradNaive p) {
+    __shared__ float red[4][4][64];
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + li;
+    const int64_t HW = (int64_t)p.H * p.W;
+    const int64_t px0 = (int64_t)blockIdx.y * p.rows_per_split * p.W, px1 = min(px0 + (int64_t)p.rows_per_split * p.W, p.B * HW);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < p.Cin)
+        for (int64_t px = px0 + q; px < px1; px += 4) {
+            const float xv = p.x[px * p.Cin + c];
+            const int64_t b = px / HW, r = px - b * HW;
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (o < p.Cout) acc[o] += xv * p.dy[(b * p.Cout + o) * HW + r];
+        }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) red[o][q][li] = acc[o];
+    __syncthreads();
+    if (q == 0 && c < p.Cin)
+        for (int o = 0; o < p.Cout; ++o)
+            p.partial[(size_t)blockIdx.y * p.Cout * p.Cin + (size_t)o * p.Cin + c] =
+                (red[o][0][li] + red[o][1][li]) + (red[o][2][li] + red[o][3][li]);
+}
+
 size_t wgrad_naive_ws_floats(int B, int H, int Cout, int Cin, int KH, int KW, int* splits_out) {
     const int rows = B * H;
     int splits = std::min(rows, 256);
@@ -302,7 +358,12 @@ int launch_wgrad_naive(const float* x, int x_nchw, const float* dy, int dy_nchw,
     (void)wgrad_naive_ws_floats(B, H, Cout, Cin, KH, KW, &splits);
     p.rows_per_split = (B * H + splits - 1) / splits;
     const int n_out = Cout * Cin * KH * KW;
-    hipLaunchKernelGGL(wgrad_naive_kernel, dim3((n_out + 127) / 128, splits), dim3(128), 0, s, p);
+    if (x_nchw && !dy_nchw && KW == 7)
+        hipLaunchKernelGGL(wgrad_rows_nchw_kernel<7>, dim3(Cin * KH, splits), dim3(64), 0, s, p);
+    else if (!x_nchw && dy_nchw && KH == 1 && KW == 1 && Cout <= 4)
+        hipLaunchKernelGGL(wgrad_thin_out_kernel, dim3((Cin + 63) / 64, splits), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(wgrad_naive_kernel, dim3((n_out + 127) / 128, splits), dim3(128), 0, s, p);
     DM_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 63) / 64, 1), dim3(256), 0, s, ws, splits, 1, (int64_t)n_out, dw,
                        accumulate);

@@ -92,7 +92,7 @@ def _oracle_steps(cfg, sd, sched, batches, ts, noises, lr, n_steps, accumulate):
             j = s * accumulate + i
             loss = to.p_losses(params, cfg, sched, batches[j] * 2 - 1, ts[j], noises[j]) / accumulate
             loss.backward()
-            total += float(loss)
+            total += float(loss.detach())
         norms.append(float(torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)))
         opt.step()
         losses.append(total)

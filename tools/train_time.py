@@ -29,3 +29,13 @@ for _ in range(args.steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
 print(f"loss+backward B={args.batch} {args.size}x{args.size}: {1e3 * dt:.2f} ms/step  {args.batch / dt:.1f} images/s  (loss {float(loss):.4f})")
+ema = dm.EMA(d, beta=0.995, update_every=10)
+dm.train_step(d, [img], lr=2e-4, ema=ema)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    loss, norm = dm.train_step(d, [img], lr=2e-4, ema=ema)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / args.steps
+print(f"full iteration (loss+backward, clip, Adam, device re-pack, EMA) B={args.batch}: {1e3 * dt:.2f} ms/step  "
+      f"{args.batch / dt:.1f} images/s  (loss {loss:.4f}, grad norm {norm:.3f})")
