@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=20, help="DDPM steps of the CPU baseline sample (config 1)")
     return ap.parse_args()
 
@@ -223,6 +224,64 @@ def other_configs(dev, replays: int = 100):
     dt = timed(lambda: d5.sample(batch_size=B, text_emb=emb, seed=1))
     out["config5_text64x64_ddim100_b32_per_gpu"] = {"ms_per_denoise_step": 1e3 * dt / S, "replays": S,
                                                     "images_per_s_per_gpu": B / (100 * dt / S)}
+    return out
+
+
+def train_leg(dev, with_cpu: bool, batch: int = 64, iters: int = 10):
+    """The training half of the caller of record, measured beside the headline: one iteration of
+    Trainer.train (DD/denoising_diffusion.py:1164-1190: p_losses + backward, clip_grad_norm_, Adam, ema.update) at the shipped
+    ddpm_cifar.yaml shape (32x32 U-Net dim 64, train_batch_size 64, dropout 0.1), all on the GPU with device-resident
+    parameters; and the same iteration through torch autograd on this box's host cores (the oracle, one iteration)."""
+    import torch
+
+    import diffusion_models_amd as dm
+    from diffusion_models_amd.spec import UnetConfig
+
+    cfg = UnetConfig(dim=64, dim_mults=(1, 2, 4, 8), channels=CHANNELS)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=0)
+    u = dm.Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=CHANNELS, dropout=0.1, device=dev)
+    u.load_state_dict(sd)
+    d = dm.DenoisingDiffusion(u, image_size=IMAGE, timesteps=T).train()
+    ema = dm.EMA(d, beta=0.995, update_every=10)
+    img = torch.rand(batch, CHANNELS, IMAGE, IMAGE, device=dev)
+    dm.train_step(d, [img], lr=2e-4, ema=ema)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        loss, norm = dm.train_step(d, [img], lr=2e-4, ema=ema)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    out = {"workload": f"Trainer.train iteration, 32x32 U-Net dim 64, batch {batch}, dropout 0.1, Adam + clip + EMA",
+           "ms_per_iteration": 1e3 * dt, "images_per_s": batch / dt, "iterations_timed": iters, "loss": loss, "grad_norm": norm}
+    del d, u, ema
+    if with_cpu:
+        from oracle import train_oracle as to
+
+        sched = dm.make_schedule(T, "linear")
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        threads = min(16, avail)
+        torch.set_num_threads(threads)
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        opt = torch.optim.Adam(list(params.values()), lr=2e-4, betas=(0.9, 0.99))
+        x = img.cpu() * 2 - 1
+        tt = torch.randint(0, T, (batch,))
+        nz = torch.randn(x.shape)
+
+        def one():
+            opt.zero_grad()
+            l = to.p_losses(params, cfg, sched, x, tt, nz)
+            l.backward()
+            torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+            opt.step()
+
+        one()  # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        one()
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"ms_per_iteration": 1e3 * cdt, "images_per_s": batch / cdt, "cores": threads, "kind": "port",
+                               "sample": "one iteration after one warm-up iteration, torch autograd through the oracle U-Net "
+                                         "(no dropout), clip_grad_norm_, torch.optim.Adam"}
+        out["gpu_over_cpu"] = cdt / dt
     return out
 
 
@@ -447,6 +506,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_other_configs:
         result["other_configs"] = other_configs(dev)
+    if rank == 0 and world == 1 and not args.no_train:
+        result["train_step"] = train_leg(dev, with_cpu=not args.no_cpu_baseline)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.cpu_steps)

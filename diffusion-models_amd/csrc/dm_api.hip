@@ -12,6 +12,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace dm {
@@ -344,6 +345,7 @@ struct dm_unet {
 namespace dm {
 
 void free_train(dm_unet* u);  // dm_train.inc
+static int ensure_packed(dm_unet* u, const float* w, hipStream_t s);
 static int build_train(dm_unet* u);
 static int upload_master_if_resident(dm_unet* u);
 
@@ -951,7 +953,8 @@ static int plan_conv(const Ctx& c, const ConvLayer& L, bool has_in1, int Hin, in
     return 0;
 }
 
-static int launch_planned(const PlannedConv& P, const ConvParams& q, hipStream_t s) {
+static int launch_planned(const PlannedConv& P, const ConvParams& q, hipStream_t s, dm_unet* u = nullptr) {
+    if (u && u->train && ensure_packed(u, q.w, s)) return 1;  // training loop: weights re-packed on the device when stale
     switch (P.kind) {
         case 7: return init7_launch(q, s);
         case 5: return pw_launch(q, s);
@@ -976,6 +979,7 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
     p.residual = residual; p.g = g; p.scale = scale;
     if (P.kind == 4) {
         if (c.dry()) return 0;
+        if (c.u && c.u->train && ensure_packed(c.u, L.wraw, c.s)) return 1;
         return launch_pointwise_small(in0, L.wraw, L.bias, out, (int64_t)c.B * p.Ho * p.Wo, L.C0, L.Cout, p.Ho * p.Wo,
                                       c.s);
     }
@@ -984,7 +988,7 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
         DM_REQUIRE(!res_parts, "residual partial sums need the landing pass");
         if (c.dry()) return 0;
         p.out = out; p.partial = 0; p.epi = full_epi;
-        return launch_planned(P, p, c.s);
+        return launch_planned(P, p, c.s, c.u);
     }
     DM_REQUIRE(!out_nchw, "split / unfused epilogue writes NHWC");
     const size_t M = (size_t)c.B * P.out_h * P.out_w;
@@ -994,7 +998,7 @@ static int run_conv(Ctx& c, const ConvLayer& L, const float* in0, const float* i
         return 0;
     }
     p.out = part; p.partial = 1; p.epi = 0;
-    if (launch_planned(P, p, c.s)) return 1;
+    if (launch_planned(P, p, c.s, c.u)) return 1;
     int rc;
     if (res_parts)
         rc = launch_norm_act(part, p.geo.splits, (int64_t)(M * L.Cout), L.bias, g, scale, c.ss_stride, P.out_h * P.out_w,
@@ -1021,7 +1025,7 @@ static int run_conv_partial(Ctx& c, const ConvLayer& L, const float* in0, const 
     *nsplit = p.geo.splits;
     if (c.dry()) return 0;
     p.out = *part; p.partial = 1; p.epi = 0;
-    return launch_planned(P, p, c.s);
+    return launch_planned(P, p, c.s, c.u);
 }
 
 // Block.forward: conv3x3 -> RMSNorm -> (scale+1, shift) -> SiLU [-> + residual]

@@ -371,6 +371,8 @@ int launch_pack_pw(const float* w, float* packed, int Cout, int Cin, int s2d_C0,
 int launch_pack_init7(const float* oihw, float* packed, int Cin, hipStream_t s);
 int launch_rot_transpose(const float* w, float* out, int Cout, int Cin, int K, int c_lo, int c_n, hipStream_t s);
 int launch_s2d_transpose(const float* w, float* out, int Cout, int C, hipStream_t s);
+// table_dev: device array of {long long src_off; float* dst; long long n;}: dst[i] = param[src_off + i]
+int launch_scatter_copy(const float* param, const void* table_dev, int n_entries, long long max_n, hipStream_t s);
 int launch_grad_norm(const float* grads, int64_t n, double* part_ws, float max_norm, float* out2, hipStream_t s);
 int launch_adam_ema(float* p, const float* g, float* m, float* v, float* ema, const float* clip2, int64_t n, float lr,
                     float b1, float b2, float eps, int step, float ema_decay, hipStream_t s);

@@ -8,6 +8,8 @@
 // materialised first (rot_transpose_kernel, s2d_transpose_kernel) and go through the same packers.
 #include "dm_common.h"
 
+#include <algorithm>
+
 namespace dm {
 
 static __device__ __forceinline__ int d_pad_to(int v, int m) { return (v + m - 1) / m * m; }
@@ -168,6 +170,27 @@ __global__ void s2d_transpose_kernel(const float* __restrict__ w, float* __restr
     if (i >= (int64_t)4 * C * Cout) return;
     const int o = (int)(i % Cout), c = (int)((i / Cout) % C), sub = (int)(i / ((int64_t)Cout * C));
     out[i] = w[(size_t)o * 4 * C + c * 4 + sub];
+}
+
+// all raw parameter copies of a re-pack (biases, gains, mem_kv, time MLP, the concatenated ResnetBlock.mlp rows) in ONE
+// launch: blockIdx.y = table entry, the entry's floats are spread over blockIdx.x
+struct ScatterEntry {
+    long long src_off;
+    float* dst;
+    long long n;
+};
+__global__ void scatter_copy_kernel(const float* __restrict__ param, const ScatterEntry* __restrict__ table) {
+    const ScatterEntry e = table[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < e.n; i += (long long)gridDim.x * blockDim.x)
+        e.dst[i] = param[e.src_off + i];
+}
+int launch_scatter_copy(const float* param, const void* table_dev, int n_entries, long long max_n, hipStream_t s) {
+    if (n_entries <= 0) return 0;
+    const int bx = (int)std::max<long long>(1, std::min<long long>(64, (max_n + 1023) / 1024));
+    hipLaunchKernelGGL(scatter_copy_kernel, dim3(bx, n_entries), dim3(256), 0, s, param,
+                       static_cast<const ScatterEntry*>(table_dev));
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 #define DM_PK_LAUNCH(kernel, n, ...)                                                                     \

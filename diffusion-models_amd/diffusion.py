@@ -233,8 +233,8 @@ class DenoisingDiffusion:
                                             _lib.ptr(out), x_start.shape[0], x_start[0].numel(), stream))
         return out
 
-    def p_losses(self, x_start, t, noise=None, offset_noise_strength=None, *, return_model_out=False, loss_scale=1.0,
-                 accumulate=False):
+    def p_losses(self, x_start, t, noise=None, offset_noise_strength=None, cond=None, *, return_model_out=False,
+                 loss_scale=1.0, accumulate=False):
         """:823-889: returns the loss (0-dim CPU tensor); the parameter gradients stay on the model
         (``self.model.grad(name)`` / ``.grads()``) -- loss and backward are one call of the library, there is no autograd
         graph to keep.  ``loss_scale`` / ``accumulate`` are the micro-batch loop of ``Trainer.train`` (:1164-1176):
@@ -252,14 +252,19 @@ class DenoisingDiffusion:
                  else self._randn(x_start.shape, _default_seed(), 0))
         t_cpu = t.detach().to("cpu", torch.long).contiguous()
         coef = self._tcoef(t_cpu)
+        cc = 0
+        if cond is not None:  # image-conditional variant (denoising_diffusion_image_conditional.py:251-311)
+            cond = cond.to(self.device, torch.float32).contiguous()
+            assert cond.shape[0] == b and tuple(cond.shape[2:]) == (h, w), "batch / size mismatch between x and cond"
+            cc = int(cond.shape[1])
         loss = C.c_float(0.0)
         out = torch.empty_like(x_start) if return_model_out else None
         t_arr = (C.c_int64 * b)(*[int(v) for v in t_cpu.tolist()])
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self._lib.dm_unet_loss_backward(
             self.model._handle, _lib.ptr(x_start), C.cast(t_arr, C.POINTER(C.c_int64)),
-            C.cast(coef.data_ptr(), C.POINTER(C.c_float)), _lib.ptr(noise), self._objective_id, float(loss_scale),
-            int(bool(accumulate)), C.byref(loss), _lib.ptr(out), b, h, w, stream))
+            C.cast(coef.data_ptr(), C.POINTER(C.c_float)), _lib.ptr(noise), _lib.ptr(cond), cc, self._objective_id,
+            float(loss_scale), int(bool(accumulate)), C.byref(loss), _lib.ptr(out), b, h, w, stream))
         val = torch.tensor(loss.value, dtype=torch.float32)
         return (val, out) if return_model_out else val
 
@@ -454,6 +459,15 @@ class ImageConditionalDenoisingDiffusion(DenoisingDiffusion):
         cond = self._cond(batch_size, cond)
         ret = self.ddim_sample(shape, None, cond, return_all_timesteps, **kw)
         return (cond, ret) if return_condition_image else ret
+
+    def forward(self, img, cond=None, *args, **kwargs):
+        """denoising_diffusion_image_conditional.py:313-319: the training loss with the condition image."""
+        b, c, h, w = img.shape
+        assert (h, w) == tuple(self.image_size), f"height and width of image must be {self.image_size}"
+        t = torch.randint(0, self.num_timesteps, (b,)).long()
+        return self.p_losses(self.normalize(img.to(self.device, torch.float32)), t, *args, cond=cond, **kwargs)
+
+    __call__ = forward
 
     @torch.inference_mode()
     def p_sample(self, x, t: int, cond=None, x_self_cond=None, *, noise=None):

@@ -312,10 +312,12 @@ int dm_unet_get_grad(dm_unet* u, const char* name, float* out_dev, void* stream)
  * coef_host: (B, 4) = sqrt_alphas_cumprod[t_b], sqrt_one_minus_alphas_cumprod[t_b], loss_weight[t_b], 0 -- the values
  * `extract` gathers (:394-397).  loss_scale = 1 / gradient_accumulate_every and accumulate != 0 adds the gradients to
  * what the buffers hold (the micro-batch loop of Trainer.train, :1164-1176).  loss_out_host receives the scalar loss;
- * model_out (optional, device) the U-Net output.  The call synchronises the stream. */
+ * model_out (optional, device) the U-Net output.  cond (optional): the condition image (B, cond_channels, H, W) of the
+ * image-conditional variant, concatenated behind x in front of init_conv (DD/denoising_diffusion_image_conditional.py:51-55,
+ * p_losses :251-311).  The call synchronises the stream. */
 int dm_unet_loss_backward(dm_unet* u, const float* x_start, const int64_t* t_host, const float* coef_host,
-                          const float* noise, int objective, float loss_scale, int accumulate, float* loss_out_host,
-                          float* model_out, int B, int H, int W, void* stream);
+                          const float* noise, const float* cond, int cond_channels, int objective, float loss_scale,
+                          int accumulate, float* loss_out_host, float* model_out, int B, int H, int W, void* stream);
 /* The rest of one Trainer.train iteration (:1178-1190) on device-resident state: the master parameters, the Adam moments and
  * the EMA copy live in flat device buffers in the reference layouts; after the update every packed weight buffer the
  * kernels read is rebuilt on the device (pack_kernels.hip, bit-identical to the host packers).

@@ -232,3 +232,28 @@ def test_dropout_training_step_with_the_same_masks_as_the_oracle():
     b = dm.DenoisingDiffusion(plain, image_size=16, timesteps=1000).ddim_sample((2, 3, 16, 16), sampling_timesteps=2,
                                                                                 noise=so.NoiseStream(1))
     assert torch.equal(a, b)  # eval-mode sampling: dropout is the identity
+
+
+def test_image_conditional_training_step_vs_oracle():
+    """ImageConditionalDenoisingDiffusion.p_losses (denoising_diffusion_image_conditional.py:251-311): the condition image
+    rides behind x through init_conv; loss and every gradient (incl. the 6-channel init_conv weight) against the oracle."""
+    from oracle import train_oracle as to
+
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3, cond_channels=3)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=7)
+    u = dm.Unet(dim=32, dim_mults=(1, 2), channels=3, cond_channels=3, device=DEV)
+    u.load_state_dict(sd)
+    d = dm.ImageConditionalDenoisingDiffusion(u, image_size=16, timesteps=1000).train()
+    g = torch.Generator().manual_seed(21)
+    B = 4
+    x_start = torch.rand((B, 3, 16, 16), generator=g) * 2 - 1
+    cond = torch.rand((B, 3, 16, 16), generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.randn((B, 3, 16, 16), generator=g)
+    loss = float(d.p_losses(x_start, t, noise=noise, cond=cond))
+    want_loss, want = to.loss_and_grads(sd, cfg, dm.make_schedule(1000, "linear"), x_start, t, noise, cond=cond)
+    assert abs(loss - want_loss) <= 1e-5 * abs(want_loss)
+    got = d.model.grads()
+    worst = max((rel_l2(got[k].cpu(), want[k]), k) for k in want)
+    print("image-conditional worst gradient", worst)
+    assert worst[0] < GRAD_TOL

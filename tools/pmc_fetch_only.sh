@@ -3,7 +3,7 @@
 set -e
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-CMD="python3 bench.py --workload ddim50 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline"
+CMD="python3 bench.py --workload ddim50 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-other-configs --no-train"
 echo "pass fetch $tag"; rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_fetch -o f -- $CMD > gpurun_out/${tag}_fetch.log 2>&1
 rm -f gpurun_out/${tag}_fetch/*kernel_trace.csv
 python3 - <<PY
