@@ -76,6 +76,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
+    // ---- staging items of this thread: (window pixel, channel quad) pairs do not depend on the block, only their image
+    //      coordinates do: the divisions are done once, a block costs additions and bounds checks
+    constexpr int YI = 4;                                       // dY: 64 px x 16 quads / 256 threads
+    constexpr int XI = MODE == 0 ? 13 : (MODE == 1 ? 4 : 16);   // X window items (upper bound, checked by the launcher)
+    const int q4 = 4 * (tid & 15);
+    int ypos[YI], xpos[XI];                                     // (row << 16) | column inside the block / window, -1: no item
+#pragma unroll
+    for (int j = 0; j < YI; ++j) {
+        const int px = (tid >> 4) + 16 * j;
+        const int r = px / TW, c = px - r * TW;
+        ypos[j] = r < R ? (r << 16) | c : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+        const int wp = (tid >> 4) + 16 * j;
+        const int wy = wp / WW, wx = wp - wy * WW;
+        xpos[j] = wp < WH * WW ? (wy << 16) | wx : -1;
+    }
+    const int co_s = ct * 64 + q4, ci_s = kt * 64 + q4;
+    const bool co_ok = co_s < p.Cout, ci_ok = ci_s < p.Cin;
+    const bool src1 = ci_s >= p.C0;
+    const float* xsrc = src1 ? p.in1 + (ci_s - p.C0) : p.in0 + ci_s;
+    const int xC = src1 ? p.C1 : p.C0;
+
     const int blk0 = split * p.blocks_per_split;
     const int blk1 = min(blk0 + p.blocks_per_split, p.n_blocks);
     for (int blk = blk0; blk < blk1; ++blk) {
@@ -84,19 +108,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p)
         const int y0 = (rem / p.tiles_x) * R, x0 = (rem % p.tiles_x) * TW;
         __syncthreads();  // the previous block's MFMA loop is done with the tiles
         // ---- stage dY: 64 pixels x 16 float4
-        for (int idx = tid; idx < 64 * 16; idx += 256) {
-            const int px = idx >> 4, q = idx & 15;
-            const int r = px / TW, c = px - r * TW;
-            const int y = y0 + r, x = x0 + c, co = ct * 64 + 4 * q;
+#pragma unroll
+        for (int j = 0; j < YI; ++j) {
+            const int px = (tid >> 4) + 16 * j;
             f32x4 v = make_f32x4(0.f, 0.f, 0.f, 0.f);
-            if (r < R && y < p.Ho && x < p.Wo && co < p.Cout)
-                v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)(b * p.Ho + y) * p.Wo + x) * p.Cout + co);
-            *reinterpret_cast<f32x4*>(sY + px * WG_SY + 4 * q) = v;
+            if (ypos[j] >= 0) {
+                const int y = y0 + (ypos[j] >> 16), x = x0 + (ypos[j] & 0xFFFF);
+                if (y < p.Ho && x < p.Wo && co_ok)
+                    v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)(b * p.Ho + y) * p.Wo + x) * p.Cout + co_s);
+            }
+            *reinterpret_cast<f32x4*>(sY + px * WG_SY + q4) = v;
         }
         // ---- stage the X window
-        for (int idx = tid; idx < WH * WW * 16; idx += 256) {
-            const int wp = idx >> 4, q = idx & 15;
-            const int wy = wp / WW, wx = wp - wy * WW;
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            if (xpos[j] < 0) continue;
+            const int wp = (tid >> 4) + 16 * j;
+            const int wy = xpos[j] >> 16, wx = xpos[j] & 0xFFFF;
             int sy, sx;
             bool ok;
             if (MODE == 0) {
@@ -109,14 +137,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p)
                 sx = S * x0 + wx;
                 ok = sy < Hs && sx < Ws;
             }
-            const int ci = kt * 64 + 4 * q;
             f32x4 v = make_f32x4(0.f, 0.f, 0.f, 0.f);
-            if (ok && ci < p.Cin) {
-                const size_t spx = (size_t)(b * Hs + sy) * Ws + sx;
-                v = ci < p.C0 ? *reinterpret_cast<const f32x4*>(p.in0 + spx * p.C0 + ci)
-                              : *reinterpret_cast<const f32x4*>(p.in1 + spx * p.C1 + (ci - p.C0));
-            }
-            *reinterpret_cast<f32x4*>(sX + wp * WG_SX + 4 * q) = v;
+            if (ok && ci_ok) v = *reinterpret_cast<const f32x4*>(xsrc + ((size_t)(b * Hs + sy) * Ws + sx) * xC);
+            *reinterpret_cast<f32x4*>(sX + wp * WG_SX + q4) = v;
         }
         __syncthreads();
         // ---- MFMA: K = pixel pairs (2 cp + k) of every row of the block
@@ -188,9 +211,11 @@ size_t wgrad_ws_floats(int B, int Ho, int Wo, int Cout, int Cin, int T, int* spl
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + R - 1) / R;
     const int n_blocks = B * tiles_x * tiles_y;
     const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
-    // enough workgroups to fill the chip twice, but at least 4 pixel blocks per split: every split writes a full
+    // enough workgroups to fill the chip twice (two per CU overlap their staging), at least 2 pixel blocks per split
+    // (swept 2 / 4 / 8: 14.85 / 15.06 / 16.55 ms per loss+backward at B=64): every split writes a full
     // [T][Cout][Cin] partial tile that the reduce kernel reads back
-    int splits = std::max(1, std::min((n_blocks + 3) / 4, (512 + tiles - 1) / tiles));
+    static const int min_bps = env_int("DM_WGRAD_MIN_BLOCKS", 2);
+    int splits = std::max(1, std::min((n_blocks + min_bps - 1) / min_bps, (512 + tiles - 1) / tiles));
     const int bps = (n_blocks + splits - 1) / splits;
     splits = (n_blocks + bps - 1) / bps;
     if (splits_out) *splits_out = splits;
@@ -222,6 +247,7 @@ int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float
     const int WH = mode == 0 ? p.R + 2 : (mode == 2 ? 2 * p.R : p.R);
     const size_t lds = (size_t)(64 * WG_SY + WH * WW * WG_SX) * sizeof(float);
     DM_REQUIRE(lds <= 160 * 1024, "wgrad: LDS");
+    DM_REQUIRE(WH * WW <= 16 * (mode == 0 ? 13 : (mode == 1 ? 4 : 16)), "wgrad: window larger than the staging items");
     const dim3 grid(p.n_ct * p.n_kt, splits);
     const bool timed = prof::enabled();
     if (timed && prof::begin("wgrad_mfma_kernel", 2.0 * T * p.Cin * Cout * (double)B * Ho * Wo,
