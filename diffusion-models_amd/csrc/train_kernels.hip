@@ -529,7 +529,7 @@ __global__ void q_sample_kernel(const float* __restrict__ x_start, const float* 
 #pragma clang fp contract(off)  // two roundings, like the reference's tensor expression
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float* c = coef + 4 * (i / per_sample);
+    const float* c = coef + DM_TRAIN_COEFS * (i / per_sample);
     x[i] = c[0] * x_start[i] + c[1] * noise[i];
 }
 int launch_q_sample(const float* x_start, const float* noise, const float* coef_dev, float* x, int B, int per_sample,
@@ -541,13 +541,36 @@ int launch_q_sample(const float* x_start, const float* noise, const float* coef_
     return 0;
 }
 
+// pred_x_start of model_predictions (:603-626) with a per-sample timestep, unclipped (p_losses :849): coef[b][4..5] =
+// sqrt_recip_alphas_cumprod[t_b], sqrt_recipm1_alphas_cumprod[t_b]; coef[b][0..1] feed predict_start_from_v
+__global__ void pred_x_start_kernel(const float* __restrict__ x, const float* __restrict__ out, const float* __restrict__ coef,
+                                    float* __restrict__ xs, int per_sample, int64_t n, int objective) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* c = coef + DM_TRAIN_COEFS * (i / per_sample);
+    float v;
+    if (objective == 0) v = c[4] * x[i] - c[5] * out[i];
+    else if (objective == 1) v = out[i];
+    else v = c[0] * x[i] - c[1] * out[i];
+    xs[i] = v;
+}
+int launch_pred_x_start(const float* x, const float* out, const float* coef_dev, float* xs, int B, int per_sample, int objective,
+                        hipStream_t s) {
+    const int64_t n = (int64_t)B * per_sample;
+    hipLaunchKernelGGL(pred_x_start_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out, coef_dev, xs, per_sample,
+                       n, objective);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // one workgroup per sample: part[b] = loss_weight * mean((out - target)^2); dout = 2 (out - target) * w / (per_sample * B)
 __global__ void mse_loss_kernel(const float* __restrict__ out, const float* __restrict__ x_start, const float* __restrict__ noise,
                                 const float* __restrict__ coef, float* __restrict__ dout, float* __restrict__ part,
                                 int per_sample, int B, int objective, float loss_scale) {
     __shared__ double red[256];
     const int b = blockIdx.x;
-    const float* c = coef + 4 * b;
+    const float* c = coef + DM_TRAIN_COEFS * b;
     const float gscale = loss_scale * 2.0f * c[2] / ((float)per_sample * (float)B);
     double s = 0.0;
     for (int i = threadIdx.x; i < per_sample; i += 256) {

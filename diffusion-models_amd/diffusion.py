@@ -157,7 +157,7 @@ class DenoisingDiffusion:
         return out
 
     def _run(self, kind, shape, times, coefs, takes_noise: Sequence[bool], return_all_timesteps, noise, seed,
-             text_emb=None, max_steps=None, cond=None, sample_offset=0):
+             text_emb=None, max_steps=None, cond=None, sample_offset=0, x_init=None, unnormalize=None):
         shape = tuple(int(v) for v in shape)
         B, Cc, H, W = shape
         assert Cc == self.channels, f"shape has {Cc} channels, the model {self.channels}"
@@ -166,7 +166,7 @@ class DenoisingDiffusion:
             seed = _default_seed()
         sample_offset = int(sample_offset)
         if noise is not None:
-            x_T = noise(shape).to(self.device, torch.float32).contiguous()
+            x_T = (noise(shape) if x_init is None else x_init).to(self.device, torch.float32).contiguous()
             rows = []
             zero = None
             for flag in takes_noise:
@@ -177,7 +177,8 @@ class DenoisingDiffusion:
                     rows.append(zero)
             noise_dev = torch.stack(rows, dim=0).to(self.device).contiguous()
         else:
-            x_T = self._randn(shape, seed, 0, sample_offset)
+            x_T = (self._randn(shape, seed, 0, sample_offset) if x_init is None
+                   else x_init.to(self.device, torch.float32).contiguous())
             noise_dev = None
         if max_steps is not None:  # bounded run (bench / smoke): first `max_steps` iterations only
             n_steps = min(n_steps, int(max_steps))
@@ -202,7 +203,8 @@ class DenoisingDiffusion:
             a.cond, a.cond_channels = _lib.ptr(cond), int(cond.shape[1])
         a.out, a.all_steps = _lib.ptr(out), _lib.ptr(all_steps)
         a.B, a.H, a.W = B, H, W
-        a.unnormalize, a.use_graph, a.stream = self._unnormalize_flag, 1 if self.use_graph else 0, stream
+        a.unnormalize = self._unnormalize_flag if unnormalize is None else int(bool(unnormalize))
+        a.use_graph, a.stream = 1 if self.use_graph else 0, stream
         _lib.check(self._lib.dm_sample_ex(self.model._handle, C.byref(a)))
         if not return_all_timesteps:
             return out
@@ -215,11 +217,14 @@ class DenoisingDiffusion:
         return self
 
     def _tcoef(self, t: torch.Tensor) -> torch.Tensor:
-        """(B, 4): what `extract` gathers for q_sample / predict_v / the loss weight at each sample's timestep."""
+        """(B, 8): what `extract` gathers for q_sample / predict_v / the loss weight / predict_start_from_noise at each
+        sample's timestep (DM_TRAIN_COEFS of include/dm_hip.h)."""
         t = t.detach().to("cpu", torch.long)
         s = self._sched
-        return torch.stack([s["sqrt_alphas_cumprod"][t], s["sqrt_one_minus_alphas_cumprod"][t], s["loss_weight"][t],
-                            torch.zeros(t.shape[0])], dim=1).to(torch.float32).contiguous()
+        z = torch.zeros(t.shape[0])
+        return torch.stack([s["sqrt_alphas_cumprod"][t], s["sqrt_one_minus_alphas_cumprod"][t], s["loss_weight"][t], z,
+                            s["sqrt_recip_alphas_cumprod"][t], s["sqrt_recipm1_alphas_cumprod"][t], z, z],
+                           dim=1).to(torch.float32).contiguous()
 
     def q_sample(self, x_start, t, noise=None):
         """:813-821 (immiscible noise assignment off, the reference default)."""
@@ -234,16 +239,21 @@ class DenoisingDiffusion:
         return out
 
     def p_losses(self, x_start, t, noise=None, offset_noise_strength=None, cond=None, *, return_model_out=False,
-                 loss_scale=1.0, accumulate=False):
+                 loss_scale=1.0, accumulate=False, self_cond=None):
         """:823-889: returns the loss (0-dim CPU tensor); the parameter gradients stay on the model
         (``self.model.grad(name)`` / ``.grads()``) -- loss and backward are one call of the library, there is no autograd
         graph to keep.  ``loss_scale`` / ``accumulate`` are the micro-batch loop of ``Trainer.train`` (:1164-1176):
-        ``loss / gradient_accumulate_every`` with the gradients added up.  Offset noise, the hybrid (KL) loss and
-        self-conditioning are not on this path."""
+        ``loss / gradient_accumulate_every`` with the gradients added up.  With ``Unet(self_condition=True)`` half of the
+        calls condition on a gradient-free prediction of x_start (:846-855; ``self_cond=True / False`` forces the branch).
+        Offset noise and the hybrid (KL) loss are not on this path."""
         if offset_noise_strength is None:
             offset_noise_strength = self.offset_noise_strength
         assert not offset_noise_strength, "offset noise is not on the HIP training path"
-        assert not self.self_condition, "self-conditioning is not on the HIP training path"
+        sc_mode = 0
+        if self.self_condition:
+            # :846-855: half of the iterations condition on the x_start a gradient-free pass predicts (self_cond= forces it)
+            use = (random.random() < 0.5) if self_cond is None else bool(self_cond)
+            sc_mode = 2 if use else 1
         if not getattr(self.model, "_training", False):
             self.model.train()
         x_start = x_start.to(self.device, torch.float32).contiguous()
@@ -263,7 +273,7 @@ class DenoisingDiffusion:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self._lib.dm_unet_loss_backward(
             self.model._handle, _lib.ptr(x_start), C.cast(t_arr, C.POINTER(C.c_int64)),
-            C.cast(coef.data_ptr(), C.POINTER(C.c_float)), _lib.ptr(noise), _lib.ptr(cond), cc, self._objective_id,
+            C.cast(coef.data_ptr(), C.POINTER(C.c_float)), _lib.ptr(noise), _lib.ptr(cond), cc, sc_mode, self._objective_id,
             float(loss_scale), int(bool(accumulate)), C.byref(loss), _lib.ptr(out), b, h, w, stream))
         val = torch.tensor(loss.value, dtype=torch.float32)
         return (val, out) if return_model_out else val
@@ -300,6 +310,29 @@ class DenoisingDiffusion:
         (h, w), channels = self.image_size, self.channels
         sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
         return sample_fn((batch_size, channels, h, w), return_all_timesteps=return_all_timesteps, **kw)
+
+    @torch.inference_mode()
+    def interpolate(self, x1, x2, t=None, lam=0.5, *, noise=None, seed=None):
+        """:786-803: diffuse x1 and x2 to step t, mix them with weight lam, run the reverse loop from t - 1 down to 0.
+        Like the reference it returns the image as the loop leaves it (no unnormalize).  ``noise`` draws, in the
+        reference's order: q_sample(x1), q_sample(x2), then one per reverse step with i > 0."""
+        assert x1.shape == x2.shape
+        b = x1.shape[0]
+        t = self.num_timesteps - 1 if t is None else int(t)
+        tb = torch.full((b,), t, dtype=torch.long)
+        if seed is None:
+            seed = _default_seed()
+        n1 = noise(tuple(x1.shape)) if noise is not None else self._randn(x1.shape, seed, 1 << 20)
+        n2 = noise(tuple(x1.shape)) if noise is not None else self._randn(x1.shape, seed, (1 << 20) + 1)
+        xt1, xt2 = self.q_sample(x1, tb, n1), self.q_sample(x2, tb, n2)
+        img = (1 - lam) * xt1 + lam * xt2
+        if t == 0:
+            return img
+        times_all, coefs_all = self._ddpm_tables()  # row i is step T-1-i
+        first = self.num_timesteps - t             # the row of step t - 1
+        times, coefs = times_all[first:], coefs_all[first:]
+        return self._run(DDPM, tuple(x1.shape), times, coefs, [ti > 0 for ti in times], False, noise, seed, x_init=img,
+                         unnormalize=False)
 
     def _eps(self, x, bt, **cond_kw):
         """The U-Net call of ``model_predictions`` (:603-606); subclasses thread their condition through ``cond_kw``."""

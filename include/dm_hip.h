@@ -309,15 +309,18 @@ int dm_unet_get_grad(dm_unet* u, const char* name, float* out_dev, void* stream)
  *   x = q_sample(x_start, t, noise) (:813-821);  out = Unet(x, t);  target per `objective` (DM_OBJ_*, :864-872);
  *   loss = loss_scale * mean_b( loss_weight[t_b] * mean((out - target)^2) ) (:874-878, :889);  every parameter gradient.
  * x_start, noise: (B, C, H, W) device, x_start already normalised to [-1, 1];  t_host: (B) timesteps;
- * coef_host: (B, 4) = sqrt_alphas_cumprod[t_b], sqrt_one_minus_alphas_cumprod[t_b], loss_weight[t_b], 0 -- the values
- * `extract` gathers (:394-397).  loss_scale = 1 / gradient_accumulate_every and accumulate != 0 adds the gradients to
+ * coef_host: (B, DM_TRAIN_COEFS = 8) = sqrt_alphas_cumprod[t_b], sqrt_one_minus_alphas_cumprod[t_b], loss_weight[t_b], 0,
+ * sqrt_recip_alphas_cumprod[t_b], sqrt_recipm1_alphas_cumprod[t_b], 0, 0 -- the values `extract` gathers (:394-397).
+ * self_cond (Unet(self_condition=True), :846-855): 0 off; 1 the U-Net sees [0 | x]; 2 it sees [x_start | x] with x_start
+ * predicted (unclipped, without gradient) by a first forward pass on [0 | x] -- the caller flips the reference's coin.  loss_scale = 1 / gradient_accumulate_every and accumulate != 0 adds the gradients to
  * what the buffers hold (the micro-batch loop of Trainer.train, :1164-1176).  loss_out_host receives the scalar loss;
  * model_out (optional, device) the U-Net output.  cond (optional): the condition image (B, cond_channels, H, W) of the
  * image-conditional variant, concatenated behind x in front of init_conv (DD/denoising_diffusion_image_conditional.py:51-55,
  * p_losses :251-311).  The call synchronises the stream. */
 int dm_unet_loss_backward(dm_unet* u, const float* x_start, const int64_t* t_host, const float* coef_host,
-                          const float* noise, const float* cond, int cond_channels, int objective, float loss_scale,
-                          int accumulate, float* loss_out_host, float* model_out, int B, int H, int W, void* stream);
+                          const float* noise, const float* cond, int cond_channels, int self_cond, int objective,
+                          float loss_scale, int accumulate, float* loss_out_host, float* model_out, int B, int H, int W,
+                          void* stream);
 /* The rest of one Trainer.train iteration (:1178-1190) on device-resident state: the master parameters, the Adam moments and
  * the EMA copy live in flat device buffers in the reference layouts; after the update every packed weight buffer the
  * kernels read is rebuilt on the device (pack_kernels.hip, bit-identical to the host packers).
@@ -342,7 +345,7 @@ int dm_unet_check_device_pack(dm_unet* u);
  * applies, n elements in (B, H, W, C) order -- parity tests hand these masks to the oracle. */
 int dm_unet_train_dropout(dm_unet* u, float p, uint64_t seed);
 int dm_op_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t call, int block_index, void* stream);
-/* q_sample (:813-821) on its own: out = coef[b][0] * x_start + coef[b][1] * noise, coef_host (B, 4) as above */
+/* q_sample (:813-821) on its own: out = coef[b][0] * x_start + coef[b][1] * noise, coef_host (B, 8) as above */
 int dm_op_q_sample(const float* x_start, const float* noise, const float* coef_host, float* out, int B, int per_sample,
                    void* stream);
 

@@ -159,3 +159,16 @@ def ddim_sample(
         imgs.append(img)
     ret = img if not return_all_timesteps else torch.stack(imgs, dim=1)
     return (ret + 1) * 0.5 if unnormalize else ret
+
+
+@torch.inference_mode()
+def interpolate(model: Model, sched, x1, x2, t: int, lam: float, noise: Callable):
+    """DD/denoising_diffusion.py:786-803: q_sample both images at step t, mix, reverse loop from t - 1 to 0, no unnormalize."""
+    a, b = sched["sqrt_alphas_cumprod"][t], sched["sqrt_one_minus_alphas_cumprod"][t]
+    xt1 = a * x1 + b * noise(x1.shape)
+    xt2 = a * x2 + b * noise(x2.shape)
+    img = (1 - lam) * xt1 + lam * xt2
+    for i in reversed(range(0, t)):
+        z = noise(x1.shape) if i > 0 else None
+        img, _ = p_sample(model, sched, img, i, z)
+    return img

@@ -49,9 +49,26 @@ def target_of(sched, objective: str, x_start, t, noise):
     raise ValueError(f"unknown objective {objective}")
 
 
-def p_losses(sd: Dict[str, torch.Tensor], cfg, sched, x_start, t, noise, objective: str = "pred_noise", **fwd_kw):
-    """:823-889 with loss_weight from the schedule buffers (ones for the default ``ddpm=True``, :532-533)."""
+def pred_x_start(sched, objective: str, x, t, out):
+    """``model_predictions(...).pred_x_start`` with per-sample timesteps, unclipped (:603-626 with clip_x_start=False)."""
+    e = lambda name: sched[name][t].reshape(-1, 1, 1, 1)  # noqa: E731
+    if objective == "pred_noise":
+        return e("sqrt_recip_alphas_cumprod") * x - e("sqrt_recipm1_alphas_cumprod") * out
+    if objective == "pred_x0":
+        return out
+    return e("sqrt_alphas_cumprod") * x - e("sqrt_one_minus_alphas_cumprod") * out
+
+
+def p_losses(sd: Dict[str, torch.Tensor], cfg, sched, x_start, t, noise, objective: str = "pred_noise", self_cond=False,
+             **fwd_kw):
+    """:823-889 with loss_weight from the schedule buffers (ones for the default ``ddpm=True``, :532-533).
+    ``self_cond`` (``Unet(self_condition=True)``): the branch of :846-855 the reference takes for half of the iterations --
+    a gradient-free forward pass predicts x_start, which conditions the differentiated pass."""
     x = q_sample(sched, x_start, t, noise)
+    if getattr(cfg, "self_condition", False) and self_cond:
+        with torch.no_grad():
+            det = {k: v.detach() for k, v in sd.items()}
+            fwd_kw = dict(fwd_kw, x_self_cond=pred_x_start(sched, objective, x, t, uo.unet_forward(det, cfg, x, t)))
     out = uo.unet_forward(sd, cfg, x, t, **fwd_kw)
     loss = torch.nn.functional.mse_loss(out, target_of(sched, objective, x_start, t, noise), reduction="none")
     loss = loss.reshape(loss.shape[0], -1).mean(dim=1) * sched["loss_weight"][t]

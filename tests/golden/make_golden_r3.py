@@ -8,7 +8,8 @@
   (DDIM on 3x16x16 + ``VQModel.decode``), the text / cross-attention loop on 3x8x8, and ``VQModel`` with
   ``ch_mult (1,2,4,8)``, ``z_channels 3``, ``n_embed 8192`` (``decode`` and ``encode_to_prequant``);
 * objectives ``pred_x0`` / ``pred_v`` (DD/denoising_diffusion.py:614-624) through both loops;
-* self-conditioning (``Unet(self_condition=True)``, :352-354, :657, :683) through both loops.
+* self-conditioning (``Unet(self_condition=True)``, :352-354, :657, :683) through both loops;
+* ``interpolate`` (:786-803).
 
 Imports and noise redirection follow make_golden.py / make_golden_configs.py.  Only DATA is written.
 """
@@ -110,6 +111,13 @@ def main():
                                    ddim_sampling_eta=0.5).eval()
         with patched_noise(dd, seed + 1):
             out[f"{obj}_ddim4"] = dict(seed=seed + 1, shape=(2, 3, 16, 16), S=4, eta=0.5, y=dS.ddim_sample((2, 3, 16, 16)))
+    # interpolate (:786-803): q_sample of two images at t = 30, the mix, the reverse loop from 29
+    dI = dd.DenoisingDiffusion(ref_small, image_size=16, timesteps=50).eval()
+    gi = torch.Generator().manual_seed(3)
+    x1 = torch.rand((2, 3, 16, 16), generator=gi) * 2 - 1
+    x2 = torch.rand((2, 3, 16, 16), generator=gi) * 2 - 1
+    with patched_noise(dd, 350):
+        out["interpolate"] = dict(seed=350, x1=x1, x2=x2, t=30, lam=0.3, T=50, y=dI.interpolate(x1, x2, t=30, lam=0.3))
     sc_cfg = UnetConfig(dim=64, dim_mults=(1, 2), channels=3, self_condition=True)
     scsd = dm.synth_state_dict(dm.unet_param_spec(sc_cfg), salt=32)
     ref_sc = dd.Unet(dim=64, dim_mults=(1, 2), channels=3, self_condition=True).eval()

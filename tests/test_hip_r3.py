@@ -160,3 +160,15 @@ def test_self_conditioning(golden_r3, use_graph):
                                     x, 400, z, x_self_cond=sc)
     got, got_x0 = d.p_sample(x, 400, sc, noise=lambda shape: z)
     assert rel_l2(got.cpu(), want) < FWD_TOL and rel_l2(got_x0.cpu(), want_x0) < FWD_TOL
+
+
+def test_interpolate(golden_r3):
+    """DenoisingDiffusion.interpolate (:786-803) against the reference's own run: q_sample of both images, the mix, the
+    reverse loop from t - 1."""
+    u, _ = _unet(UnetConfig(dim=64, dim_mults=(1, 2), channels=3), 31)
+    b = golden_r3["interpolate"]
+    d = dm.DenoisingDiffusion(u, image_size=16, timesteps=b["T"])
+    got = d.interpolate(b["x1"], b["x2"], t=b["t"], lam=b["lam"], noise=so.NoiseStream(b["seed"])).cpu()
+    err = rel_l2(got, b["y"])
+    print("interpolate", err)
+    assert err < LOOP_TOL

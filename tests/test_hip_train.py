@@ -257,3 +257,30 @@ def test_image_conditional_training_step_vs_oracle():
     worst = max((rel_l2(got[k].cpu(), want[k]), k) for k in want)
     print("image-conditional worst gradient", worst)
     assert worst[0] < GRAD_TOL
+
+
+@pytest.mark.parametrize("use_prediction", [False, True])
+def test_self_conditioned_training_step_vs_oracle(use_prediction):
+    """Unet(self_condition=True): p_losses conditions on zeros or (half of the iterations, :846-855) on the x_start a
+    gradient-free forward pass predicts; loss and every gradient against the oracle for both branches."""
+    from oracle import train_oracle as to
+
+    cfg = UnetConfig(dim=64, dim_mults=(1, 2), channels=3, self_condition=True)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=32)
+    u = dm.Unet(dim=64, dim_mults=(1, 2), channels=3, self_condition=True, device=DEV)
+    u.load_state_dict(sd)
+    d = dm.DenoisingDiffusion(u, image_size=16, timesteps=1000).train()
+    g = torch.Generator().manual_seed(33)
+    B = 4
+    x_start = torch.rand((B, 3, 16, 16), generator=g) * 2 - 1
+    t = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.randn((B, 3, 16, 16), generator=g)
+    loss = float(d.p_losses(x_start, t, noise=noise, self_cond=use_prediction))
+    torch.set_num_threads(8)
+    want_loss, want = to.loss_and_grads(sd, cfg, dm.make_schedule(1000, "linear"), x_start, t, noise, self_cond=use_prediction)
+    print("self-cond", use_prediction, "loss", loss, want_loss)
+    assert abs(loss - want_loss) <= 1e-5 * abs(want_loss)
+    got = d.model.grads()
+    worst = max((rel_l2(got[k].cpu(), want[k]), k) for k in want)
+    print("self-cond worst gradient", worst)
+    assert worst[0] < GRAD_TOL

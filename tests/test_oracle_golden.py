@@ -350,6 +350,9 @@ def test_r3_objectives_and_self_conditioning(golden_r3):
         y = so.ddim_sample(model, dm.make_schedule(1000, "linear"), b["shape"], so.NoiseStream(b["seed"]), b["S"],
                            eta=b["eta"], objective=obj)
         assert rel_l2(y, b["y"]) < 1e-4, obj
+    b = golden_r3["interpolate"]
+    y = so.interpolate(model, dm.make_schedule(b["T"], "linear"), b["x1"], b["x2"], b["t"], b["lam"], so.NoiseStream(b["seed"]))
+    assert rel_l2(y, b["y"]) < 1e-4
     scfg = UnetConfig(dim=64, dim_mults=(1, 2), channels=3, self_condition=True)
     ssd = dm.synth_state_dict(dm.unet_param_spec(scfg), salt=32)
     b = golden_r3["unet_selfcond"]
