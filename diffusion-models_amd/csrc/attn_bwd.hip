@@ -19,7 +19,7 @@ constexpr int BDH = 32;
 constexpr int NMEM = 4;
 
 // part 1: grid (ceil(n / 64), B), 64 * heads threads (thread = head * 64 + token): dq, and this block's share of dctx
-__global__ void linattn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+__global__ __launch_bounds__(256) void linattn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
                                      const float* __restrict__ dout, float* __restrict__ dqkv,
                                      float* __restrict__ dctx_part, int n, int heads, float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -143,44 +143,36 @@ __global__ __launch_bounds__(256) void linattn_bwd_kv_kernel(const float* __rest
         }
         __syncthreads();
     }
+    // one token per thread; only v and the dv accumulators live in registers over the d loop (ks[d] and dk[d] are formed and
+    // stored row by row: holding all four 32-vectors spilled 343 registers)
     for (int t = tid; t < ntok; t += 256) {
-        float ks[BDH], vv[BDH];
         const bool mem = t < NMEM;
+        float vv[BDH], dvv[BDH];
 #pragma unroll
+        for (int e = 0; e < BDH; ++e) {
+            vv[e] = mem ? mv[e * NMEM + t] : vbase[(size_t)(t - NMEM) * ld + e];
+            dvv[e] = 0.f;
+        }
+        float* ok = mem ? dmem_part + (size_t)b * 2 * heads * BDH * NMEM + (size_t)h * BDH * NMEM + t
+                        : dqkv + ((size_t)b * n + (t - NMEM)) * ld + heads * BDH + h * BDH;
+        const int ks_stride = mem ? NMEM : 1;
+#pragma unroll 2
         for (int d = 0; d < BDH; ++d) {
             const float kv = mem ? mk[d * NMEM + t] : kbase[(size_t)(t - NMEM) * ld + d];
-            ks[d] = __expf(kv - kmax[d]) * kinv[d];
-            vv[d] = mem ? mv[d * NMEM + t] : vbase[(size_t)(t - NMEM) * ld + d];
-        }
-        float dk[BDH], dvv[BDH];
-#pragma unroll
-        for (int e = 0; e < BDH; ++e) dvv[e] = 0.f;
-#pragma unroll
-        for (int d = 0; d < BDH; ++d) {
+            const float ksd = __expf(kv - kmax[d]) * kinv[d];
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < BDH; ++e) {
-                s += dctx[d][e] * vv[e];
-                dvv[e] += ks[d] * dctx[d][e];
+                const float c = dctx[d][e];
+                s += c * vv[e];
+                dvv[e] += ksd * c;
             }
-            dk[d] = ks[d] * (s - S[d]);
+            ok[d * ks_stride] = ksd * (s - S[d]);
         }
-        if (mem) {
-            float* o = dmem_part + (size_t)b * 2 * heads * BDH * NMEM;
+        float* ov = mem ? dmem_part + (size_t)b * 2 * heads * BDH * NMEM + (size_t)(heads + h) * BDH * NMEM + t
+                        : dqkv + ((size_t)b * n + (t - NMEM)) * ld + 2 * heads * BDH + h * BDH;
 #pragma unroll
-            for (int d = 0; d < BDH; ++d) {
-                o[((size_t)h * BDH + d) * NMEM + t] = dk[d];
-                o[((size_t)(heads + h) * BDH + d) * NMEM + t] = dvv[d];
-            }
-        } else {
-            float* ok = dqkv + ((size_t)b * n + (t - NMEM)) * ld + heads * BDH + h * BDH;
-            float* ov = ok + heads * BDH;
-#pragma unroll
-            for (int d = 0; d < BDH; ++d) {
-                ok[d] = dk[d];
-                ov[d] = dvv[d];
-            }
-        }
+        for (int e = 0; e < BDH; ++e) ov[e * ks_stride] = dvv[e];
     }
 }
 
@@ -193,7 +185,7 @@ int launch_linear_attention_core_bwd(const float* qkv, const float* mem_kv, cons
     DM_REQUIRE(dh == BDH && heads >= 1 && heads <= 16, "linear attention backward: dim_head 32");
     const int nblk = (n + 63) / 64;
     const size_t lds = (size_t)(heads * BDH * BDH + 2 * heads * 64 * (BDH + 1)) * sizeof(float);
-    DM_REQUIRE(lds <= 160 * 1024 && 64 * heads <= 1024, "linear attention backward: too many heads");
+    DM_REQUIRE(lds <= 160 * 1024 && 64 * heads <= 256, "linear attention backward: at most 4 heads per workgroup");
     static LdsOptIn flag;
     if (lds_opt_in(flag, reinterpret_cast<const void*>(linattn_bwd_q_kernel), 1)) return 1;
     hipLaunchKernelGGL(linattn_bwd_q_kernel, dim3(nblk, B), dim3(64 * heads), lds, s, qkv, ctx, dout, dqkv, ws, n, heads,

@@ -115,8 +115,15 @@ struct DeviceOwner {
     void record_raw(const std::string& name, float* dst, size_t n) {
         if (rec && !refreshing) rec->push_back(PackOp{PK_RAW_NAME, dst, n, 0, 0, 0, 0, 0, PackSrc(), name});
     }
-    ~DeviceOwner() {
+    ~DeviceOwner() { reset(); }
+    DeviceOwner() = default;
+    DeviceOwner(const DeviceOwner&) = delete;  // owns device memory
+    DeviceOwner& operator=(const DeviceOwner&) = delete;
+    void reset() {  // free every buffer (the input-gradient layers are rebuilt from scratch on a refresh)
         for (void* p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+        sizes.clear();
+        cursor = 0;
     }
     int upload(const float* host, size_t n, float** out) {
         if (refreshing) {

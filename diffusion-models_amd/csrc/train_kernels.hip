@@ -250,13 +250,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     __syncthreads();
     if (q == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
 }
-__global__ void colsum_finish_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ out,
-                                     int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// 256 threads = 64 columns x 4 lanes over the partial rows, fixed order
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int blocks, int C,
+                                                            float* __restrict__ out, int accumulate) {
+    __shared__ float red[4][64];
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + li;
     float s = 0.f;
-    for (int b = 0; b < blocks; ++b) s += part[(size_t)b * C + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < C)
+        for (int b = q; b < blocks; b += 4) s += part[(size_t)b * C + c];
+    red[q][li] = s;
+    __syncthreads();
+    if (q == 0 && c < C) {
+        const float v = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
+        out[c] = accumulate ? out[c] + v : v;
+    }
 }
 // few rows (a batch of per-image vectors): one pass, thread per column
 __global__ void colsum_small_kernel(const float* __restrict__ x, int rows, int C, int64_t row_stride, int64_t col_stride,
@@ -267,7 +275,7 @@ __global__ void colsum_small_kernel(const float* __restrict__ x, int rows, int C
     for (int r = 0; r < rows; ++r) s += x[r * row_stride + c * col_stride];
     out[c] = accumulate ? out[c] + s : s;
 }
-static int colsum_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(64, rows / 128)); }
+static int colsum_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(512, rows / 64)); }
 size_t colsum_ws_floats(int64_t rows, int C) { return (size_t)colsum_blocks(rows) * C; }
 int launch_colsum(const float* x, int64_t rows, int C, int64_t row_stride, int64_t col_stride, float* ws, float* out,
                   int accumulate, hipStream_t s) {
@@ -283,7 +291,7 @@ int launch_colsum(const float* x, int64_t rows, int C, int64_t row_stride, int64
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, nb), dim3(256), 0, s, x, rows, C, row_stride, col_stride,
                        rpb, ws);
     DM_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, nb, C, out, accumulate);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, s, ws, nb, C, out, accumulate);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -493,6 +501,37 @@ int launch_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, float
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
+// The 19 ResnetBlock.mlp (SiLU -> Linear) gradients in ONE launch: row o of the concatenated [ss_total][I] matrix goes to
+// dw_rows[o] (a pointer into that block's mlp.1.weight gradient), its bias gradient to db_rows[o].
+// grid (ceil(I / 64), ss_total), 64 threads: dW[o][i] = sum_r dy[r][o] * silu(x[r][i]); thread 0 also sums the bias.
+__global__ void mlp_rows_wgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
+                                      float* const* __restrict__ dw_rows, float* const* __restrict__ db_rows, int R, int I,
+                                      int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int o = blockIdx.y;
+    if (i >= I) return;
+    float s = 0.f, sb = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float d = dy[(size_t)r * ldy + o];
+        const float xv = x[(size_t)r * ldx + i];
+        s += d * (xv / (1.0f + __expf(-xv)));
+        sb += d;
+    }
+    float* q = dw_rows[o] + i;
+    *q = accumulate ? *q + s : s;
+    if (i == 0) {
+        float* b = db_rows[o];
+        *b = accumulate ? *b + sb : sb;
+    }
+}
+int launch_mlp_rows_wgrad(const float* dy, int ldy, const float* x, int ldx, float* const* dw_rows, float* const* db_rows,
+                          int R, int I, int O, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(mlp_rows_wgrad_kernel, dim3((I + 63) / 64, O), dim3(64), 0, s, dy, ldy, x, ldx, dw_rows, db_rows, R, I,
+                       accumulate);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // nn.Linear input gradient: dx[r][i] = sum_o dy[r * ldy + o] * W[o][i]   (W as stored: (O, I)).
 // grid (ceil(I / 64), R), 1024 threads = 64 columns x 16 slices of the O range, combined through LDS in a fixed order.
 __global__ __launch_bounds__(1024) void linear_dgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ W,
