@@ -147,8 +147,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_unet_grad_floats.argtypes = [vp]
     lib.dm_unet_grad_floats.restype = i64
     lib.dm_unet_get_grad.argtypes = [vp, C.c_char_p, fp, vp]
-    lib.dm_unet_loss_backward.argtypes = [vp, fp, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, i32, i32, i32, C.c_float,
-                                          i32, C.POINTER(C.c_float), fp, i32, i32, i32, vp]
+    lib.dm_unet_loss_backward.argtypes = [vp, fp, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, i32, fp, i32, i32, i32,
+                                          C.c_float, i32, C.POINTER(C.c_float), fp, i32, i32, i32, vp]
     lib.dm_unet_optimizer_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), vp]
     lib.dm_unet_ema_update.argtypes = [vp, C.c_float, i32, vp]
     lib.dm_unet_get_param.argtypes = [vp, C.c_char_p, i32, fp, vp]

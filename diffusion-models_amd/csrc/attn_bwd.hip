@@ -198,37 +198,54 @@ int launch_linear_attention_core_bwd(const float* qkv, const float* mem_kv, cons
 }
 
 // ---------------------------------------------------------------------------------------
-// Full attention: P = softmax_j(scale q_i k_j), o_i = sum_j P_ij v_j (keys = 4 memory rows, then the tokens)
+// Full attention: P = softmax_j(scale q_i k_j), o_i = sum_j P_ij v_j (keys = n_mem memory rows, then the nk key rows)
 //   dP_ij = do_i . v_j;  D_i = do_i . o_i;  dS_ij = P_ij (dP_ij - D_i);  dq_i = scale sum_j dS_ij k_j;
 //   dk_j = scale sum_i dS_ij q_i;  dv_j = sum_i P_ij do_i
 // grid (heads, B); phase 1: thread = query (row statistics, dq); phase 2: thread = key (dk, dv), fixed order over queries.
+// Self-attention (Attention :215-229): q, k, v are column blocks of one qkv tensor and 4 learned memory rows come first;
+// cross-attention (DD/denoising_diffusion_text_conditional.py:54-78): k, v are projections of the text context, no memory.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ mem_kv,
-                                                       const float* __restrict__ dout, float* __restrict__ dqkv,
-                                                       float* __restrict__ dmem_part, int n, int heads, float scale) {
+struct AttnBwdParams {
+    const float *q, *k, *v;      // rows of ldq / ldk floats per token, head h at column h * 32
+    const float *mem_k, *mem_v;  // (heads, n_mem, 32) or nullptr
+    const float* dout;           // (B, nq, heads * 32)
+    float *dq, *dk, *dv;         // same strides as q / k / v
+    float* dmem_part;            // (B, 2, heads, n_mem, 32) or nullptr
+    int ldq, ldk, nq, nk, n_mem, heads;
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int nk = n + NMEM;
-    float* Ks = sm;                       // [nk][33]
-    float* Vs = Ks + nk * (BDH + 1);      // [nk][33]
-    float* Qs = Vs + nk * (BDH + 1);      // [n][33]
+    const int nkt = p.nk + p.n_mem, n = p.nq;
+    float* Ks = sm;                       // [nkt][33]
+    float* Vs = Ks + nkt * (BDH + 1);     // [nkt][33]
+    float* Qs = Vs + nkt * (BDH + 1);     // [n][33]
     float* Ds = Qs + n * (BDH + 1);       // [n][33]  dout
     float* rm = Ds + n * (BDH + 1);       // [n] row max
     float* rl = rm + n;                   // [n] 1 / row sum
     float* rD = rl + n;                   // [n] D_i
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int ld = 3 * heads * BDH, hid = heads * BDH;
-    const float* mk = mem_kv + (size_t)h * NMEM * BDH;            // [j][d]
-    const float* mv = mem_kv + (size_t)(heads + h) * NMEM * BDH;
-    for (int i = tid; i < nk * BDH; i += 256) {
+    const int hid = p.heads * BDH;
+    const float scale = p.scale;
+    for (int i = tid; i < nkt * BDH; i += 256) {
         const int j = i >> 5, d = i & 31;
-        const size_t row = ((size_t)b * n + (j - NMEM)) * ld + h * BDH + d;
-        Ks[j * (BDH + 1) + d] = j < NMEM ? mk[j * BDH + d] : qkv[row + hid];
-        Vs[j * (BDH + 1) + d] = j < NMEM ? mv[j * BDH + d] : qkv[row + 2 * hid];
+        float kv, vv;
+        if (j < p.n_mem) {
+            kv = p.mem_k[((size_t)h * p.n_mem + j) * BDH + d];
+            vv = p.mem_v[((size_t)h * p.n_mem + j) * BDH + d];
+        } else {
+            const size_t row = ((size_t)b * p.nk + (j - p.n_mem)) * p.ldk + h * BDH + d;
+            kv = p.k[row];
+            vv = p.v[row];
+        }
+        Ks[j * (BDH + 1) + d] = kv;
+        Vs[j * (BDH + 1) + d] = vv;
     }
     for (int i = tid; i < n * BDH; i += 256) {
         const int t = i >> 5, d = i & 31;
-        Qs[t * (BDH + 1) + d] = qkv[((size_t)b * n + t) * ld + h * BDH + d];
-        Ds[t * (BDH + 1) + d] = dout[((size_t)b * n + t) * hid + h * BDH + d];
+        Qs[t * (BDH + 1) + d] = p.q[((size_t)b * n + t) * p.ldq + h * BDH + d];
+        Ds[t * (BDH + 1) + d] = p.dout[((size_t)b * n + t) * hid + h * BDH + d];
     }
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
@@ -239,14 +256,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             dov[d] = Ds[i * (BDH + 1) + d];
         }
         float m = -INFINITY;
-        for (int j = 0; j < nk; ++j) {
+        for (int j = 0; j < nkt; ++j) {
             float sc = 0.f;
 #pragma unroll
             for (int d = 0; d < BDH; ++d) sc += q[d] * Ks[j * (BDH + 1) + d];
             m = fmaxf(m, sc * scale);
         }
         float l = 0.f, D = 0.f;
-        for (int j = 0; j < nk; ++j) {
+        for (int j = 0; j < nkt; ++j) {
             float sc = 0.f, dp = 0.f;
 #pragma unroll
             for (int d = 0; d < BDH; ++d) {
@@ -262,7 +279,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         float dq[BDH];
 #pragma unroll
         for (int d = 0; d < BDH; ++d) dq[d] = 0.f;
-        for (int j = 0; j < nk; ++j) {
+        for (int j = 0; j < nkt; ++j) {
             float sc = 0.f, dp = 0.f;
 #pragma unroll
             for (int d = 0; d < BDH; ++d) {
@@ -276,12 +293,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         rm[i] = m;
         rl[i] = linv;
         rD[i] = D;
-        float* o = dqkv + ((size_t)b * n + i) * ld + h * BDH;
+        float* o = p.dq + ((size_t)b * n + i) * p.ldq + h * BDH;
 #pragma unroll
         for (int d = 0; d < BDH; ++d) o[d] = scale * dq[d];
     }
     __syncthreads();
-    for (int j = tid; j < nk; j += 256) {
+    for (int j = tid; j < nkt; j += 256) {
         float kk[BDH], vv[BDH], dk[BDH], dv[BDH];
 #pragma unroll
         for (int d = 0; d < BDH; ++d) {
@@ -305,37 +322,61 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 dv[d] += P * Ds[i * (BDH + 1) + d];
             }
         }
-        if (j < NMEM) {
-            float* o = dmem_part + (size_t)b * 2 * heads * NMEM * BDH;
+        if (j < p.n_mem) {
+            float* o = p.dmem_part + (size_t)b * 2 * p.heads * p.n_mem * BDH;
 #pragma unroll
             for (int d = 0; d < BDH; ++d) {
-                o[((size_t)h * NMEM + j) * BDH + d] = scale * dk[d];
-                o[((size_t)(heads + h) * NMEM + j) * BDH + d] = dv[d];
+                o[((size_t)h * p.n_mem + j) * BDH + d] = scale * dk[d];
+                o[((size_t)(p.heads + h) * p.n_mem + j) * BDH + d] = dv[d];
             }
         } else {
-            float* ok = dqkv + ((size_t)b * n + (j - NMEM)) * ld + hid + h * BDH;
-            float* ov = ok + hid;
+            const size_t row = ((size_t)b * p.nk + (j - p.n_mem)) * p.ldk + h * BDH;
 #pragma unroll
             for (int d = 0; d < BDH; ++d) {
-                ok[d] = scale * dk[d];
-                ov[d] = dv[d];
+                p.dk[row + d] = scale * dk[d];
+                p.dv[row + d] = dv[d];
             }
         }
     }
+}
+
+static int launch_attn_bwd(const AttnBwdParams& p, int B, hipStream_t s) {
+    const size_t lds = ((size_t)(2 * (p.nk + p.n_mem) + 2 * p.nq) * (BDH + 1) + 3 * p.nq) * sizeof(float);
+    DM_REQUIRE(lds <= 160 * 1024, "attention backward: sequence too long for the LDS-resident kernel");
+    static LdsOptIn flag;
+    if (lds_opt_in(flag, reinterpret_cast<const void*>(attn_bwd_kernel), 1)) return 1;
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(p.heads, B), dim3(256), lds, s, p);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 // qkv (B, n, 3*heads*32), dout (B, n, heads*32) -> dqkv, dmem_part (B, 2, heads, 4, 32)
 int launch_attention_core_bwd(const float* qkv, const float* mem_kv, const float* dout, float* dqkv, float* dmem_part, int B,
                               int n, int heads, int dh, hipStream_t s) {
     DM_REQUIRE(dh == BDH, "attention backward: dim_head 32");
-    const size_t lds = ((size_t)(2 * (n + NMEM) + 2 * n) * (BDH + 1) + 3 * n) * sizeof(float);
-    DM_REQUIRE(lds <= 160 * 1024, "attention backward: sequence too long for the LDS-resident kernel");
-    static LdsOptIn flag;
-    if (lds_opt_in(flag, reinterpret_cast<const void*>(attn_bwd_kernel), 1)) return 1;
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(heads, B), dim3(256), lds, s, qkv, mem_kv, dout, dqkv, dmem_part, n, heads,
-                       1.0f / sqrtf((float)dh));
-    DM_CHECK_HIP(hipGetLastError());
-    return 0;
+    const int hid = heads * BDH;
+    AttnBwdParams p{};
+    p.q = qkv; p.k = qkv + hid; p.v = qkv + 2 * hid;
+    p.mem_k = mem_kv; p.mem_v = mem_kv + (size_t)heads * NMEM * BDH;
+    p.dout = dout;
+    p.dq = dqkv; p.dk = dqkv + hid; p.dv = dqkv + 2 * hid;
+    p.dmem_part = dmem_part;
+    p.ldq = p.ldk = 3 * hid; p.nq = p.nk = n; p.n_mem = NMEM; p.heads = heads;
+    p.scale = 1.0f / sqrtf((float)dh);
+    return launch_attn_bwd(p, B, s);
+}
+
+// CrossAttention core: q (B, nq, heads*32), k / v (B, m, heads*32) projections of the context -> dq, dk, dv (same shapes)
+int launch_cross_attention_core_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
+                                    float* dv, int B, int nq, int m, int heads, int dh, hipStream_t s) {
+    DM_REQUIRE(dh == BDH, "attention backward: dim_head 32");
+    AttnBwdParams p{};
+    p.q = q; p.k = k; p.v = v;
+    p.dout = dout;
+    p.dq = dq; p.dk = dk; p.dv = dv;
+    p.ldq = p.ldk = heads * BDH; p.nq = nq; p.nk = m; p.n_mem = 0; p.heads = heads;
+    p.scale = 1.0f / sqrtf((float)dh);
+    return launch_attn_bwd(p, B, s);
 }
 
 }  // namespace dm

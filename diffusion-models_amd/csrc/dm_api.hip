@@ -674,7 +674,9 @@ static int build_attn(dm_unet* u, AttnLayer& A, const std::string& p, int dim, b
 static int build_cross_body(dm_unet* u, CrossLayer& C, const std::string& p, int dim) {
     int inner = 4 * u->dh;
     // nn.Linear weights [out, in] are 1x1 conv weights (out, in, 1, 1)
+    conv_src(u, p + ".to_q.weight", "");
     if (make_conv(u->own, C.q, P(u, p + ".to_q.weight").data.data(), nullptr, inner, dim, 0, 1, 1, 1, 0, false)) return 1;
+    conv_src(u, p + ".to_out.0.weight", p + ".to_out.0.bias");
     if (make_conv(u->own, C.out, P(u, p + ".to_out.0.weight").data.data(), P(u, p + ".to_out.0.bias").data.data(), dim,
                   inner, 0, 1, 1, 1, 0, false)) return 1;
     if (up1(u, p + ".to_k.weight", &C.wk) || up1(u, p + ".to_v.weight", &C.wv) || up1(u, p + ".to_out.1.g", &C.g) ||

@@ -388,5 +388,7 @@ int launch_linear_attention_core_bwd(const float* qkv, const float* mem_kv, cons
                                      float* dqkv, float* dmem_part, int B, int n, int heads, int dh, hipStream_t s);
 int launch_attention_core_bwd(const float* qkv, const float* mem_kv, const float* dout, float* dqkv, float* dmem_part, int B,
                               int n, int heads, int dh, hipStream_t s);
+int launch_cross_attention_core_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
+                                    float* dv, int B, int nq, int m, int heads, int dh, hipStream_t s);
 
 }  // namespace dm

@@ -239,7 +239,7 @@ class DenoisingDiffusion:
         return out
 
     def p_losses(self, x_start, t, noise=None, offset_noise_strength=None, cond=None, *, return_model_out=False,
-                 loss_scale=1.0, accumulate=False, self_cond=None):
+                 loss_scale=1.0, accumulate=False, self_cond=None, text_emb=None):
         """:823-889: returns the loss (0-dim CPU tensor); the parameter gradients stay on the model
         (``self.model.grad(name)`` / ``.grads()``) -- loss and backward are one call of the library, there is no autograd
         graph to keep.  ``loss_scale`` / ``accumulate`` are the micro-batch loop of ``Trainer.train`` (:1164-1176):
@@ -267,13 +267,15 @@ class DenoisingDiffusion:
             cond = cond.to(self.device, torch.float32).contiguous()
             assert cond.shape[0] == b and tuple(cond.shape[2:]) == (h, w), "batch / size mismatch between x and cond"
             cc = int(cond.shape[1])
+        ctx, m = self.model._ctx(text_emb, b) if text_emb is not None else (None, 0)
         loss = C.c_float(0.0)
         out = torch.empty_like(x_start) if return_model_out else None
         t_arr = (C.c_int64 * b)(*[int(v) for v in t_cpu.tolist()])
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self._lib.dm_unet_loss_backward(
             self.model._handle, _lib.ptr(x_start), C.cast(t_arr, C.POINTER(C.c_int64)),
-            C.cast(coef.data_ptr(), C.POINTER(C.c_float)), _lib.ptr(noise), _lib.ptr(cond), cc, sc_mode, self._objective_id,
+            C.cast(coef.data_ptr(), C.POINTER(C.c_float)), _lib.ptr(noise), _lib.ptr(cond), cc, _lib.ptr(ctx), m, sc_mode,
+            self._objective_id,
             float(loss_scale), int(bool(accumulate)), C.byref(loss), _lib.ptr(out), b, h, w, stream))
         val = torch.tensor(loss.value, dtype=torch.float32)
         return (val, out) if return_model_out else val
@@ -427,6 +429,19 @@ class TextConditionalDenoisingDiffusion(DenoisingDiffusion):
         return sample_fn((batch_size, channels, h, w), save_path_for_text, return_all_timesteps=return_all_timesteps,
                          **kw)
 
+    def p_losses(self, x_start, t, text_emb=None, noise=None, offset_noise_strength=None, **kw):
+        """denoising_diffusion_text_conditional.py:476-542 (the reference's positional order: x_start, t, text_emb, noise)."""
+        return super().p_losses(x_start, t, noise, offset_noise_strength, text_emb=text_emb, **kw)
+
+    def forward(self, img, text_emb=None, *args, **kwargs):
+        """denoising_diffusion_text_conditional.py:544-550: the training loss with the caption embeddings."""
+        b, c, h, w = img.shape
+        assert (h, w) == tuple(self.image_size), f"height and width of image must be {self.image_size}"
+        t = torch.randint(0, self.num_timesteps, (b,)).long()
+        return self.p_losses(self.normalize(img.to(self.device, torch.float32)), t, text_emb, *args, **kwargs)
+
+    __call__ = forward
+
     @torch.inference_mode()
     def p_sample(self, x, t: int, text_emb=None, x_self_cond=None, *, noise=None):
         """denoising_diffusion_text_conditional.py:310-317 (the reference's positional order: x, t, text_emb)."""
@@ -525,6 +540,17 @@ class LatentDiffusion(DenoisingDiffusion):
     def decode(self, latents):
         return self.vae.decode(latents)
 
+    def encode(self, images):
+        """latent_diffusion.py:33-40: the (frozen) VAE's latents of a batch of images."""
+        latents = self.vae.encode(images)
+        return latents[0] if isinstance(latents, tuple) else latents
+
+    def forward(self, real_images, *args, **kwargs):
+        """latent_diffusion.py:51-56: the training loss on the VAE latents of the images."""
+        return super().forward(self.encode(real_images), *args, **kwargs)
+
+    __call__ = forward
+
     @torch.inference_mode()
     def sample(self, batch_size=16, return_all_timesteps=False, **kw):
         (h, w), channels = self.image_size, self.channels
@@ -554,6 +580,12 @@ class TextConditionalLatentDiffusion(TextConditionalDenoisingDiffusion):
 
     def decode(self, latents):
         return self.vae.decode(latents)
+
+    def forward(self, target, text_emb, *args, **kwargs):
+        """latent_diffusion_text_conditional.py:62-76: the text-conditional training loss on the VAE latents of `target`."""
+        return super().forward(self.encode(target), text_emb, *args, **kwargs)
+
+    __call__ = forward
 
     @torch.inference_mode()
     def sample(self, batch_size=16, save_path_for_text=None, return_all_timesteps=False, **kw):
@@ -588,6 +620,13 @@ class ImageConditionalLatentDiffusion(ImageConditionalDenoisingDiffusion):
 
     def decode(self, latents, cond=False):
         return (self.cond_vae if cond else self.vae).decode(latents)
+
+    def forward(self, target, cond, *args, **kwargs):
+        """latent_diffusion_image_conditional.py:171-183: the training loss on the latents of `target`, conditioned on the
+        latents of `cond` (each through its own VQ model)."""
+        return super().forward(self.encode(target), *args, cond=self.encode(cond, cond=True), **kwargs)
+
+    __call__ = forward
 
     def get_random_condition(self, batch, device):
         """:82-111: like the pixel-space variant, at ``init_image_size``."""

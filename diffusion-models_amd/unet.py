@@ -158,9 +158,8 @@ class Unet:
         if mode:
             if not self._loaded:
                 raise RuntimeError("load_state_dict() must be called before train()")
-            if self.text_condition or (self.self_condition and self.cfg.cond_channels):
-                raise NotImplementedError("the HIP training step covers the unconditional, self-conditioned and "
-                                          "image-conditional U-Net (not text-conditional, not self-condition + image)")
+            if self.self_condition and self.cfg.cond_channels:
+                raise NotImplementedError("the HIP training step does not combine self-conditioning with an image condition")
             _lib.check(self._lib.dm_unet_train_enable(self._handle))
             if not getattr(self, "_training", False):
                 self.set_dropout_seed(int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()))

@@ -316,11 +316,13 @@ int dm_unet_get_grad(dm_unet* u, const char* name, float* out_dev, void* stream)
  * what the buffers hold (the micro-batch loop of Trainer.train, :1164-1176).  loss_out_host receives the scalar loss;
  * model_out (optional, device) the U-Net output.  cond (optional): the condition image (B, cond_channels, H, W) of the
  * image-conditional variant, concatenated behind x in front of init_conv (DD/denoising_diffusion_image_conditional.py:51-55,
- * p_losses :251-311).  The call synchronises the stream. */
+ * p_losses :251-311).  ctx (optional): the text embeddings (B, ctx_tokens, text_emb_dim) of the text-conditional variant
+ * (DD/denoising_diffusion_text_conditional.py:131-214, p_losses :476-542), concat or cross-attention per the handle's
+ * text_mode.  The call synchronises the stream. */
 int dm_unet_loss_backward(dm_unet* u, const float* x_start, const int64_t* t_host, const float* coef_host,
-                          const float* noise, const float* cond, int cond_channels, int self_cond, int objective,
-                          float loss_scale, int accumulate, float* loss_out_host, float* model_out, int B, int H, int W,
-                          void* stream);
+                          const float* noise, const float* cond, int cond_channels, const float* ctx, int ctx_tokens,
+                          int self_cond, int objective, float loss_scale, int accumulate, float* loss_out_host,
+                          float* model_out, int B, int H, int W, void* stream);
 /* The rest of one Trainer.train iteration (:1178-1190) on device-resident state: the master parameters, the Adam moments and
  * the EMA copy live in flat device buffers in the reference layouts; after the update every packed weight buffer the
  * kernels read is rebuilt on the device (pack_kernels.hip, bit-identical to the host packers).
