@@ -6,10 +6,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 echo "== pmc"; bash tools/pmc_run.sh ${tag}_pmc
 python3 tools/pmc_summary.py gpurun_out/${tag}_pmc > gpurun_out/${tag}_pmc_hbm_traffic.json
 mkdir -p profiles && cp gpurun_out/${tag}_pmc_hbm_traffic.json profiles/${tag}_pmc_hbm_traffic.json
-echo "== bench"; python3 bench.py --steps 3 --warmup 1 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 600 gpurun_out/${tag}_bench.json
 echo "== rocprof stats (ddpm1000, 1 call)"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -o s -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-other-configs --no-train > gpurun_out/${tag}_stats.log 2>&1
 rm -f gpurun_out/${tag}_stats/*kernel_trace.csv; ls gpurun_out/${tag}_stats
+cp gpurun_out/${tag}_stats/s_kernel_stats.csv profiles/${tag}_kernel_stats.csv   # bench.py reads the family shares from it
+echo "== bench"; python3 bench.py --steps 3 --warmup 1 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 600 gpurun_out/${tag}_bench.json
 echo "== configs"; python3 tools/config_bench.py > gpurun_out/${tag}_other_configs.txt 2>&1; tail -12 gpurun_out/${tag}_other_configs.txt
 echo "== b8 stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_b8 -o s -- python3 tools/step_time.py --batch 8 --size 64 > gpurun_out/${tag}_b8.log 2>&1
