@@ -30,7 +30,7 @@ EXPORTS = (
     "dm_op_attention", "dm_op_sampler_update",
     "dm_conv_create", "dm_conv_destroy", "dm_conv_forward", "dm_op_pool2d", "dm_op_resize_bilinear",
     "dm_op_copy_channels_nhwc", "dm_op_global_avgpool", "dm_op_linear",
-    "dm_unet_train_enable", "dm_unet_grad_floats", "dm_unet_get_grad", "dm_unet_loss_backward", "dm_op_q_sample",
+    "dm_unet_train_enable", "dm_unet_grad_floats", "dm_unet_grads_flat", "dm_unet_get_grad", "dm_unet_loss_backward", "dm_op_q_sample",
     "dm_unet_optimizer_step", "dm_unet_ema_update", "dm_unet_get_param", "dm_unet_train_sync", "dm_unet_check_device_pack",
     "dm_unet_train_dropout", "dm_op_dropout_mask",
     "dm_op_conv2d_bwd", "dm_op_downsample_bwd", "dm_op_block_bwd", "dm_op_rmsnorm_bwd", "dm_op_linear_attention_bwd",
@@ -147,6 +147,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_unet_grad_floats.argtypes = [vp]
     lib.dm_unet_grad_floats.restype = i64
     lib.dm_unet_get_grad.argtypes = [vp, C.c_char_p, fp, vp]
+    lib.dm_unet_grads_flat.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     lib.dm_unet_loss_backward.argtypes = [vp, fp, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, i32, fp, i32, i32, i32,
                                           C.c_float, i32, C.POINTER(C.c_float), fp, i32, i32, i32, vp]
     lib.dm_unet_optimizer_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), vp]

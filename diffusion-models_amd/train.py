@@ -76,10 +76,13 @@ class EMA:
 
 
 def train_step(diffusion, micro_batches: Iterable[torch.Tensor], *, lr=1e-4, betas=(0.9, 0.99), eps=1e-8,
-               max_grad_norm=1.0, ema: Optional[EMA] = None, t=None, noise=None):
+               max_grad_norm=1.0, ema: Optional[EMA] = None, t=None, noise=None, group=None):
     """One iteration of ``Trainer.train`` (:1164-1190).  ``micro_batches``: the ``gradient_accumulate_every`` image batches
     (in [0, 1]) of the iteration.  ``t`` / ``noise`` (lists, one per micro-batch) inject the random draws for tests.
-    Returns (total_loss, grad_norm)."""
+    Under ``torch.distributed`` (one process per GPU, as ``accelerate`` runs the reference's Trainer) every rank computes the
+    gradients of ITS micro-batches and ONE in-place all-reduce of the flat gradient buffer (RCCL over xGMI) averages them
+    before the optimiser step -- all 245 gradients in a single collective; every rank then takes the same step.
+    Returns (total_loss of this rank, grad_norm)."""
     batches = list(micro_batches)
     k = len(batches)
     total = 0.0
@@ -88,6 +91,13 @@ def train_step(diffusion, micro_batches: Iterable[torch.Tensor], *, lr=1e-4, bet
         ti = t[i] if t is not None else torch.randint(0, diffusion.num_timesteps, (x.shape[0],)).long()
         ni = noise[i] if noise is not None else None
         total += float(diffusion.p_losses(x, ti, noise=ni, loss_scale=1.0 / k, accumulate=i > 0))
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():  # also at world size 1: the collective is the same code path
+        flat = diffusion.model.grads_flat()
+        torch.cuda.current_stream(diffusion.device).synchronize()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(dist.get_world_size(group))  # DDP averages; the buffer is the library's own (zero-copy view)
     norm = diffusion.model.optimizer_step(lr=lr, betas=betas, eps=eps, max_grad_norm=max_grad_norm)
     if ema is not None:
         ema.update()

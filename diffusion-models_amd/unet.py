@@ -185,6 +185,18 @@ class Unet:
     def grads(self) -> Dict[str, torch.Tensor]:
         return {name: self.grad(name) for name, _ in self.param_spec()}
 
+    def grads_flat(self) -> torch.Tensor:
+        """A zero-copy torch VIEW of the library's flat gradient buffer (all parameters, state-dict order): what
+        data-parallel training all-reduces in place -- one collective for every gradient."""
+        ptr, n = C.c_void_p(), C.c_int64(0)
+        _lib.check(self._lib.dm_unet_grads_flat(self._handle, C.byref(ptr), C.byref(n)))
+
+        class _View:  # the CUDA array interface: torch wraps the memory without copying or owning it
+            __cuda_array_interface__ = {"shape": (int(n.value),), "typestr": "<f4", "data": (int(ptr.value), False),
+                                        "version": 2}
+
+        return torch.as_tensor(_View(), device=self.device)
+
     def optimizer_step(self, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=1.0) -> float:
         """``clip_grad_norm_(max_grad_norm)`` + ``Adam(lr, betas).step()`` of ``Trainer.train``
         (denoising_diffusion.py:1006, :1178-1183) on the device-resident parameters; every packed weight buffer is then

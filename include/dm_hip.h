@@ -303,6 +303,9 @@ int dm_op_linear(const float* x, const float* weight, const float* bias, float* 
 int dm_unet_train_enable(dm_unet* u);
 /* total floats of the flat gradient buffer (parameters in state-dict order, each padded to a multiple of 4), or -1 */
 int64_t dm_unet_grad_floats(dm_unet* u);
+/* the flat gradient buffer itself (device pointer, dm_unet_grad_floats floats): data-parallel training (accelerate / DDP in
+ * the reference's Trainer) all-reduces it in place -- ONE collective for all gradients -- before dm_unet_optimizer_step */
+int dm_unet_grads_flat(dm_unet* u, float** ptr_out, int64_t* n_out);
 /* copy the gradient of one parameter (names as in dm_unet_set_param) into a DEVICE buffer of the parameter's size */
 int dm_unet_get_grad(dm_unet* u, const char* name, float* out_dev, void* stream);
 /* One p_losses call (:823-889) + backward:
