@@ -1,4 +1,4 @@
-// Winograd F(4x4, 3x3) convolution for gfx950 on the f32-input MFMA (v_mfma_f32_32x32x2_f32).
+// Winograd F(4x4, 3x3) convolution for gfx950 on the f32-input MFMA (v_mfma_f32_16x16x4_f32).
 //
 // The 3x3 / stride-1 / pad-1 convolutions of Block (DD/denoising_diffusion.py:108, inside ResnetBlock :136-148) and
 // the plain 3x3 convs of the last Downsample / Upsample stage (:291, :303) on power-of-two images: 36 multiplies per

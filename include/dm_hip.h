@@ -277,7 +277,8 @@ typedef struct dm_conv dm_conv;
 int dm_conv_create(const float* weight_host, const float* bias_host, int Cout, int Cin, int KH, int KW, int stride,
                    int pad_h, int pad_w, int relu, int device, dm_conv** out);
 void dm_conv_destroy(dm_conv* c);
-/* in: (B, H, W, Cin) NHWC, or (B, Cin, H, W) when in_nchw != 0; out: (B, Ho, Wo, Cout) NHWC */
+/* in: (B, H, W, Cin) NHWC, or (B, Cin, H, W) when in_nchw != 0; out: (B, Ho, Wo, Cout) NHWC.  All dm_conv handles of a
+ * device share one scratch workspace (K-split partial sums): their calls must be ordered on one stream. */
 int dm_conv_forward(dm_conv* c, const float* in, int in_nchw, int B, int H, int W, float* out_nhwc, void* stream);
 /* F.max_pool2d / F.avg_pool2d on NHWC: mode 0 max, 1 avg with count_include_pad=True, 2 avg with count_include_pad=False */
 int dm_op_pool2d(const float* in, float* out, int B, int H, int W, int C, int k, int stride, int pad, int mode,
