@@ -17,32 +17,43 @@ namespace dm {
 
 constexpr int BDH = 32;
 constexpr int NMEM = 4;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ f32x4 make_f32x4(float a, float b, float c, float d) { return f32x4{a, b, c, d}; }
 
-// part 1: grid (ceil(n / 64), B), 64 * heads threads (thread = head * 64 + token): dq, and this block's share of dctx
-__global__ __launch_bounds__(256) void linattn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
-                                     const float* __restrict__ dout, float* __restrict__ dqkv,
-                                     float* __restrict__ dctx_part, int n, int heads, float scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* cs = sm;                                // [heads][32][32] ctx
-    float* ps = cs + heads * BDH * BDH;            // [heads][64][33] scale * p
-    float* ds = ps + heads * 64 * (BDH + 1);       // [heads][64][33] dout
-    const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
-    const int tid = threadIdx.x;
-    const int h = tid >> 6, tl = tid & 63;
+constexpr int LSTR = BDH + 4;  // LDS row stride of a token row: 16-byte aligned, 128-bit accesses of 8 consecutive lanes cover all banks
+
+// part 1: grid (ceil(n / 64), heads, B), one wave (lane = token): dq, and this block's share of dctx.  One head per block
+// keeps the tile at 22 KB, so seven blocks share a CU and hide each other's row loads.
+__global__ __launch_bounds__(64) void linattn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                           const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                           float* __restrict__ dctx_part, int n, int heads, float scale) {
+    __shared__ __attribute__((aligned(16))) float cs[BDH * BDH];   // ctx of this (image, head)
+    __shared__ __attribute__((aligned(16))) float ps[64 * LSTR];   // scale * p
+    __shared__ __attribute__((aligned(16))) float ds[64 * LSTR];   // dout
+    const int blk = blockIdx.x, nblk = gridDim.x, h = blockIdx.y, b = blockIdx.z;
+    const int tl = threadIdx.x;
     const int tok = blk * 64 + tl;
     const int ld = 3 * heads * BDH, hid = heads * BDH;
-    for (int i = tid; i < heads * BDH * BDH; i += blockDim.x) cs[i] = ctx[(size_t)b * heads * BDH * BDH + i];
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(ctx + (size_t)(b * heads + h) * BDH * BDH);
+        for (int i = tl; i < BDH * BDH / 4; i += 64) reinterpret_cast<f32x4*>(cs)[i] = src[i];
+    }
     float q[BDH], dq[BDH], dov[BDH];
     const bool ok = tok < n;
-    const float* qp = qkv + ((size_t)b * n + (ok ? tok : 0)) * ld + h * BDH;
-    const float* dp = dout + ((size_t)b * n + (ok ? tok : 0)) * hid + h * BDH;
+    const f32x4* qp = reinterpret_cast<const f32x4*>(qkv + ((size_t)b * n + (ok ? tok : 0)) * ld + h * BDH);
+    const f32x4* dp = reinterpret_cast<const f32x4*>(dout + ((size_t)b * n + (ok ? tok : 0)) * hid + h * BDH);
+#pragma unroll
+    for (int j = 0; j < BDH / 4; ++j) {
+        const f32x4 a = qp[j], c = dp[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            q[4 * j + i] = a[i];
+            dov[4 * j + i] = ok ? c[i] : 0.f;
+        }
+    }
     float m = -INFINITY;
 #pragma unroll
-    for (int d = 0; d < BDH; ++d) {
-        q[d] = qp[d];
-        dov[d] = ok ? dp[d] : 0.f;
-        m = fmaxf(m, q[d]);
-    }
+    for (int d = 0; d < BDH; ++d) m = fmaxf(m, q[d]);
     float sum = 0.f;
 #pragma unroll
     for (int d = 0; d < BDH; ++d) {
@@ -56,143 +67,212 @@ __global__ __launch_bounds__(256) void linattn_bwd_q_kernel(const float* __restr
     for (int d = 0; d < BDH; ++d) {
         q[d] *= inv;  // p
         float s = 0.f;
-        const float* cr = cs + (h * BDH + d) * BDH;
+        const float* cr = cs + d * BDH;
 #pragma unroll
         for (int e = 0; e < BDH; ++e) s += cr[e] * dov[e];
         dq[d] = s;  // dqs
         dot += q[d] * s;
     }
     if (ok) {
-        float* o = dqkv + ((size_t)b * n + tok) * ld + h * BDH;
+        f32x4* o = reinterpret_cast<f32x4*>(dqkv + ((size_t)b * n + tok) * ld + h * BDH);
 #pragma unroll
-        for (int d = 0; d < BDH; ++d) o[d] = scale * q[d] * (dq[d] - dot);
+        for (int j = 0; j < BDH / 4; ++j)
+            o[j] = make_f32x4(scale * q[4 * j] * (dq[4 * j] - dot), scale * q[4 * j + 1] * (dq[4 * j + 1] - dot),
+                              scale * q[4 * j + 2] * (dq[4 * j + 2] - dot), scale * q[4 * j + 3] * (dq[4 * j + 3] - dot));
     }
 #pragma unroll
-    for (int d = 0; d < BDH; ++d) {
-        ps[(h * 64 + tl) * (BDH + 1) + d] = ok ? scale * q[d] : 0.f;
-        ds[(h * 64 + tl) * (BDH + 1) + d] = dov[d];
+    for (int j = 0; j < BDH / 4; ++j) {
+        const float z = ok ? scale : 0.f;
+        *reinterpret_cast<f32x4*>(ps + tl * LSTR + 4 * j) =
+            make_f32x4(z * q[4 * j], z * q[4 * j + 1], z * q[4 * j + 2], z * q[4 * j + 3]);
+        *reinterpret_cast<f32x4*>(ds + tl * LSTR + 4 * j) = make_f32x4(dov[4 * j], dov[4 * j + 1], dov[4 * j + 2], dov[4 * j + 3]);
     }
     __syncthreads();
-    // dctx share of this block: thread -> (head, d, 16 e's)
+    // dctx share of this block: lane -> (d, 16 e's), tokens in order
     {
-        const int hh = tid >> 6, d = (tid & 63) >> 1, e0 = (tid & 1) * 16;
+        const int d = tl >> 1, e0 = (tl & 1) * 16;
         float acc[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         for (int t = 0; t < 64; ++t) {
-            const float pv = ps[(hh * 64 + t) * (BDH + 1) + d];
-            const float* dr = ds + (hh * 64 + t) * (BDH + 1) + e0;
+            const float pv = ps[t * LSTR + d];
+            const f32x4* dr = reinterpret_cast<const f32x4*>(ds + t * LSTR + e0);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] += pv * dr[e];
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 v = dr[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[4 * j + i] += pv * v[i];
+            }
         }
-        float* o = dctx_part + ((((size_t)b * nblk + blk) * heads + hh) * BDH + d) * BDH + e0;
+        f32x4* o = reinterpret_cast<f32x4*>(dctx_part + ((((size_t)b * nblk + blk) * heads + h) * BDH + d) * BDH + e0);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[e] = acc[e];
+        for (int j = 0; j < 4; ++j) o[j] = make_f32x4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
     }
 }
 
-// part 2: grid (heads, B), 256 threads: dk, dv (and the memory key/value gradients of this image)
-__global__ __launch_bounds__(256) void linattn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ mem_kv,
-                                                             const float* __restrict__ ctx,
-                                                             const float* __restrict__ dctx_part, int nblk,
-                                                             float* __restrict__ dqkv, float* __restrict__ dmem_part, int n,
-                                                             int heads) {
+// part 2a: grid (heads, B), 256 threads: dctx = sum of the block shares (left in share 0), per d the softmax statistics of
+// k over the tokens (memory tokens first, as the reference concatenates them) and S[d] -> stats (B, heads, 3, 32), and the
+// gradients of this image's 4 memory key/value tokens
+__global__ __launch_bounds__(256) void linattn_bwd_stats_kernel(const float* __restrict__ qkv, const float* __restrict__ mem_kv,
+                                                                const float* __restrict__ ctx, float* __restrict__ dctx_part,
+                                                                int nblk, float* __restrict__ stats,
+                                                                float* __restrict__ dmem_part, int n, int heads) {
     __shared__ float dctx[BDH][BDH + 1];
-    __shared__ float S[BDH], kmax[BDH], kinv[BDH];
+    __shared__ float kmax[BDH], kinv[BDH], S[BDH];
     __shared__ float red[8][BDH];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int ld = 3 * heads * BDH;
     const float* kbase = qkv + (size_t)b * n * ld + heads * BDH + h * BDH;
-    const float* vbase = qkv + (size_t)b * n * ld + 2 * heads * BDH + h * BDH;
-    const float* mk = mem_kv + (size_t)h * BDH * NMEM;            // [d][j]
-    const float* mv = mem_kv + (size_t)(heads + h) * BDH * NMEM;  // [e][j]
-    const int ntok = n + NMEM;
+    const float* mk = mem_kv + (size_t)h * BDH * NMEM;  // [d][j]
     for (int i = tid; i < BDH * BDH; i += 256) {
         float s = 0.f;
         for (int k = 0; k < nblk; ++k) s += dctx_part[(((size_t)b * nblk + k) * heads + h) * BDH * BDH + i];
         dctx[i >> 5][i & 31] = s;
+        dctx_part[((size_t)b * nblk * heads + h) * BDH * BDH + i] = s;
     }
-    // softmax statistics of k over the tokens (memory tokens first, as the reference concatenates them)
+    const int d = tid & 31, part = tid >> 5;
+    float m = part < NMEM ? mk[d * NMEM + part] : -INFINITY;
     {
-        const int d = tid & 31, part = tid >> 5;
-        float m = -INFINITY;
-        for (int t = part; t < ntok; t += 8) m = fmaxf(m, t < NMEM ? mk[d * NMEM + t] : kbase[(size_t)(t - NMEM) * ld + d]);
-        red[part][d] = m;
-        __syncthreads();
-        if (tid < BDH) {
-            float mm = red[0][tid];
-            for (int q = 1; q < 8; ++q) mm = fmaxf(mm, red[q][tid]);
-            kmax[tid] = mm;
+        int t = part;
+        for (; t + 56 < n; t += 64) {  // 8 independent row loads in flight
+            float kv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kv[j] = kbase[(size_t)(t + 8 * j) * ld + d];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = fmaxf(m, kv[j]);
         }
-        __syncthreads();
-        float s = 0.f;
-        const float km = kmax[d];
-        for (int t = part; t < ntok; t += 8)
-            s += __expf((t < NMEM ? mk[d * NMEM + t] : kbase[(size_t)(t - NMEM) * ld + d]) - km);
-        __syncthreads();
-        red[part][d] = s;
-        __syncthreads();
-        if (tid < BDH) {
-            float ss = 0.f;
-            for (int q = 0; q < 8; ++q) ss += red[q][tid];
-            kinv[tid] = 1.0f / ss;
-            const float* cr = ctx + ((size_t)(b * heads + h) * BDH + tid) * BDH;
-            float sd = 0.f;
-            for (int e = 0; e < BDH; ++e) sd += dctx[tid][e] * cr[e];
-            S[tid] = sd;
-        }
-        __syncthreads();
+        for (; t < n; t += 8) m = fmaxf(m, kbase[(size_t)t * ld + d]);
     }
-    // one token per thread; only v and the dv accumulators live in registers over the d loop (ks[d] and dk[d] are formed and
-    // stored row by row: holding all four 32-vectors spilled 343 registers)
-    for (int t = tid; t < ntok; t += 256) {
-        const bool mem = t < NMEM;
-        float vv[BDH], dvv[BDH];
+    red[part][d] = m;
+    __syncthreads();
+    if (tid < BDH) {
+        float mm = red[0][tid];
+        for (int q = 1; q < 8; ++q) mm = fmaxf(mm, red[q][tid]);
+        kmax[tid] = mm;
+    }
+    __syncthreads();
+    const float km = kmax[d];
+    float s = part < NMEM ? __expf(mk[d * NMEM + part] - km) : 0.f;
+    {
+        int t = part;
+        for (; t + 56 < n; t += 64) {
+            float kv[8];
 #pragma unroll
-        for (int e = 0; e < BDH; ++e) {
-            vv[e] = mem ? mv[e * NMEM + t] : vbase[(size_t)(t - NMEM) * ld + e];
-            dvv[e] = 0.f;
+            for (int j = 0; j < 8; ++j) kv[j] = kbase[(size_t)(t + 8 * j) * ld + d];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += __expf(kv[j] - km);
         }
-        float* ok = mem ? dmem_part + (size_t)b * 2 * heads * BDH * NMEM + (size_t)h * BDH * NMEM + t
-                        : dqkv + ((size_t)b * n + (t - NMEM)) * ld + heads * BDH + h * BDH;
-        const int ks_stride = mem ? NMEM : 1;
-#pragma unroll 2
-        for (int d = 0; d < BDH; ++d) {
-            const float kv = mem ? mk[d * NMEM + t] : kbase[(size_t)(t - NMEM) * ld + d];
-            const float ksd = __expf(kv - kmax[d]) * kinv[d];
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < BDH; ++e) {
-                const float c = dctx[d][e];
-                s += c * vv[e];
-                dvv[e] += ksd * c;
-            }
-            ok[d * ks_stride] = ksd * (s - S[d]);
+        for (; t < n; t += 8) s += __expf(kbase[(size_t)t * ld + d] - km);
+    }
+    __syncthreads();
+    red[part][d] = s;
+    __syncthreads();
+    if (tid < BDH) {
+        float ss = 0.f;
+        for (int q = 0; q < 8; ++q) ss += red[q][tid];
+        const float* cr = ctx + ((size_t)(b * heads + h) * BDH + tid) * BDH;
+        float sd = 0.f;
+        for (int e = 0; e < BDH; ++e) sd += dctx[tid][e] * cr[e];
+        float* st = stats + (size_t)(b * heads + h) * 3 * BDH;
+        st[tid] = kmax[tid];
+        st[BDH + tid] = kinv[tid] = 1.0f / ss;
+        st[2 * BDH + tid] = S[tid] = sd;
+    }
+    __syncthreads();
+    if (tid < NMEM * BDH) {  // memory tokens: thread (t, x) forms dk[d = x][t] and dv[e = x][t]
+        const int t = tid >> 5, x = tid & 31;
+        const float* mv = mem_kv + (size_t)(heads + h) * BDH * NMEM;  // [e][j]
+        float sk = 0.f, sv = 0.f;
+        for (int j = 0; j < BDH; ++j) {
+            sk += dctx[x][j] * mv[j * NMEM + t];
+            sv += __expf(mk[j * NMEM + t] - kmax[j]) * kinv[j] * dctx[j][x];
         }
-        float* ov = mem ? dmem_part + (size_t)b * 2 * heads * BDH * NMEM + (size_t)(heads + h) * BDH * NMEM + t
-                        : dqkv + ((size_t)b * n + (t - NMEM)) * ld + 2 * heads * BDH + h * BDH;
-#pragma unroll
-        for (int e = 0; e < BDH; ++e) ov[e * ks_stride] = dvv[e];
+        float* o = dmem_part + (size_t)b * 2 * heads * BDH * NMEM;
+        o[((size_t)h * BDH + x) * NMEM + t] = __expf(mk[x * NMEM + t] - kmax[x]) * kinv[x] * (sk - S[x]);
+        o[((size_t)(heads + h) * BDH + x) * NMEM + t] = sv;
     }
 }
 
-size_t linattn_bwd_ws_floats(int B, int n, int heads) { return (size_t)B * ((n + 63) / 64) * heads * BDH * BDH; }
+// part 2b: grid (ceil(n / 64), heads, B), one wave (lane = token): dk, dv.  k and v rows sit in registers; dk overwrites k
+// row by row.
+__global__ __launch_bounds__(64, 3) void linattn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx_part,
+                                                            int nblk, const float* __restrict__ stats, float* __restrict__ dqkv,
+                                                            int n, int heads) {
+    __shared__ __attribute__((aligned(16))) float dctx[BDH * BDH];
+    __shared__ float st[3 * BDH];
+    const int h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    const int ld = 3 * heads * BDH;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(dctx_part + ((size_t)b * nblk * heads + h) * BDH * BDH);
+        for (int i = lane; i < BDH * BDH / 4; i += 64) reinterpret_cast<f32x4*>(dctx)[i] = src[i];
+        for (int i = lane; i < 3 * BDH; i += 64) st[i] = stats[(size_t)(b * heads + h) * 3 * BDH + i];
+    }
+    __syncthreads();
+    const int t = blockIdx.x * 64 + lane;
+    if (t >= n) return;
+    // two passes over dctx, so that only two 32-vectors and one dctx row are live at a time (one pass holding k, v, dv and
+    // the prefetched rows spills at 3 waves per SIMD):  dv[e] = sum_d ks[d] dctx[d][e], then dk[d] = ks[d] (dctx[d] . v - S[d])
+    float kk[BDH], vv[BDH];
+    const f32x4* kp = reinterpret_cast<const f32x4*>(qkv + ((size_t)b * n + t) * ld + heads * BDH + h * BDH);
+    const f32x4* vp = reinterpret_cast<const f32x4*>(qkv + ((size_t)b * n + t) * ld + 2 * heads * BDH + h * BDH);
+    f32x4* ok = reinterpret_cast<f32x4*>(dqkv + ((size_t)b * n + t) * ld + heads * BDH + h * BDH);
+    f32x4* ov = reinterpret_cast<f32x4*>(dqkv + ((size_t)b * n + t) * ld + 2 * heads * BDH + h * BDH);
+#pragma unroll
+    for (int j = 0; j < BDH / 4; ++j) {
+        const f32x4 a = kp[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            kk[4 * j + i] = __expf(a[i] - st[4 * j + i]) * st[BDH + 4 * j + i];  // ks
+            vv[4 * j + i] = 0.f;                                                 // dv
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < BDH; ++d) {
+#pragma unroll
+        for (int e = 0; e < BDH; ++e) vv[e] += kk[d] * dctx[d * BDH + e];
+        asm volatile("" ::: "memory");  // one dctx row in flight
+    }
+#pragma unroll
+    for (int j = 0; j < BDH / 4; ++j) ov[j] = make_f32x4(vv[4 * j], vv[4 * j + 1], vv[4 * j + 2], vv[4 * j + 3]);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < BDH / 4; ++j) {
+        const f32x4 c = vp[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vv[4 * j + i] = c[i];
+    }
+#pragma unroll
+    for (int d = 0; d < BDH; ++d) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < BDH; ++e) s += dctx[d * BDH + e] * vv[e];
+        kk[d] *= s - st[2 * BDH + d];  // dk
+        asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int j = 0; j < BDH / 4; ++j) ok[j] = make_f32x4(kk[4 * j], kk[4 * j + 1], kk[4 * j + 2], kk[4 * j + 3]);
+}
+
+// block shares of dctx (the sum lands in share 0) + the per-(image, head) statistics
+size_t linattn_bwd_ws_floats(int B, int n, int heads) {
+    return (size_t)B * ((n + 63) / 64) * heads * BDH * BDH + (size_t)B * heads * 3 * BDH;
+}
 
 // qkv (B, n, 3*heads*32), ctx (B, heads, 32, 32) as the forward core left it, dout (B, n, heads*32) -> dqkv (same shape as
 // qkv), dmem_part (B, 2, heads, 32, 4) per-image memory key/value gradients (the caller sums over B)
 int launch_linear_attention_core_bwd(const float* qkv, const float* mem_kv, const float* ctx, const float* dout, float* ws,
                                      float* dqkv, float* dmem_part, int B, int n, int heads, int dh, hipStream_t s) {
     DM_REQUIRE(dh == BDH && heads >= 1 && heads <= 16, "linear attention backward: dim_head 32");
+    DM_REQUIRE(B <= 65535 && n >= 1, "linear attention backward: batch");
     const int nblk = (n + 63) / 64;
-    const size_t lds = (size_t)(heads * BDH * BDH + 2 * heads * 64 * (BDH + 1)) * sizeof(float);
-    DM_REQUIRE(lds <= 160 * 1024 && 64 * heads <= 256, "linear attention backward: at most 4 heads per workgroup");
-    static LdsOptIn flag;
-    if (lds_opt_in(flag, reinterpret_cast<const void*>(linattn_bwd_q_kernel), 1)) return 1;
-    hipLaunchKernelGGL(linattn_bwd_q_kernel, dim3(nblk, B), dim3(64 * heads), lds, s, qkv, ctx, dout, dqkv, ws, n, heads,
+    float* stats = ws + (size_t)B * nblk * heads * BDH * BDH;
+    hipLaunchKernelGGL(linattn_bwd_q_kernel, dim3(nblk, heads, B), dim3(64), 0, s, qkv, ctx, dout, dqkv, ws, n, heads,
                        1.0f / sqrtf((float)dh));
     DM_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(linattn_bwd_kv_kernel, dim3(heads, B), dim3(256), 0, s, qkv, mem_kv, ctx, ws, nblk, dqkv, dmem_part, n,
-                       heads);
+    hipLaunchKernelGGL(linattn_bwd_stats_kernel, dim3(heads, B), dim3(256), 0, s, qkv, mem_kv, ctx, ws, nblk, stats, dmem_part,
+                       n, heads);
+    DM_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(linattn_bwd_kv_kernel, dim3(nblk, heads, B), dim3(64), 0, s, qkv, ws, nblk, stats, dqkv, n, heads);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }

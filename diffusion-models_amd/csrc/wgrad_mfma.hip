@@ -32,7 +32,7 @@ struct WgradParams {
     int C0, C1, Cin, Cout;
     int B, Ho, Wo;   // size of dY (and of the input the convolution sees, except s2d: input is 2Ho x 2Wo)
     int up;          // sources are (Ho/2, Wo/2), nearest-upsampled
-    int TW, R;       // pixel block: R rows x TW columns (TW even), R*TW <= 64
+    int TW, R, NB;   // pixel block: NB images x R rows x TW columns (TW even), NB*R*TW <= 64; NB > 1 only for whole images
     int tiles_x, tiles_y;
     int n_blocks, blocks_per_split;
     int n_ct, n_kt;  // cout / cin tiles of 64
@@ -77,95 +77,110 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p)
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
     // ---- staging items of this thread: (window pixel, channel quad) pairs do not depend on the block, only their image
-    //      coordinates do: the divisions are done once, a block costs additions and bounds checks
-    constexpr int YI = 4;                                       // dY: 64 px x 16 quads / 256 threads
-    constexpr int XI = MODE == 0 ? 13 : (MODE == 1 ? 4 : 16);   // X window items (upper bound, checked by the launcher)
+    //      coordinates do: the divisions are done once, a block costs additions and bounds checks.  The items of the NEXT
+    //      block are loaded into registers before the MFMA loop of the current one (one workgroup hides its own staging).
+    constexpr int YI = 4;                                      // dY: 64 px x 16 quads / 256 threads
+    constexpr int XI = MODE == 0 ? 9 : (MODE == 1 ? 4 : 16);   // X window items (upper bound, checked by the launcher)
+    const int NB = p.NB;
     const int q4 = 4 * (tid & 15);
-    int ypos[YI], xpos[XI];                                     // (row << 16) | column inside the block / window, -1: no item
+    int ypos[YI], xpos[XI];  // (image << 24) | (row << 12) | column inside the block / window, -1: no item
 #pragma unroll
     for (int j = 0; j < YI; ++j) {
         const int px = (tid >> 4) + 16 * j;
-        const int r = px / TW, c = px - r * TW;
-        ypos[j] = r < R ? (r << 16) | c : -1;
+        const int nb = px / (R * TW), rem = px - nb * (R * TW);
+        const int r = rem / TW, c = rem - r * TW;
+        ypos[j] = nb < NB ? (nb << 24) | (r << 12) | c : -1;
     }
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
         const int wp = (tid >> 4) + 16 * j;
-        const int wy = wp / WW, wx = wp - wy * WW;
-        xpos[j] = wp < WH * WW ? (wy << 16) | wx : -1;
+        const int nb = wp / (WH * WW), rem = wp - nb * (WH * WW);
+        const int wy = rem / WW, wx = rem - wy * WW;
+        xpos[j] = nb < NB ? (nb << 24) | (wy << 12) | wx : -1;
     }
     const int co_s = ct * 64 + q4, ci_s = kt * 64 + q4;
     const bool co_ok = co_s < p.Cout, ci_ok = ci_s < p.Cin;
     const bool src1 = ci_s >= p.C0;
     const float* xsrc = src1 ? p.in1 + (ci_s - p.C0) : p.in0 + ci_s;
     const int xC = src1 ? p.C1 : p.C0;
+    const int per_img = p.tiles_x * p.tiles_y;
+
+    f32x4 yreg[YI], xreg[XI];
+    auto load_block = [&](int blk) {
+        const int bg = blk / per_img, rem = blk - bg * per_img;
+        const int b0 = bg * NB;
+        const int y0 = (rem / p.tiles_x) * R, x0 = (rem % p.tiles_x) * TW;
+#pragma unroll
+        for (int j = 0; j < YI; ++j) {
+            f32x4 v = make_f32x4(0.f, 0.f, 0.f, 0.f);
+            if (ypos[j] >= 0) {
+                const int b = b0 + (ypos[j] >> 24), y = y0 + ((ypos[j] >> 12) & 0xFFF), x = x0 + (ypos[j] & 0xFFF);
+                if (b < p.B && y < p.Ho && x < p.Wo && co_ok)
+                    v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)(b * p.Ho + y) * p.Wo + x) * p.Cout + co_s);
+            }
+            yreg[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            f32x4 v = make_f32x4(0.f, 0.f, 0.f, 0.f);
+            if (xpos[j] >= 0) {
+                const int b = b0 + (xpos[j] >> 24), wy = (xpos[j] >> 12) & 0xFFF, wx = xpos[j] & 0xFFF;
+                int sy, sx;
+                bool ok;
+                if (MODE == 0) {
+                    const int uy = y0 - 1 + wy, ux = x0 - 1 + wx;
+                    ok = uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo;
+                    sy = p.up ? uy >> 1 : uy;
+                    sx = p.up ? ux >> 1 : ux;
+                } else {
+                    sy = S * y0 + wy;
+                    sx = S * x0 + wx;
+                    ok = sy < Hs && sx < Ws;
+                }
+                if (ok && ci_ok && b < p.B) v = *reinterpret_cast<const f32x4*>(xsrc + ((size_t)(b * Hs + sy) * Ws + sx) * xC);
+            }
+            xreg[j] = v;
+        }
+    };
 
     const int blk0 = split * p.blocks_per_split;
     const int blk1 = min(blk0 + p.blocks_per_split, p.n_blocks);
+    if (blk0 < blk1) load_block(blk0);
     for (int blk = blk0; blk < blk1; ++blk) {
-        const int per_img = p.tiles_x * p.tiles_y;
-        const int b = blk / per_img, rem = blk - b * per_img;
-        const int y0 = (rem / p.tiles_x) * R, x0 = (rem % p.tiles_x) * TW;
         __syncthreads();  // the previous block's MFMA loop is done with the tiles
-        // ---- stage dY: 64 pixels x 16 float4
 #pragma unroll
-        for (int j = 0; j < YI; ++j) {
-            const int px = (tid >> 4) + 16 * j;
-            f32x4 v = make_f32x4(0.f, 0.f, 0.f, 0.f);
-            if (ypos[j] >= 0) {
-                const int y = y0 + (ypos[j] >> 16), x = x0 + (ypos[j] & 0xFFFF);
-                if (y < p.Ho && x < p.Wo && co_ok)
-                    v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)(b * p.Ho + y) * p.Wo + x) * p.Cout + co_s);
-            }
-            *reinterpret_cast<f32x4*>(sY + px * WG_SY + q4) = v;
-        }
-        // ---- stage the X window
+        for (int j = 0; j < YI; ++j) *reinterpret_cast<f32x4*>(sY + ((tid >> 4) + 16 * j) * WG_SY + q4) = yreg[j];
 #pragma unroll
-        for (int j = 0; j < XI; ++j) {
-            if (xpos[j] < 0) continue;
-            const int wp = (tid >> 4) + 16 * j;
-            const int wy = xpos[j] >> 16, wx = xpos[j] & 0xFFFF;
-            int sy, sx;
-            bool ok;
-            if (MODE == 0) {
-                const int uy = y0 - 1 + wy, ux = x0 - 1 + wx;
-                ok = uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo;
-                sy = p.up ? uy >> 1 : uy;
-                sx = p.up ? ux >> 1 : ux;
-            } else {
-                sy = S * y0 + wy;
-                sx = S * x0 + wx;
-                ok = sy < Hs && sx < Ws;
-            }
-            f32x4 v = make_f32x4(0.f, 0.f, 0.f, 0.f);
-            if (ok && ci_ok) v = *reinterpret_cast<const f32x4*>(xsrc + ((size_t)(b * Hs + sy) * Ws + sx) * xC);
-            *reinterpret_cast<f32x4*>(sX + wp * WG_SX + q4) = v;
-        }
+        for (int j = 0; j < XI; ++j)
+            if (xpos[j] >= 0) *reinterpret_cast<f32x4*>(sX + ((tid >> 4) + 16 * j) * WG_SX + q4) = xreg[j];
         __syncthreads();
-        // ---- MFMA: K = pixel pairs (2 cp + k) of every row of the block
+        if (blk + 1 < blk1) load_block(blk + 1);  // in flight during the MFMAs below
+        // ---- MFMA: K = pixel pairs (2 cp + k) of every row of every image of the block
         const float* ya = sY + wo * 32 + l31;
         const float* xb = sX + wc * 32 + l31;
+        for (int nb = 0; nb < NB; ++nb)
         for (int r = 0; r < R; ++r) {
             for (int cp = 0; cp < TW / 2; ++cp) {
                 const int c = 2 * cp + k;
-                const float a = ya[(r * TW + c) * WG_SY];
+                const float a = ya[((nb * R + r) * TW + c) * WG_SY];
+                const float* xw = xb + (size_t)nb * WH * WW * WG_SX;
                 if (MODE == 0) {
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) {
-                            const float bv = xb[((r + ky) * WW + c + kx) * WG_SX];
+                            const float bv = xw[((r + ky) * WW + c + kx) * WG_SX];
                             acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ky * 3 + kx], 0, 0, 0);
                         }
                 } else if (MODE == 1) {
-                    const float bv = xb[(r * WW + c) * WG_SX];
+                    const float bv = xw[(r * WW + c) * WG_SX];
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[0], 0, 0, 0);
                 } else {
 #pragma unroll
                     for (int p1 = 0; p1 < 2; ++p1)
 #pragma unroll
                         for (int p2 = 0; p2 < 2; ++p2) {
-                            const float bv = xb[((2 * r + p1) * WW + 2 * c + p2) * WG_SX];
+                            const float bv = xw[((2 * r + p1) * WW + 2 * c + p2) * WG_SX];
                             acc[p1 * 2 + p2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[p1 * 2 + p2], 0, 0, 0);
                         }
                 }
@@ -205,21 +220,43 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-size_t wgrad_ws_floats(int B, int Ho, int Wo, int Cout, int Cin, int T, int* splits_out) {
-    int TW = std::min((Wo + 1) & ~1, 64);
-    int R = std::max(1, std::min(64 / TW, Ho));
-    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + R - 1) / R;
-    const int n_blocks = B * tiles_x * tiles_y;
+// pixel-block geometry of a (Ho, Wo) output: R rows x TW columns of one image, or NB whole images when an image has at
+// most 32 pixels (4x4 / 2x2 / 1x1 maps of the deep layers: a 16-pixel block would stage as much as it multiplies)
+struct WgradGeo {
+    int TW, R, NB, tiles_x, tiles_y, n_blocks;
+};
+static WgradGeo wgrad_geo(int B, int Ho, int Wo, int mode) {
+    WgradGeo g{};
+    const int tw_max = mode == 0 ? 32 : 64;  // 3x3: the staged window of a block must fit 9 items per thread
+    g.TW = std::min((Wo + 1) & ~1, tw_max);
+    g.R = std::max(1, std::min(64 / g.TW, Ho));
+    g.tiles_x = (Wo + g.TW - 1) / g.TW;
+    g.tiles_y = (Ho + g.R - 1) / g.R;
+    g.NB = 1;
+    if (g.tiles_x == 1 && g.tiles_y == 1) {
+        const int win = mode == 0 ? (g.R + 2) * (g.TW + 2) : (mode == 2 ? 4 : 1) * g.R * g.TW;
+        const int items = 16 * (mode == 0 ? 9 : (mode == 1 ? 4 : 16));
+        g.NB = std::max(1, std::min(std::min(64 / (g.R * g.TW), items / win), B));
+    }
+    g.n_blocks = ((B + g.NB - 1) / g.NB) * g.tiles_x * g.tiles_y;
+    return g;
+}
+
+static size_t wgrad_ws_floats_mode(int B, int Ho, int Wo, int Cout, int Cin, int T, int mode, int* splits_out) {
+    const WgradGeo g = wgrad_geo(B, Ho, Wo, mode);
     const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
-    // enough workgroups to fill the chip twice (two per CU overlap their staging), at least 2 pixel blocks per split
-    // (swept 2 / 4 / 8: 14.85 / 15.06 / 16.55 ms per loss+backward at B=64): every split writes a full
-    // [T][Cout][Cin] partial tile that the reduce kernel reads back
+    // One workgroup per CU hides its own staging (the next block is loaded during the MFMAs), so the split count only has
+    // to fill the chip; every split writes a full [T][Cout][Cin] partial tile that the reduce kernel reads back.
     static const int min_bps = env_int("DM_WGRAD_MIN_BLOCKS", 2);
-    int splits = std::max(1, std::min((n_blocks + min_bps - 1) / min_bps, (512 + tiles - 1) / tiles));
-    const int bps = (n_blocks + splits - 1) / splits;
-    splits = (n_blocks + bps - 1) / bps;
+    static const int target = env_int("DM_WGRAD_TARGET_WGS", 256);
+    int splits = std::max(1, std::min((g.n_blocks + min_bps - 1) / min_bps, (target + tiles - 1) / tiles));
+    const int bps = (g.n_blocks + splits - 1) / splits;
+    splits = (g.n_blocks + bps - 1) / bps;
     if (splits_out) *splits_out = splits;
     return (size_t)splits * T * Cout * Cin;
+}
+size_t wgrad_ws_floats(int B, int Ho, int Wo, int Cout, int Cin, int T, int* splits_out) {
+    return wgrad_ws_floats_mode(B, Ho, Wo, Cout, Cin, T, T == 9 ? 0 : (T == 1 ? 1 : 2), splits_out);
 }
 
 // mode: 0 3x3 pad 1 (up: nearest x2 source), 1 1x1, 2 2x2 stride 2 (Ho, Wo = OUTPUT size; the source is 2Ho x 2Wo)
@@ -232,22 +269,24 @@ int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float
     p.in0 = in0; p.in1 = C1 ? in1 : in0; p.dy = dy; p.partial = ws;
     p.C0 = C0; p.C1 = C1; p.Cin = C0 + C1; p.Cout = Cout;
     p.B = B; p.Ho = Ho; p.Wo = Wo; p.up = up;
-    p.TW = std::min((Wo + 1) & ~1, 64);
-    p.R = std::max(1, std::min(64 / p.TW, Ho));
-    p.tiles_x = (Wo + p.TW - 1) / p.TW;
-    p.tiles_y = (Ho + p.R - 1) / p.R;
-    p.n_blocks = B * p.tiles_x * p.tiles_y;
+    const WgradGeo g = wgrad_geo(B, Ho, Wo, mode);
+    p.TW = g.TW; p.R = g.R; p.NB = g.NB;
+    p.tiles_x = g.tiles_x;
+    p.tiles_y = g.tiles_y;
+    p.n_blocks = g.n_blocks;
     p.n_ct = (Cout + 63) / 64;
     p.n_kt = (p.Cin + 63) / 64;
     const int T = mode == 0 ? 9 : (mode == 1 ? 1 : 4);
     int splits = 1;
-    (void)wgrad_ws_floats(B, Ho, Wo, Cout, p.Cin, T, &splits);
+    (void)wgrad_ws_floats_mode(B, Ho, Wo, Cout, p.Cin, T, mode, &splits);
     p.blocks_per_split = (p.n_blocks + splits - 1) / splits;
     const int WW = mode == 0 ? p.TW + 2 : (mode == 2 ? 2 * p.TW : p.TW);
     const int WH = mode == 0 ? p.R + 2 : (mode == 2 ? 2 * p.R : p.R);
-    const size_t lds = (size_t)(64 * WG_SY + WH * WW * WG_SX) * sizeof(float);
+    const size_t lds = (size_t)(64 * WG_SY + p.NB * WH * WW * WG_SX) * sizeof(float);
     DM_REQUIRE(lds <= 160 * 1024, "wgrad: LDS");
-    DM_REQUIRE(WH * WW <= 16 * (mode == 0 ? 13 : (mode == 1 ? 4 : 16)), "wgrad: window larger than the staging items");
+    DM_REQUIRE(p.NB * p.R * p.TW <= 64 && p.NB * WH * WW <= 16 * (mode == 0 ? 9 : (mode == 1 ? 4 : 16)) && p.TW < 4096 &&
+                   WH < 4096,
+               "wgrad: block larger than the staging items");
     const dim3 grid(p.n_ct * p.n_kt, splits);
     const bool timed = prof::enabled();
     if (timed && prof::begin("wgrad_mfma_kernel", 2.0 * T * p.Cin * Cout * (double)B * Ho * Wo,

@@ -209,3 +209,40 @@ def test_attention_bwd(case):
     errs.update({k: rel_l2(o.cpu(), sd[k].grad) for k, o in zip(names, outs)})
     print(case, errs)
     assert max(errs.values()) < TOL, errs
+
+
+def test_conv_backward_random_shapes():
+    """Seeded random shapes through the weight-gradient kernel's tiling (ragged pixel blocks, several cin / cout tiles,
+    K splits) and through whichever forward kernel the input-gradient convolution dispatches to."""
+    import random
+
+    rng = random.Random(2024)
+    lib = _lib.load()
+    for it in range(14):
+        k = rng.choice([3, 3, 1])
+        B = rng.choice([1, 2, 3, 5])
+        H, W = rng.choice([(4, 4), (8, 8), (6, 10), (16, 16), (12, 20), (32, 32), (3, 3), (1, 1), (2, 2)])
+        C0 = 4 * rng.randint(1, 40)
+        C1 = rng.choice([0, 0, 4 * rng.randint(1, 24)])
+        Cout = 4 * rng.randint(1, 48)
+        up2 = k == 3 and C1 == 0 and rng.random() < 0.25
+        x0 = seeded((B, C0, H, W), 100 + it).requires_grad_(True)
+        x1 = seeded((B, C1, H, W), 200 + it).requires_grad_(True) if C1 else None
+        w = (seeded((Cout, C0 + C1, k, k), 300 + it) / (k * (C0 + C1) ** 0.5)).requires_grad_(True)
+        b = seeded((Cout,), 400 + it, 0.1).requires_grad_(True)
+        x = x0 if x1 is None else torch.cat((x0, x1), dim=1)
+        if up2:
+            x = F.interpolate(x, scale_factor=2, mode="nearest")
+        y = F.conv2d(x, w, b, padding=k // 2)
+        dy = seeded(tuple(y.shape), 500 + it)
+        y.backward(dy)
+        d0 = torch.empty((B, C0, H, W), device=DEV)
+        d1 = torch.empty((B, C1, H, W), device=DEV) if C1 else None
+        dw, db = torch.empty(w.shape, device=DEV), torch.empty((Cout,), device=DEV)
+        a = [dev(x0.detach()), dev(w.detach()), dev(x1.detach()) if C1 else None, dev(dy)]
+        _lib.check(lib.dm_op_conv2d_bwd(_lib.ptr(a[0]), C0, _lib.ptr(a[2]), C1, _lib.ptr(a[1]), _lib.ptr(a[3]), _lib.ptr(d0),
+                                        _lib.ptr(d1), _lib.ptr(dw), _lib.ptr(db), B, H, W, Cout, k, k // 2, int(up2), None))
+        errs = dict(dx0=rel_l2(d0.cpu(), x0.grad), dw=rel_l2(dw.cpu(), w.grad), db=rel_l2(db.cpu(), b.grad))
+        if C1:
+            errs["dx1"] = rel_l2(d1.cpu(), x1.grad)
+        assert max(errs.values()) < TOL, ((B, C0, C1, H, W, Cout, k, up2), errs)
