@@ -6,12 +6,15 @@
 // Both operands are NHWC, i.e. K-major with the M / N index contiguous -- exactly what the 32x32x2 operand layout wants
 // (lane = (row, k): the 32 lanes of one k read 32 consecutive floats).
 //
-// One workgroup = 4 waves = 64 couts x 64 cins x ALL taps; wave (wo, wc) owns 32 couts x 32 cins and keeps one 32x32
-// accumulator per tap (9 x 16 = 144 registers for a 3x3 kernel): the dY value of a pixel pair is loaded once and meets the
-// nine shifted X values, which all come out of the same LDS window.  Per block of <= 64 pixels (R rows x TW columns of one
-// image) the workgroup stages dY (64 px x 64 couts) and the X window ((R+2) x (TW+2) px x 64 cins) in LDS; two workgroups
-// per CU overlap each other's staging.  The pixel blocks are split over blockIdx.y; every split writes its partial
-// [tap][cout][cin] tile and wgrad_reduce_kernel sums the splits into the OIHW gradient (deterministic, no atomics).
+// One workgroup = 4 waves = 64 couts x 64 cins x one kernel ROW (the three taps ky = blockIdx.z of a 3x3 kernel; all taps
+// of the 1x1 / 2x2 forms); wave (wo, wc) owns 32 couts x 32 cins and keeps one 32x32 accumulator per tap: the dY value of a
+// pixel pair is loaded once and meets the shifted X values, which come out of the same LDS window.  Per block of <= 64
+// pixels (R rows x TW columns of one image, or several whole small images) the workgroup stages dY (64 px x 64 couts) and
+// the X window (R x (TW+2) px x 64 cins) in LDS; the next block's items are prefetched into registers during the MFMAs.
+// The pixel blocks are split over blockIdx.y; every split writes its partial [tap][cout][cin] tile and
+// wgrad_reduce_kernel sums the splits into the OIHW gradient (deterministic, no atomics).  A workgroup per kernel row
+// instead of per 3x3 kernel: the chip is filled with a third of the splits, i.e. a third of the partial-sum traffic (which
+// was 38 MB per layer, written and read back), for three times the (cheap) staging.
 //
 // Modes: 3x3 / pad 1 (optionally on a nearest-x2 upsampled source: Upsample :48-52), 1x1, and the 2x2 / stride 2 form of
 // Downsample (:54-58; weight index c*4 + p1*2 + p2).  Inputs may be the channel concatenation of two tensors (the up
@@ -44,16 +47,18 @@ static constexpr int WG_SX = 64;  // floats per staged X pixel
 template <int MODE>
 struct WgradMode;
 template <>
-struct WgradMode<0> { static constexpr int T = 9, S = 1; };
+struct WgradMode<0> { static constexpr int T = 9, TA = 3, S = 1; };
 template <>
-struct WgradMode<1> { static constexpr int T = 1, S = 1; };
+struct WgradMode<1> { static constexpr int T = 1, TA = 1, S = 1; };
 template <>
-struct WgradMode<2> { static constexpr int T = 4, S = 2; };
+struct WgradMode<2> { static constexpr int T = 4, TA = 4, S = 2; };
 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p) {
-    constexpr int T = WgradMode<MODE>::T;
+    constexpr int T = WgradMode<MODE>::T;    // taps of the partial layout
+    constexpr int TA = WgradMode<MODE>::TA;  // taps (accumulators) of this workgroup
     constexpr int S = WgradMode<MODE>::S;
+    const int kyb = MODE == 0 ? blockIdx.z : 0;  // kernel row of this workgroup
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sY = smem;                // [64 px][64 couts]
     float* sX = smem + 64 * WG_SY;   // [WH * WW px][64 cins]
@@ -66,13 +71,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p)
     const int split = blockIdx.y;
     const int TW = p.TW, R = p.R;
     const int WW = MODE == 0 ? TW + 2 : S * TW;
-    const int WH = MODE == 0 ? R + 2 : S * R;
+    const int WH = S * R;
     const int Hs = MODE == 2 ? 2 * p.Ho : (p.up ? p.Ho / 2 : p.Ho);  // source tensor size
     const int Ws = MODE == 2 ? 2 * p.Wo : (p.up ? p.Wo / 2 : p.Wo);
 
-    f32x16 acc[T];
+    f32x16 acc[TA];
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int t = 0; t < TA; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p)
     //      coordinates do: the divisions are done once, a block costs additions and bounds checks.  The items of the NEXT
     //      block are loaded into registers before the MFMA loop of the current one (one workgroup hides its own staging).
     constexpr int YI = 4;                                      // dY: 64 px x 16 quads / 256 threads
-    constexpr int XI = MODE == 0 ? 9 : (MODE == 1 ? 4 : 16);   // X window items (upper bound, checked by the launcher)
+    constexpr int XI = MODE == 0 ? 6 : (MODE == 1 ? 4 : 16);   // X window items (upper bound, checked by the launcher)
     const int NB = p.NB;
     const int q4 = 4 * (tid & 15);
     int ypos[YI], xpos[XI];  // (image << 24) | (row << 12) | column inside the block / window, -1: no item
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p)
                 int sy, sx;
                 bool ok;
                 if (MODE == 0) {
-                    const int uy = y0 - 1 + wy, ux = x0 - 1 + wx;
+                    const int uy = y0 - 1 + kyb + wy, ux = x0 - 1 + wx;
                     ok = uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo;
                     sy = p.up ? uy >> 1 : uy;
                     sx = p.up ? ux >> 1 : ux;
@@ -166,12 +171,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p)
                 const float* xw = xb + (size_t)nb * WH * WW * WG_SX;
                 if (MODE == 0) {
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const float bv = xw[((r + ky) * WW + c + kx) * WG_SX];
-                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ky * 3 + kx], 0, 0, 0);
-                        }
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float bv = xw[(r * WW + c + kx) * WG_SX];
+                        acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[kx], 0, 0, 0);
+                    }
                 } else if (MODE == 1) {
                     const float bv = xw[(r * WW + c) * WG_SX];
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[0], 0, 0, 0);
@@ -191,11 +194,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p)
     const int ci = kt * 64 + wc * 32 + l31;
     if (ci < p.Cin) {
 #pragma unroll
-        for (int t = 0; t < T; ++t)
+        for (int t = 0; t < TA; ++t)
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int co = ct * 64 + wo * 32 + 8 * (v >> 2) + 4 * k + (v & 3);
-                if (co < p.Cout) p.partial[(((size_t)split * T + t) * p.Cout + co) * p.Cin + ci] = acc[t][v];
+                if (co < p.Cout) p.partial[(((size_t)split * T + kyb * 3 + t) * p.Cout + co) * p.Cin + ci] = acc[t][v];
             }
     }
 }
@@ -227,15 +230,14 @@ struct WgradGeo {
 };
 static WgradGeo wgrad_geo(int B, int Ho, int Wo, int mode) {
     WgradGeo g{};
-    const int tw_max = mode == 0 ? 32 : 64;  // 3x3: the staged window of a block must fit 9 items per thread
-    g.TW = std::min((Wo + 1) & ~1, tw_max);
+    g.TW = std::min((Wo + 1) & ~1, 64);
     g.R = std::max(1, std::min(64 / g.TW, Ho));
     g.tiles_x = (Wo + g.TW - 1) / g.TW;
     g.tiles_y = (Ho + g.R - 1) / g.R;
     g.NB = 1;
     if (g.tiles_x == 1 && g.tiles_y == 1) {
-        const int win = mode == 0 ? (g.R + 2) * (g.TW + 2) : (mode == 2 ? 4 : 1) * g.R * g.TW;
-        const int items = 16 * (mode == 0 ? 9 : (mode == 1 ? 4 : 16));
+        const int win = mode == 0 ? g.R * (g.TW + 2) : (mode == 2 ? 4 : 1) * g.R * g.TW;
+        const int items = 16 * (mode == 0 ? 6 : (mode == 1 ? 4 : 16));
         g.NB = std::max(1, std::min(std::min(64 / (g.R * g.TW), items / win), B));
     }
     g.n_blocks = ((B + g.NB - 1) / g.NB) * g.tiles_x * g.tiles_y;
@@ -244,11 +246,13 @@ static WgradGeo wgrad_geo(int B, int Ho, int Wo, int mode) {
 
 static size_t wgrad_ws_floats_mode(int B, int Ho, int Wo, int Cout, int Cin, int T, int mode, int* splits_out) {
     const WgradGeo g = wgrad_geo(B, Ho, Wo, mode);
-    const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
-    // One workgroup per CU hides its own staging (the next block is loaded during the MFMAs), so the split count only has
-    // to fill the chip; every split writes a full [T][Cout][Cin] partial tile that the reduce kernel reads back.
+    const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64) * (mode == 0 ? 3 : 1);
+    // A workgroup hides its own staging (the next block is loaded during the MFMAs), so the split count only has to fill
+    // the chip; every split writes a full [T][Cout][Cin] partial tile that the reduce kernel reads back.
     static const int min_bps = env_int("DM_WGRAD_MIN_BLOCKS", 2);
-    static const int target = env_int("DM_WGRAD_TARGET_WGS", 256);
+    // (swept at B=64: 256 / 512 / 768 / 1024 / 1536 workgroups -> 13.0 / 12.3 / 12.0 / 12.5 / 12.6 ms per loss+backward:
+    // three 146-register workgroups fit a CU)
+    static const int target = env_int("DM_WGRAD_TARGET_WGS", 768);
     int splits = std::max(1, std::min((g.n_blocks + min_bps - 1) / min_bps, (target + tiles - 1) / tiles));
     const int bps = (g.n_blocks + splits - 1) / splits;
     splits = (g.n_blocks + bps - 1) / bps;
@@ -281,13 +285,13 @@ int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float
     (void)wgrad_ws_floats_mode(B, Ho, Wo, Cout, p.Cin, T, mode, &splits);
     p.blocks_per_split = (p.n_blocks + splits - 1) / splits;
     const int WW = mode == 0 ? p.TW + 2 : (mode == 2 ? 2 * p.TW : p.TW);
-    const int WH = mode == 0 ? p.R + 2 : (mode == 2 ? 2 * p.R : p.R);
+    const int WH = mode == 2 ? 2 * p.R : p.R;
     const size_t lds = (size_t)(64 * WG_SY + p.NB * WH * WW * WG_SX) * sizeof(float);
     DM_REQUIRE(lds <= 160 * 1024, "wgrad: LDS");
-    DM_REQUIRE(p.NB * p.R * p.TW <= 64 && p.NB * WH * WW <= 16 * (mode == 0 ? 9 : (mode == 1 ? 4 : 16)) && p.TW < 4096 &&
+    DM_REQUIRE(p.NB * p.R * p.TW <= 64 && p.NB * WH * WW <= 16 * (mode == 0 ? 6 : (mode == 1 ? 4 : 16)) && p.TW < 4096 &&
                    WH < 4096,
                "wgrad: block larger than the staging items");
-    const dim3 grid(p.n_ct * p.n_kt, splits);
+    const dim3 grid(p.n_ct * p.n_kt, splits, mode == 0 ? 3 : 1);
     const bool timed = prof::enabled();
     if (timed && prof::begin("wgrad_mfma_kernel", 2.0 * T * p.Cin * Cout * (double)B * Ho * Wo,
                              4.0 * ((double)B * Ho * Wo * (p.Cin * (mode == 2 ? 4 : 1) + Cout) + (double)T * p.Cin * Cout), s))
