@@ -357,7 +357,9 @@ int launch_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, float
                         int accumulate, hipStream_t s);
 int launch_mlp_rows_wgrad(const float* dy, int ldy, const float* x, int ldx, float* const* dw_rows, float* const* db_rows,
                           int R, int I, int O, int accumulate, hipStream_t s);
-int launch_linear_dgrad(const float* dy, int ldy, const float* W, float* dx, int ldx, int R, int I, int O, hipStream_t s);
+size_t linear_dgrad_ws_floats(int R, int I, int O);
+int launch_linear_dgrad(const float* dy, int ldy, const float* W, float* dx, int ldx, int R, int I, int O, float* ws,
+                        hipStream_t s);
 // per-sample scalars of the training step, gathered on the host as `extract` does: [0] sqrt_alphas_cumprod[t],
 // [1] sqrt_one_minus_alphas_cumprod[t], [2] loss_weight[t], [3] 0, [4] sqrt_recip_alphas_cumprod[t], [5] sqrt_recipm1_alphas_cumprod[t], [6..7] 0
 #define DM_TRAIN_COEFS 8

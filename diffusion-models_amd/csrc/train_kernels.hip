@@ -250,37 +250,31 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     __syncthreads();
     if (q == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
 }
-// 256 threads = 64 columns x 4 lanes over the partial rows, fixed order
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int blocks, int C,
-                                                            float* __restrict__ out, int accumulate) {
-    __shared__ float red[4][64];
+// finish / few rows (a batch of per-image vectors, the [blocks][C] partial sums): one pass, 1024 threads = 64 columns x 16
+// lanes over the rows, combined in a fixed order
+__global__ __launch_bounds__(1024) void colsum_lanes_kernel(const float* __restrict__ x, int rows, int C, int64_t row_stride,
+                                                            int64_t col_stride, float* __restrict__ out, int accumulate) {
+    __shared__ float red[16][64];
     const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + li;
     float s = 0.f;
     if (c < C)
-        for (int b = q; b < blocks; b += 4) s += part[(size_t)b * C + c];
+        for (int r = q; r < rows; r += 16) s += x[r * row_stride + c * col_stride];
     red[q][li] = s;
     __syncthreads();
     if (q == 0 && c < C) {
-        const float v = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][li];
         out[c] = accumulate ? out[c] + v : v;
     }
-}
-// few rows (a batch of per-image vectors): one pass, thread per column
-__global__ void colsum_small_kernel(const float* __restrict__ x, int rows, int C, int64_t row_stride, int64_t col_stride,
-                                    float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += x[r * row_stride + c * col_stride];
-    out[c] = accumulate ? out[c] + s : s;
 }
 static int colsum_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(512, rows / 64)); }
 size_t colsum_ws_floats(int64_t rows, int C) { return (size_t)colsum_blocks(rows) * C; }
 int launch_colsum(const float* x, int64_t rows, int C, int64_t row_stride, int64_t col_stride, float* ws, float* out,
                   int accumulate, hipStream_t s) {
     if (rows <= 512) {
-        hipLaunchKernelGGL(colsum_small_kernel, dim3((C + 63) / 64), dim3(64), 0, s, x, (int)rows, C, row_stride, col_stride,
+        hipLaunchKernelGGL(colsum_lanes_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, x, (int)rows, C, row_stride, col_stride,
                            out, accumulate);
         DM_CHECK_HIP(hipGetLastError());
         return 0;
@@ -291,30 +285,31 @@ int launch_colsum(const float* x, int64_t rows, int C, int64_t row_stride, int64
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, nb), dim3(256), 0, s, x, rows, C, row_stride, col_stride,
                        rpb, ws);
     DM_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, s, ws, nb, C, out, accumulate);
+    hipLaunchKernelGGL(colsum_lanes_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, ws, nb, C, (int64_t)C, (int64_t)1, out,
+                       accumulate);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
 // bias gradient of a convolution whose dY is NCHW (final_conv): sum over b and pixels of dy[b][c][:]
-__global__ void colsum_nchw_kernel(const float* __restrict__ dy, int B, int C, int HW, float* __restrict__ out,
-                                   int accumulate) {
-    __shared__ float red[256];
+__global__ __launch_bounds__(1024) void colsum_nchw_kernel(const float* __restrict__ dy, int B, int C, int HW,
+                                                           float* __restrict__ out, int accumulate) {
+    __shared__ float red[1024];
     const int c = blockIdx.x;
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < (int64_t)B * HW; i += 256) {
-        const int64_t b = i / HW, q = i - b * HW;
-        s += dy[(b * C + c) * HW + q];
+    for (int b = 0; b < B; ++b) {
+        const float* row = dy + ((size_t)b * C + c) * HW;
+        for (int q = threadIdx.x; q < HW; q += 1024) s += row[q];
     }
     red[threadIdx.x] = s;
     __syncthreads();
-    for (int m = 128; m > 0; m >>= 1) {
+    for (int m = 512; m > 0; m >>= 1) {
         if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
         __syncthreads();
     }
     if (threadIdx.x == 0) out[c] = accumulate ? out[c] + red[0] : red[0];
 }
 int launch_colsum_nchw(const float* dy, int B, int C, int HW, float* out, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_nchw_kernel, dim3(C), dim3(256), 0, s, dy, B, C, HW, out, accumulate);
+    hipLaunchKernelGGL(colsum_nchw_kernel, dim3(C), dim3(1024), 0, s, dy, B, C, HW, out, accumulate);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -503,57 +498,106 @@ int launch_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, float
 }
 // The 19 ResnetBlock.mlp (SiLU -> Linear) gradients in ONE launch: row o of the concatenated [ss_total][I] matrix goes to
 // dw_rows[o] (a pointer into that block's mlp.1.weight gradient), its bias gradient to db_rows[o].
-// grid (ceil(I / 64), ss_total), 64 threads: dW[o][i] = sum_r dy[r][o] * silu(x[r][i]); thread 0 also sums the bias.
-__global__ void mlp_rows_wgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
-                                      float* const* __restrict__ dw_rows, float* const* __restrict__ db_rows, int R, int I,
-                                      int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int o = blockIdx.y;
-    if (i >= I) return;
-    float s = 0.f, sb = 0.f;
+// grid (ceil(I / 64), ceil(ss_total / 16)), 64 threads: dW[o][i] = sum_r dy[r][o] * silu(x[r][i]) for 16 rows o per
+// workgroup (silu(x) is formed once per r and meets 16 dy values); lane 0 of the first column block also sums the biases.
+constexpr int MLP_ROWS = 16;
+__global__ __launch_bounds__(64) void mlp_rows_wgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x,
+                                                            int ldx, float* const* __restrict__ dw_rows,
+                                                            float* const* __restrict__ db_rows, int R, int I, int O,
+                                                            int accumulate) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int o0 = blockIdx.y * MLP_ROWS;
+    const bool i_ok = i < I;
+    float s[MLP_ROWS], sb[MLP_ROWS];
+#pragma unroll
+    for (int j = 0; j < MLP_ROWS; ++j) s[j] = sb[j] = 0.f;
     for (int r = 0; r < R; ++r) {
-        const float d = dy[(size_t)r * ldy + o];
-        const float xv = x[(size_t)r * ldx + i];
-        s += d * (xv / (1.0f + __expf(-xv)));
-        sb += d;
+        const float xv = i_ok ? x[(size_t)r * ldx + i] : 0.f;
+        const float a = xv / (1.0f + __expf(-xv));
+        const float* dr = dy + (size_t)r * ldy + o0;
+#pragma unroll
+        for (int j = 0; j < MLP_ROWS; ++j) {
+            const float d = o0 + j < O ? dr[j] : 0.f;
+            s[j] += d * a;
+            sb[j] += d;
+        }
     }
-    float* q = dw_rows[o] + i;
-    *q = accumulate ? *q + s : s;
-    if (i == 0) {
-        float* b = db_rows[o];
-        *b = accumulate ? *b + sb : sb;
+#pragma unroll
+    for (int j = 0; j < MLP_ROWS; ++j) {
+        if (o0 + j >= O) break;
+        if (i_ok) {
+            float* q = dw_rows[o0 + j] + i;
+            *q = accumulate ? *q + s[j] : s[j];
+        }
+        if (i == 0) {
+            float* b = db_rows[o0 + j];
+            *b = accumulate ? *b + sb[j] : sb[j];
+        }
     }
 }
 int launch_mlp_rows_wgrad(const float* dy, int ldy, const float* x, int ldx, float* const* dw_rows, float* const* db_rows,
                           int R, int I, int O, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(mlp_rows_wgrad_kernel, dim3((I + 63) / 64, O), dim3(64), 0, s, dy, ldy, x, ldx, dw_rows, db_rows, R, I,
-                       accumulate);
+    hipLaunchKernelGGL(mlp_rows_wgrad_kernel, dim3((I + 63) / 64, (O + MLP_ROWS - 1) / MLP_ROWS), dim3(64), 0, s, dy, ldy, x, ldx,
+                       dw_rows, db_rows, R, I, O, accumulate);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 // nn.Linear input gradient: dx[r][i] = sum_o dy[r * ldy + o] * W[o][i]   (W as stored: (O, I)).
-// grid (ceil(I / 64), R), 1024 threads = 64 columns x 16 slices of the O range, combined through LDS in a fixed order.
-__global__ __launch_bounds__(1024) void linear_dgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ W,
-                                                            float* __restrict__ dx, int ldx, int R, int I, int O) {
-    __shared__ float red[16][64];
+// grid (ceil(I / 64), ceil(R / 8), OS), 256 threads = 64 columns x 4 slices of this workgroup's share of the O range: a W
+// value is loaded once for 8 rows r, the four slices meet in LDS in a fixed order.  OS > 1 (the 9 k-row scale/shift
+// matrix): every share writes its partial (R, I) block to the workspace and linear_dgrad_sum_kernel adds them in order.
+constexpr int LD_ROWS = 8;
+__global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ W,
+                                                           float* __restrict__ dx, int ldx, int R, int I, int O, int o_share) {
+    __shared__ float red[4][LD_ROWS][64];
     const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + li, r = blockIdx.y;
-    float s = 0.f;
-    if (i < I)
-        for (int o = q; o < O; o += 16) s += dy[(size_t)r * ldy + o] * W[(size_t)o * I + i];
-    red[q][li] = s;
-    __syncthreads();
-    if (q == 0 && i < I) {
-        float v = 0.f;
+    const int i = blockIdx.x * 64 + li, r0 = blockIdx.y * LD_ROWS;
+    const int oa = blockIdx.z * o_share, ob = min(oa + o_share, O);
+    float s[LD_ROWS];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v += red[k][li];
-        dx[(size_t)r * ldx + i] = v;
-    }
+    for (int j = 0; j < LD_ROWS; ++j) s[j] = 0.f;
+    if (i < I)
+        for (int o = oa + q; o < ob; o += 4) {
+            const float w = W[(size_t)o * I + i];
+#pragma unroll
+            for (int j = 0; j < LD_ROWS; ++j)
+                if (r0 + j < R) s[j] += dy[(size_t)(r0 + j) * ldy + o] * w;
+        }
+#pragma unroll
+    for (int j = 0; j < LD_ROWS; ++j) red[q][j][li] = s[j];
+    __syncthreads();
+    if (i < I)
+        for (int j = q; j < LD_ROWS; j += 4)
+            if (r0 + j < R)
+                dx[(size_t)blockIdx.z * R * ldx + (size_t)(r0 + j) * ldx + i] =
+                    (red[0][j][li] + red[1][j][li]) + (red[2][j][li] + red[3][j][li]);
 }
-int launch_linear_dgrad(const float* dy, int ldy, const float* W, float* dx, int ldx, int R, int I, int O, hipStream_t s) {
-    hipLaunchKernelGGL(linear_dgrad_kernel, dim3((I + 63) / 64, R), dim3(1024), 0, s, dy, ldy, W, dx, ldx, R, I, O);
+__global__ void linear_dgrad_sum_kernel(const float* __restrict__ part, int shares, int64_t n, float* __restrict__ dx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < shares; ++k) s += part[(int64_t)k * n + i];
+    dx[i] = s;
+}
+static int linear_dgrad_shares(int I, int O) { return O >= 2048 ? 16 : 1; }
+size_t linear_dgrad_ws_floats(int R, int I, int O) {
+    const int sh = linear_dgrad_shares(I, O);
+    return sh > 1 ? (size_t)sh * R * I : 0;
+}
+// ws: linear_dgrad_ws_floats(R, I, O) floats (may be nullptr when that is 0, or to force the one-pass form)
+int launch_linear_dgrad(const float* dy, int ldy, const float* W, float* dx, int ldx, int R, int I, int O, float* ws,
+                        hipStream_t s) {
+    const int sh = (ws && ldx == I) ? linear_dgrad_shares(I, O) : 1;
+    const int o_share = (O + sh - 1) / sh;
+    const dim3 grid((I + 63) / 64, (R + LD_ROWS - 1) / LD_ROWS, sh);
+    hipLaunchKernelGGL(linear_dgrad_kernel, grid, dim3(256), 0, s, dy, ldy, W, sh > 1 ? ws : dx, ldx, R, I, O, o_share);
     DM_CHECK_HIP(hipGetLastError());
+    if (sh > 1) {
+        const int64_t n = (int64_t)R * I;
+        hipLaunchKernelGGL(linear_dgrad_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, sh, n, dx);
+        DM_CHECK_HIP(hipGetLastError());
+    }
     return 0;
 }
 

@@ -348,35 +348,45 @@ __global__ void wgrad_naive_kernel(const WgradNaive p) {
     p.partial[(size_t)blockIdx.y * n_out + i] = s;
 }
 
-// init_conv (DD/denoising_diffusion.py:262): x NCHW with a handful of channels, dy NHWC.  One workgroup = one kernel ROW
-// (c, ky) for a slice of the image rows; thread = output channel, KW accumulators: a dy value is loaded once (coalesced
-// over the channels) and meets the KW neighbouring x values (same address for all lanes).
-template <int KW>
-__global__ void wgrad_rows_nchw_kernel(const WgradNaive p) {
-    const int c = blockIdx.x / p.KH, ky = blockIdx.x % p.KH;
+// init_conv (DD/denoising_diffusion.py:262): x NCHW with a handful of channels, dy NHWC.  One wave = one input channel c x 64
+// output channels (lane) x a slice of the image rows, KH x KW accumulators per lane: per output row the KH zero-padded
+// input rows are staged in LDS, a dy value is loaded once (coalesced over the channels) and meets the KH x KW neighbouring
+// x values (LDS broadcasts).  dy is read Cin times in all (it was Cin x KH times with one kernel row per workgroup).
+template <int KH, int KW>
+__global__ __launch_bounds__(64) void wgrad_init_kernel(const WgradNaive p) {
+    extern __shared__ float win[];  // [KH][W + KW - 1]
+    const int c = blockIdx.x, o = blockIdx.z * 64 + threadIdx.x;
+    const bool o_ok = o < p.Cout;
+    const int WP = p.W + KW - 1;
     const int row0 = blockIdx.y * p.rows_per_split, row1 = min(row0 + p.rows_per_split, p.B * p.H);
-    for (int o = threadIdx.x; o < p.Cout; o += blockDim.x) {
-        float acc[KW];
+    float acc[KH][KW];
 #pragma unroll
-        for (int k = 0; k < KW; ++k) acc[k] = 0.f;
-        for (int row = row0; row < row1; ++row) {
-            const int b = row / p.H, y = row - b * p.H;
-            const int sy = y + ky - p.pad;
-            if (sy < 0 || sy >= p.H) continue;
-            const float* xr = p.x + b * p.xs_b + c * p.xs_c + (int64_t)sy * p.W;
-            const float* dr = p.dy + ((int64_t)row * p.W) * p.Cout + o;
-            for (int x = 0; x < p.W; ++x) {
-                const float d = dr[(int64_t)x * p.Cout];
+    for (int a = 0; a < KH; ++a)
 #pragma unroll
-                for (int k = 0; k < KW; ++k) {
-                    const int sx = x + k - p.pad;
-                    acc[k] += d * ((sx >= 0 && sx < p.W) ? xr[sx] : 0.f);
-                }
-            }
+        for (int k = 0; k < KW; ++k) acc[a][k] = 0.f;
+    for (int row = row0; row < row1; ++row) {
+        const int b = row / p.H, y = row - b * p.H;
+        __syncthreads();
+        for (int i = threadIdx.x; i < KH * WP; i += 64) {
+            const int ky = i / WP, sx = i - ky * WP - p.pad, sy = y + ky - p.pad;
+            win[i] = (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) ? p.x[b * p.xs_b + c * p.xs_c + (int64_t)sy * p.W + sx] : 0.f;
         }
-        float* q = p.partial + (size_t)blockIdx.y * p.Cout * p.Cin * p.KH * KW + (((size_t)o * p.Cin + c) * p.KH + ky) * KW;
+        __syncthreads();
+        const float* dr = p.dy + ((int64_t)row * p.W) * p.Cout + (o_ok ? o : 0);
+        for (int x = 0; x < p.W; ++x) {
+            const float d = dr[(int64_t)x * p.Cout];
 #pragma unroll
-        for (int k = 0; k < KW; ++k) q[k] = acc[k];
+            for (int a = 0; a < KH; ++a)
+#pragma unroll
+                for (int k = 0; k < KW; ++k) acc[a][k] += d * win[a * WP + x + k];
+        }
+    }
+    if (o_ok) {
+        float* q = p.partial + (size_t)blockIdx.y * p.Cout * p.Cin * KH * KW + ((size_t)o * p.Cin + c) * KH * KW;
+#pragma unroll
+        for (int a = 0; a < KH; ++a)
+#pragma unroll
+            for (int k = 0; k < KW; ++k) q[a * KW + k] = acc[a][k];
     }
 }
 // final_conv (:343): 1x1 with a handful of outputs, x NHWC, dy NCHW.  256 threads = 64 input channels x 4 pixel lanes.
@@ -427,8 +437,9 @@ int launch_wgrad_naive(const float* x, int x_nchw, const float* dy, int dy_nchw,
     (void)wgrad_naive_ws_floats(B, H, Cout, Cin, KH, KW, &splits);
     p.rows_per_split = (B * H + splits - 1) / splits;
     const int n_out = Cout * Cin * KH * KW;
-    if (x_nchw && !dy_nchw && KW == 7)
-        hipLaunchKernelGGL(wgrad_rows_nchw_kernel<7>, dim3(Cin * KH, splits), dim3(64), 0, s, p);
+    if (x_nchw && !dy_nchw && KW == 7 && KH == 7 && (size_t)7 * (W + 6) * sizeof(float) <= 48 * 1024)
+        hipLaunchKernelGGL((wgrad_init_kernel<7, 7>), dim3(Cin, splits, (Cout + 63) / 64), dim3(64), 7 * (W + 6) * sizeof(float), s,
+                           p);
     else if (!x_nchw && dy_nchw && KH == 1 && KW == 1 && Cout <= 4)
         hipLaunchKernelGGL(wgrad_thin_out_kernel, dim3((Cin + 63) / 64, splits), dim3(256), 0, s, p);
     else
