@@ -252,9 +252,50 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
         y[(size_t)r * ldy + o] = acc;
     }
 }
+// The same for a batch of different rows (the training step: one time embedding per image): a wave forms its output o for 8
+// rows r, so a weight row is read once per 8 rows instead of once per row.  Same summation order per (r, o) as above.
+__global__ __launch_bounds__(256) void linear_rows8_kernel(const float* __restrict__ x, int ldx,
+                                                           const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           int ldy, int R, int I, int O, int act_in, int act_out) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r0 = blockIdx.y * 8;
+    if (o >= O) return;
+    const float* wr = W + (size_t)o * I;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int i = lane; i < I; i += 64) {
+        const float w = wr[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = r0 + j < R ? x[(size_t)(r0 + j) * ldx + i] : 0.f;
+            if (act_in == 1) v = silu_f(v);
+            else if (act_in == 2) v = gelu_erf_f(v);
+            acc[j] += v * w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float a = wave_sum(acc[j]);
+        if (lane == 0 && r0 + j < R) {
+            if (bias) a += bias[o];
+            if (act_out == 1) a = silu_f(a);
+            else if (act_out == 2) a = gelu_erf_f(a);
+            y[(size_t)(r0 + j) * ldy + o] = a;
+        }
+    }
+}
 int launch_linear_rows(const float* x, int ldx, const float* W, const float* bias, float* y, int ldy, int R, int I,
                        int O, int act_in, int act_out, hipStream_t s) {
     if (R == 0 || O == 0) return 0;
+    if (R >= 8) {
+        hipLaunchKernelGGL(linear_rows8_kernel, dim3((O + 3) / 4, (R + 7) / 8), dim3(256), 0, s, x, ldx, W, bias, y, ldy, R, I, O,
+                           act_in, act_out);
+        DM_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(linear_rows_kernel, dim3((O + 3) / 4, R), dim3(256), 0, s, x, ldx, W, bias, y, ldy, I, O,
                        act_in, act_out);
     DM_CHECK_HIP(hipGetLastError());

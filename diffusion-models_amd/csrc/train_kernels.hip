@@ -511,15 +511,24 @@ __global__ __launch_bounds__(64) void mlp_rows_wgrad_kernel(const float* __restr
     float s[MLP_ROWS], sb[MLP_ROWS];
 #pragma unroll
     for (int j = 0; j < MLP_ROWS; ++j) s[j] = sb[j] = 0.f;
-    for (int r = 0; r < R; ++r) {
-        const float xv = i_ok ? x[(size_t)r * ldx + i] : 0.f;
-        const float a = xv / (1.0f + __expf(-xv));
-        const float* dr = dy + (size_t)r * ldy + o0;
+    for (int r0 = 0; r0 < R; r0 += 4) {  // the loads of 4 rows first (independent), then the arithmetic
+        float xv[4], d[4][MLP_ROWS];
 #pragma unroll
-        for (int j = 0; j < MLP_ROWS; ++j) {
-            const float d = o0 + j < O ? dr[j] : 0.f;
-            s[j] += d * a;
-            sb[j] += d;
+        for (int k = 0; k < 4; ++k) {
+            const bool r_ok = r0 + k < R;
+            xv[k] = (i_ok && r_ok) ? x[(size_t)(r0 + k) * ldx + i] : 0.f;
+            const float* dr = dy + (size_t)(r0 + k) * ldy + o0;
+#pragma unroll
+            for (int j = 0; j < MLP_ROWS; ++j) d[k][j] = (r_ok && o0 + j < O) ? dr[j] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = xv[k] / (1.0f + __expf(-xv[k]));
+#pragma unroll
+            for (int j = 0; j < MLP_ROWS; ++j) {
+                s[j] += d[k][j] * a;
+                sb[j] += d[k][j];
+            }
         }
     }
 #pragma unroll
@@ -548,8 +557,10 @@ int launch_mlp_rows_wgrad(const float* dy, int ldy, const float* x, int ldx, flo
 // value is loaded once for 8 rows r, the four slices meet in LDS in a fixed order.  OS > 1 (the 9 k-row scale/shift
 // matrix): every share writes its partial (R, I) block to the workspace and linear_dgrad_sum_kernel adds them in order.
 constexpr int LD_ROWS = 8;
+constexpr int LD_OT = 512;  // o values per staged tile of dy
 __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ W,
                                                            float* __restrict__ dx, int ldx, int R, int I, int O, int o_share) {
+    __shared__ float dys[LD_ROWS][LD_OT];
     __shared__ float red[4][LD_ROWS][64];
     const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + li, r0 = blockIdx.y * LD_ROWS;
@@ -557,13 +568,24 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restri
     float s[LD_ROWS];
 #pragma unroll
     for (int j = 0; j < LD_ROWS; ++j) s[j] = 0.f;
-    if (i < I)
-        for (int o = oa + q; o < ob; o += 4) {
-            const float w = W[(size_t)o * I + i];
-#pragma unroll
-            for (int j = 0; j < LD_ROWS; ++j)
-                if (r0 + j < R) s[j] += dy[(size_t)(r0 + j) * ldy + o] * w;
+    for (int ot = oa; ot < ob; ot += LD_OT) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < LD_ROWS * LD_OT; idx += 256) {
+            const int j = idx / LD_OT, oo = idx - j * LD_OT;
+            dys[j][oo] = (r0 + j < R && ot + oo < ob) ? dy[(size_t)(r0 + j) * ldy + ot + oo] : 0.f;
         }
+        __syncthreads();
+        const int n = min(LD_OT, ob - ot);
+        if (i < I) {
+            const float* wp = W + (size_t)ot * I + i;
+#pragma unroll 4
+            for (int oo = q; oo < n; oo += 4) {
+                const float w = wp[(size_t)oo * I];
+#pragma unroll
+                for (int j = 0; j < LD_ROWS; ++j) s[j] += dys[j][oo] * w;
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < LD_ROWS; ++j) red[q][j][li] = s[j];
     __syncthreads();

@@ -373,12 +373,20 @@ __global__ __launch_bounds__(64) void wgrad_init_kernel(const WgradNaive p) {
         }
         __syncthreads();
         const float* dr = p.dy + ((int64_t)row * p.W) * p.Cout + (o_ok ? o : 0);
-        for (int x = 0; x < p.W; ++x) {
-            const float d = dr[(int64_t)x * p.Cout];
+        for (int x0 = 0; x0 < p.W; x0 += 16) {  // 16 dy values in flight, then 16 x KH x KW products on a sliding LDS window
+            float d[16];
 #pragma unroll
-            for (int a = 0; a < KH; ++a)
+            for (int xx = 0; xx < 16; ++xx) d[xx] = x0 + xx < p.W ? dr[(int64_t)(x0 + xx) * p.Cout] : 0.f;
 #pragma unroll
-                for (int k = 0; k < KW; ++k) acc[a][k] += d * win[a * WP + x + k];
+            for (int a = 0; a < KH; ++a) {
+                float wv[16 + KW - 1];
+#pragma unroll
+                for (int j = 0; j < 16 + KW - 1; ++j) wv[j] = x0 + j < WP ? win[a * WP + x0 + j] : 0.f;
+#pragma unroll
+                for (int xx = 0; xx < 16; ++xx)
+#pragma unroll
+                    for (int k = 0; k < KW; ++k) acc[a][k] += d[xx] * wv[xx + k];
+            }
         }
     }
     if (o_ok) {
