@@ -25,7 +25,7 @@ from .diffusion import (  # noqa: F401
 from .vae import VQDecoder, VQEncoder, VQModel  # noqa: F401
 from .dist import gather_shards, sample_global, sample_sharded, shard_bounds, shared_seed  # noqa: F401
 from .checkpoint import load_trainer_checkpoint, load_vae_checkpoint  # noqa: F401
-from .train import EMA, train_step  # noqa: F401
+from .train import EMA, diffusion_state_dict, load_checkpoint, save_checkpoint, train_step  # noqa: F401
 from .inception import FIDEvaluation, InceptionScoreEvaluation, InceptionV3, calculate_frechet_distance  # noqa: F401
 from .inception_spec import inception_param_spec  # noqa: F401
 

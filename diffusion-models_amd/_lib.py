@@ -31,7 +31,8 @@ EXPORTS = (
     "dm_conv_create", "dm_conv_destroy", "dm_conv_forward", "dm_op_pool2d", "dm_op_resize_bilinear",
     "dm_op_copy_channels_nhwc", "dm_op_global_avgpool", "dm_op_linear",
     "dm_unet_train_enable", "dm_unet_grad_floats", "dm_unet_grads_flat", "dm_unet_get_grad", "dm_unet_loss_backward", "dm_op_q_sample",
-    "dm_unet_optimizer_step", "dm_unet_ema_update", "dm_unet_get_param", "dm_unet_train_sync", "dm_unet_check_device_pack",
+    "dm_unet_optimizer_step", "dm_unet_ema_update", "dm_unet_get_param", "dm_unet_set_train_tensor", "dm_unet_adam_step",
+    "dm_unet_train_sync", "dm_unet_check_device_pack",
     "dm_unet_train_dropout", "dm_op_dropout_mask",
     "dm_op_conv2d_bwd", "dm_op_downsample_bwd", "dm_op_block_bwd", "dm_op_rmsnorm_bwd", "dm_op_linear_attention_bwd",
     "dm_op_attention_bwd",
@@ -153,6 +154,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_unet_optimizer_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), vp]
     lib.dm_unet_ema_update.argtypes = [vp, C.c_float, i32, vp]
     lib.dm_unet_get_param.argtypes = [vp, C.c_char_p, i32, fp, vp]
+    lib.dm_unet_set_train_tensor.argtypes = [vp, C.c_char_p, i32, fp, vp]
+    lib.dm_unet_adam_step.argtypes = [vp, C.c_longlong]
+    lib.dm_unet_adam_step.restype = C.c_longlong
     lib.dm_unet_train_sync.argtypes = [vp]
     lib.dm_unet_train_dropout.argtypes = [vp, C.c_float, u64]
     lib.dm_op_dropout_mask.argtypes = [fp, i64, C.c_float, u64, u64, i32, vp]

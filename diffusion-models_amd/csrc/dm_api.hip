@@ -1522,6 +1522,9 @@ int dm_unet_finalize(dm_unet* u) {
 int dm_unet_update_param(dm_unet* u, const char* name, const float* data_host, const int64_t* shape, int ndim) {
     DM_REQUIRE(u && name && data_host && shape, "null argument");
     DM_REQUIRE(u->finalized, "dm_unet_update_param before dm_unet_finalize (use dm_unet_set_param)");
+    // the device-resident parameters have moved on (dm_unet_optimizer_step): bring the host copies up to date first, so
+    // that "unchanged" below compares with the current values and a partial update does not resurrect stale ones
+    if (u->infer_stale && dm_unet_train_sync(u)) return 1;
     auto it = u->params.find(name);
     if (it == u->params.end()) {
         set_error(std::string("unexpected parameter: ") + name);

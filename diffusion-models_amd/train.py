@@ -50,6 +50,28 @@ class EMA:
             return
         unet.ema_update(self.get_current_decay(), copy=False)
 
+    def state_dict(self):
+        """``ema_pytorch.EMA.state_dict()`` as ``Trainer.save`` stores it under ``'ema'`` (:1108): the averaged copy under
+        ``ema_model.`` (the prefix the reference's sampling scripts strip, denoising-diffusion-pytorch/sampling.py:157-159),
+        the online model under ``online_model.``, and the ``initted`` / ``step`` buffers (names from ema-pytorch's
+        published source; parity unpinned beyond the ``ema_model.`` prefix)."""
+        d = self.online_model
+        out = {"initted": torch.tensor(bool(self.initted)), "step": torch.tensor(int(self.step))}
+        online = diffusion_state_dict(d)
+        out.update({"online_model." + k: v for k, v in online.items()})
+        averaged = diffusion_state_dict(d, ema=True) if self.step > 0 else online
+        out.update({"ema_model." + k: v for k, v in averaged.items()})
+        return out
+
+    def load_state_dict(self, sd):
+        self.initted = bool(sd["initted"])
+        self.step = int(sd["step"])
+        pre = "ema_model.model."
+        if self.step > 0:
+            self.online_model.model.load_ema_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
+        self._ema_model_step = -1
+        return self
+
     @property
     def ema_model(self):
         """A sampler holding the EMA weights (a second U-Net handle, refreshed when the EMA state has moved on)."""
@@ -73,6 +95,42 @@ class EMA:
             self._ema_model.model.load_state_dict(d.model.state_dict(ema=True))
             self._ema_model_step = self.step
         return self._ema_model
+
+
+def diffusion_state_dict(diffusion, ema: bool = False):
+    """``DenoisingDiffusion.state_dict()`` of the reference module: the 13 schedule buffers + ``model.*`` (the online
+    parameters of the device-resident training state, or its EMA copy)."""
+    out = dict(diffusion.state_dict())
+    out.update({"model." + k: v.cpu() for k, v in diffusion.model.state_dict(ema=ema).items()})
+    return out
+
+
+def save_checkpoint(path, diffusion, *, step: int, ema: Optional[EMA] = None, lr=1e-4, betas=(0.9, 0.99), eps=1e-8,
+                    version: str = "dm_hip"):
+    """``Trainer.save`` (:1100-1113): ``{'step', 'model', 'opt', 'ema', 'scaler', 'version'}`` in the reference's layouts
+    (``model``: ``DenoisingDiffusion.state_dict()``; ``opt``: ``torch.optim.Adam.state_dict()``; ``ema``:
+    ``ema_pytorch.EMA.state_dict()``), so that the reference's ``Trainer.load`` / sampling scripts -- and
+    ``load_checkpoint`` below -- read it back.  Tensors are written on the CPU."""
+    opt = diffusion.model.optimizer_state_dict(lr=lr, betas=betas, eps=eps)
+    for st in opt["state"].values():
+        st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].cpu(), st["exp_avg_sq"].cpu()
+    data = {"step": int(step), "model": diffusion_state_dict(diffusion), "opt": opt,
+            "ema": ema.state_dict() if ema is not None else None, "scaler": None, "version": version}
+    torch.save(data, str(path))
+    return data
+
+
+def load_checkpoint(path, diffusion, *, ema: Optional[EMA] = None):
+    """``Trainer.load`` (:1115-1133) into a diffusion object in training mode: the online parameters, Adam's moments and
+    step counter, the EMA copy and its counters.  Returns ``(step, adam_hyper_parameters)``.  The file is opened with
+    ``weights_only=True`` (nothing from it is executed)."""
+    data = torch.load(str(path), map_location="cpu", weights_only=True)
+    diffusion.load_state_dict(data["model"])
+    diffusion.train()
+    hyper = diffusion.model.load_optimizer_state_dict(data["opt"])
+    if ema is not None and data.get("ema") is not None:
+        ema.load_state_dict(data["ema"])
+    return int(data["step"]), hyper
 
 
 def train_step(diffusion, micro_batches: Iterable[torch.Tensor], *, lr=1e-4, betas=(0.9, 0.99), eps=1e-8,

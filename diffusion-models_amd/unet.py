@@ -216,13 +216,75 @@ class Unet:
         """The trained parameters (reference names / shapes) from the device-resident state; ``ema=True``: the EMA copy."""
         if not getattr(self, "_training", False):
             raise RuntimeError("state_dict() reads the device-resident training state: call train() first")
+        return self._train_tensors(1 if ema else 0)
+
+    def _train_tensors(self, which: int) -> Dict[str, torch.Tensor]:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         out = {}
         for name, shape in self.param_spec():
             t = torch.empty(tuple(shape), device=self.device, dtype=torch.float32)
-            _lib.check(self._lib.dm_unet_get_param(self._handle, name.encode(), 1 if ema else 0, _lib.ptr(t), stream))
+            _lib.check(self._lib.dm_unet_get_param(self._handle, name.encode(), which, _lib.ptr(t), stream))
             out[name] = t
         return out
+
+    def _set_train_tensors(self, which: int, tensors: Dict[str, torch.Tensor]):
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        keep = []
+        for name, shape in self.param_spec():
+            t = tensors[name].detach().to(device=self.device, dtype=torch.float32).contiguous()
+            if tuple(t.shape) != tuple(shape):
+                raise RuntimeError(f"size mismatch for {name}: {tuple(t.shape)} vs {tuple(shape)}")
+            keep.append(t)
+            _lib.check(self._lib.dm_unet_set_train_tensor(self._handle, name.encode(), which, _lib.ptr(t), stream))
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def optimizer_state_dict(self, lr=1e-4, betas=(0.9, 0.99), eps=1e-8) -> Dict:
+        """``torch.optim.Adam(model.parameters(), lr, betas).state_dict()`` of the device-resident optimiser state -- what
+        ``Trainer.save`` stores under ``'opt'`` (denoising_diffusion.py:1006, :1107): per parameter (in ``parameters()``
+        order = the state-dict order of the U-Net) ``step`` / ``exp_avg`` / ``exp_avg_sq``; the ``param_groups`` entry is
+        taken from a ``torch.optim.Adam`` of the installed torch, so that ``opt.load_state_dict`` accepts it."""
+        if not getattr(self, "_training", False):
+            raise RuntimeError("optimizer_state_dict() reads the device-resident training state: call train() first")
+        names = [n for n, _ in self.param_spec()]
+        dummy = [torch.nn.Parameter(torch.empty(0)) for _ in names]
+        groups = torch.optim.Adam(dummy, lr=lr, betas=tuple(betas), eps=eps).state_dict()["param_groups"]
+        step = int(self._lib.dm_unet_adam_step(self._handle, -1))
+        state = {}
+        if step > 0:
+            m, v = self._train_tensors(2), self._train_tensors(3)
+            for i, n in enumerate(names):
+                state[i] = {"step": torch.tensor(float(step)), "exp_avg": m[n], "exp_avg_sq": v[n]}
+        return {"state": state, "param_groups": groups}
+
+    def load_optimizer_state_dict(self, sd: Dict) -> Dict:
+        """Restore ``exp_avg`` / ``exp_avg_sq`` / ``step`` from a ``torch.optim.Adam`` state dict (``Trainer.load``,
+        :1125).  Returns the hyper-parameters of the (single) param group (``lr``, ``betas``, ``eps``)."""
+        if not getattr(self, "_training", False):
+            raise RuntimeError("load_optimizer_state_dict() writes the device-resident training state: call train() first")
+        names = [n for n, _ in self.param_spec()]
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(names):
+            raise RuntimeError("optimizer state does not match the U-Net: one param group over "
+                               f"{len(names)} parameters expected")
+        g = groups[0]
+        if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
+            raise RuntimeError("only the reference's plain Adam (no weight decay / amsgrad / maximize) is on the HIP path")
+        state = sd["state"]
+        if state:
+            idx = g["params"]
+            steps = {int(float(state[i]["step"])) for i in idx}
+            if len(steps) != 1:
+                raise RuntimeError("parameters with different Adam step counts")
+            self._set_train_tensors(2, {n: state[i]["exp_avg"] for n, i in zip(names, idx)})
+            self._set_train_tensors(3, {n: state[i]["exp_avg_sq"] for n, i in zip(names, idx)})
+            self._lib.dm_unet_adam_step(self._handle, steps.pop())
+        else:
+            self._lib.dm_unet_adam_step(self._handle, 0)
+        return {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"]}
+
+    def load_ema_state_dict(self, sd: Dict[str, torch.Tensor]):
+        """The EMA copy of the parameters from a dict with the U-Net's names."""
+        self._set_train_tensors(1, sd)
 
     def sync(self):
         """Make the sampling path of THIS handle see the trained weights (device -> host -> re-pack)."""

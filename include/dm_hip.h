@@ -333,7 +333,12 @@ int dm_unet_loss_backward(dm_unet* u, const float* x_start, const int64_t* t_hos
  *   dm_unet_optimizer_step: clip_grad_norm_(max_grad_norm; <= 0: off), Adam(lr, (beta1, beta2), eps) step; the total
  *                           gradient norm (before clipping) goes to grad_norm_out_host when given.
  *   dm_unet_ema_update:     copy != 0: ema <- online;  else ema <- ema * decay + online * (1 - decay)
- *   dm_unet_get_param:      one parameter of the online (which = 0) or EMA (which = 1) state into a device buffer
+ *   dm_unet_get_param:      one tensor of the online parameters (which = 0), the EMA copy (1) or Adam's exp_avg (2) /
+ *                           exp_avg_sq (3) into a device buffer -- what Trainer.save (:1100-1113) writes as 'model' / 'ema' /
+ *                           'opt'
+ *   dm_unet_set_train_tensor: the inverse for which = 1, 2, 3 (Trainer.load, :1115-1133; the online parameters go through
+ *                           dm_unet_set_param + dm_unet_refresh);  dm_unet_adam_step: torch.optim.Adam's `step` counter,
+ *                           returned (set first when set_to >= 0; -1: not a training handle)
  *   dm_unet_train_sync:     device -> host copies + dm_unet_refresh, after which the handle samples with the trained weights
  *                           (the sampling entry points refuse to run on stale fused packs until then)
  *   dm_unet_check_device_pack: self-check, number of packed buffers whose device packer differs from the host packer */
@@ -341,6 +346,8 @@ int dm_unet_optimizer_step(dm_unet* u, float lr, float beta1, float beta2, float
                            float* grad_norm_out_host, void* stream);
 int dm_unet_ema_update(dm_unet* u, float decay, int copy, void* stream);
 int dm_unet_get_param(dm_unet* u, const char* name, int which, float* out_dev, void* stream);
+int dm_unet_set_train_tensor(dm_unet* u, const char* name, int which, const float* src_dev, void* stream);
+long long dm_unet_adam_step(dm_unet* u, long long set_to);
 int dm_unet_train_sync(dm_unet* u);
 int dm_unet_check_device_pack(dm_unet* u);
 /* nn.Dropout(p) of the Blocks in training mode (Unet(dropout = p), :111,121; the shipped ddpm_cifar.yaml trains with 0.1).

@@ -163,6 +163,76 @@ def test_ema_and_sync_and_sampling_from_trained_weights():
     assert e.shape == a.shape and bool(torch.isfinite(e).all()) and not torch.equal(e, a)
 
 
+def test_checkpoint_round_trip_and_torch_adam_reads_the_optimiser_state(tmp_path):
+    """Trainer.save / Trainer.load (:1100-1133) on the device-resident state.
+    (1) two iterations, save, a third: a fresh object that loads the file and runs the third iteration ends with
+        bit-identical parameters, Adam moments and EMA copy (every kernel of the step is deterministic);
+    (2) the file is the reference's layout: ``weights_only=True`` loads it, ``data['model']`` is
+        ``DenoisingDiffusion.state_dict()``, ``data['ema']`` carries ``ema_model.*`` (what sampling.py:157-159 strips),
+        and ``data['opt']`` loads into a real ``torch.optim.Adam`` over parameters in state-dict order, whose next step on
+        the same gradients lands on the same parameters as dm_unet_optimizer_step;
+    (3) loading a state dict into a handle whose parameters moved on the device does not compare against stale host copies."""
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3)
+    g = torch.Generator().manual_seed(11)
+    batches = [torch.rand((4, 3, 16, 16), generator=g) for _ in range(3)]
+    ts = [torch.randint(0, 1000, (4,), generator=g) for _ in range(3)]
+    noises = [torch.randn((4, 3, 16, 16), generator=g) for _ in range(3)]
+    lr = 1e-3
+
+    def fresh():
+        d = _model(cfg, 41, "pred_noise", 1000)
+        return d, dm.EMA(d, beta=0.995, update_every=1, update_after_step=0)
+
+    d, ema = fresh()
+    for s in range(2):
+        dm.train_step(d, [batches[s]], lr=lr, ema=ema, t=[ts[s]], noise=[noises[s]])
+    path = tmp_path / "model-1.pt"
+    dm.save_checkpoint(path, d, step=2, ema=ema, lr=lr)
+    initial = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=41)
+    trained = {k: v.clone() for k, v in d.model.state_dict().items()}
+    # (2) the layout
+    data = torch.load(str(path), map_location="cpu", weights_only=True)
+    assert set(data) == {"step", "model", "opt", "ema", "scaler", "version"} and data["step"] == 2
+    names = [n for n, _ in d.model.param_spec()]
+    assert [k for k in data["model"] if k.startswith("model.")] == ["model." + n for n in names]
+    assert "betas" in data["model"] and "loss_weight" in data["model"]
+    assert dm.checkpoint.diffusion_state_dict_from_checkpoint(data).keys() == data["model"].keys()
+    assert int(data["ema"]["step"]) == 2 and "ema_model.model." + names[0] in data["ema"]
+    params = [torch.nn.Parameter(data["model"]["model." + n].clone()) for n in names]
+    opt = torch.optim.Adam(params, lr=lr, betas=(0.9, 0.99))
+    opt.load_state_dict(data["opt"])
+    assert all(float(opt.state[p]["step"]) == 2.0 for p in params)
+    # third iteration on the handle that kept running
+    dm.train_step(d, [batches[2]], lr=lr, ema=ema, t=[ts[2]], noise=[noises[2]])
+    grads = d.model.grads()  # the (unclipped) gradients of the third iteration
+    for p, n in zip(params, names):
+        p.grad = grads[n].cpu().clone()
+    torch.nn.utils.clip_grad_norm_(params, 1.0)
+    opt.step()
+    want = d.model.state_dict()
+    worst = max((rel_l2(p.detach(), want[n].cpu()), n) for p, n in zip(params, names))
+    print("torch.optim.Adam resumed from the file vs dm_unet_optimizer_step:", worst)
+    assert worst[0] < 1e-6
+    # (1) resume in a fresh object
+    d2, ema2 = fresh()
+    step, hyper = dm.load_checkpoint(path, d2, ema=ema2)
+    assert step == 2 and abs(hyper["lr"] - lr) < 1e-12 and tuple(hyper["betas"]) == (0.9, 0.99)
+    assert ema2.step == 2 and ema2.initted == ema.initted
+    dm.train_step(d2, [batches[2]], lr=lr, ema=ema2, t=[ts[2]], noise=[noises[2]])
+    for which, a, b in (("param", d.model.state_dict(), d2.model.state_dict()),
+                        ("ema", d.model.state_dict(ema=True), d2.model.state_dict(ema=True)),
+                        ("exp_avg", d.model._train_tensors(2), d2.model._train_tensors(2)),
+                        ("exp_avg_sq", d.model._train_tensors(3), d2.model._train_tensors(3))):
+        diff = [k for k in a if not torch.equal(a[k], b[k])]
+        assert not diff, (which, diff[:3])
+    assert d2.model._lib.dm_unet_adam_step(d2.model._handle, -1) == 3
+    # (3) the host copies of `d` still hold the initial weights; loading them back must reach the device all the same
+    d.model.load_state_dict(initial)
+    back = d.model.state_dict()
+    assert all(torch.equal(back[k].cpu(), initial[k]) for k in initial)
+    assert not torch.equal(trained[names[0]].cpu(), initial[names[0]])
+
+
 def _block_shapes(cfg, side):
     """(C, H, W) of every Block output in the order Unet.forward runs them (two per ResnetBlock)."""
     dims = cfg.dims
