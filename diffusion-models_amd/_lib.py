@@ -31,6 +31,7 @@ EXPORTS = (
     "dm_conv_create", "dm_conv_destroy", "dm_conv_forward", "dm_op_pool2d", "dm_op_resize_bilinear",
     "dm_op_copy_channels_nhwc", "dm_op_global_avgpool", "dm_op_linear",
     "dm_unet_train_enable", "dm_unet_grad_floats", "dm_unet_grads_flat", "dm_unet_get_grad", "dm_unet_loss_backward", "dm_op_q_sample",
+    "dm_op_offset_noise", "dm_op_cdist", "dm_op_gather_rows",
     "dm_unet_optimizer_step", "dm_unet_ema_update", "dm_unet_get_param", "dm_unet_set_train_tensor", "dm_unet_adam_step",
     "dm_unet_train_sync", "dm_unet_check_device_pack",
     "dm_unet_train_dropout", "dm_op_dropout_mask",
@@ -149,7 +150,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_unet_grad_floats.restype = i64
     lib.dm_unet_get_grad.argtypes = [vp, C.c_char_p, fp, vp]
     lib.dm_unet_grads_flat.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
-    lib.dm_unet_loss_backward.argtypes = [vp, fp, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, i32, fp, i32, i32, i32,
+    lib.dm_unet_loss_backward.argtypes = [vp, fp, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, fp, i32, fp, i32, i32, i32,
                                           C.c_float, i32, C.POINTER(C.c_float), fp, i32, i32, i32, vp]
     lib.dm_unet_optimizer_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), vp]
     lib.dm_unet_ema_update.argtypes = [vp, C.c_float, i32, vp]
@@ -162,6 +163,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_op_dropout_mask.argtypes = [fp, i64, C.c_float, u64, u64, i32, vp]
     lib.dm_unet_check_device_pack.argtypes = [vp]
     lib.dm_op_q_sample.argtypes = [fp, fp, C.POINTER(C.c_float), fp, i32, i32, vp]
+    lib.dm_op_offset_noise.argtypes = [fp, fp, C.c_float, i32, i32, vp]
+    lib.dm_op_cdist.argtypes = [fp, fp, fp, i32, i32, i64, vp]
+    lib.dm_op_gather_rows.argtypes = [fp, C.POINTER(i64), fp, i32, i64, vp]
     lib.dm_op_conv2d_bwd.argtypes = [fp, i32, fp, i32, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.dm_op_downsample_bwd.argtypes = [fp, i32, fp, fp, fp, fp, fp, i32, i32, i32, i32, vp]
     lib.dm_op_block_bwd.argtypes = [fp, i32] + [fp] * 12 + [i32, i32, i32, i32, vp]

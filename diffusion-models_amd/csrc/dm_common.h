@@ -357,6 +357,8 @@ int launch_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, float
                         int accumulate, hipStream_t s);
 int launch_mlp_rows_wgrad(const float* dy, int ldy, const float* x, int ldx, float* const* dw_rows, float* const* db_rows,
                           int R, int I, int O, int accumulate, hipStream_t s);
+int launch_offset_noise(float* noise, const float* offset, float strength, int BC, int HW, hipStream_t s);
+int launch_cdist(const float* x, const float* y, float* out, int n, int m, int64_t D, hipStream_t s);
 size_t linear_dgrad_ws_floats(int R, int I, int O);
 int launch_linear_dgrad(const float* dy, int ldy, const float* W, float* dx, int ldx, int R, int I, int O, float* ws,
                         hipStream_t s);

@@ -637,6 +637,47 @@ __global__ void q_sample_kernel(const float* __restrict__ x_start, const float* 
     const float* c = coef + DM_TRAIN_COEFS * (i / per_sample);
     x[i] = c[0] * x_start[i] + c[1] * noise[i];
 }
+// offset noise (:830-834): noise += offset_noise_strength * offset[b][c] (two roundings, as the reference's expression)
+__global__ void offset_noise_kernel(float* __restrict__ noise, const float* __restrict__ offset, float strength, int HW,
+                                    int64_t n) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float o = strength * offset[i / HW];
+    noise[i] = noise[i] + o;
+}
+int launch_offset_noise(float* noise, const float* offset, float strength, int BC, int HW, hipStream_t s) {
+    const int64_t n = (int64_t)BC * HW;
+    hipLaunchKernelGGL(offset_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, noise, offset, strength, HW, n);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// torch.cdist (p = 2) of two flattened batches: out[i][j] = sqrt(sum_d (x[i][d] - y[j][d])^2), one workgroup per pair
+__global__ __launch_bounds__(256) void cdist_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                    float* __restrict__ out, int m, int64_t D) {
+    __shared__ float red[256];
+    const int i = blockIdx.y, j = blockIdx.x;
+    const float* a = x + (size_t)i * D;
+    const float* b = y + (size_t)j * D;
+    float s = 0.f;
+    for (int64_t d = threadIdx.x; d < D; d += 256) {
+        const float v = a[d] - b[d];
+        s += v * v;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(size_t)i * m + j] = sqrtf(red[0]);
+}
+int launch_cdist(const float* x, const float* y, float* out, int n, int m, int64_t D, hipStream_t s) {
+    DM_REQUIRE(n <= 65535, "cdist: at most 65535 rows");
+    hipLaunchKernelGGL(cdist_kernel, dim3(m, n), dim3(256), 0, s, x, y, out, m, D);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 int launch_q_sample(const float* x_start, const float* noise, const float* coef_dev, float* x, int B, int per_sample,
                     hipStream_t s) {
     const int64_t n = (int64_t)B * per_sample;

@@ -97,7 +97,9 @@ class DenoisingDiffusion:
             lw = {"pred_noise": clipped / snr, "pred_x0": clipped, "pred_v": clipped / (snr + 1)}[objective]
             sched["loss_weight"] = lw.to(torch.float32)
         # training options the HIP training step does not implement are refused where they would change the result
-        assert not immiscible and not hybrid_loss, "immiscible noise assignment / hybrid loss are not on the HIP path"
+        # hybrid_loss (:880-897) is not built: the reference's KL term divides by posterior_variance[t], which is 0 at
+        # t = 0, and masks the result afterwards (inf * 0): its loss is NaN for every batch that holds a t = 0 sample
+        assert not hybrid_loss, "hybrid (KL) loss is not on the HIP path"
         self.offset_noise_strength = offset_noise_strength
         self.immiscible, self.hybrid_loss = immiscible, hybrid_loss
         self._sched = sched  # fp32 CPU tensors; the per-step scalars are derived from them on the host
@@ -226,11 +228,38 @@ class DenoisingDiffusion:
                             s["sqrt_recip_alphas_cumprod"][t], s["sqrt_recipm1_alphas_cumprod"][t], z, z],
                            dim=1).to(torch.float32).contiguous()
 
+    def noise_assignment(self, x_start, noise):
+        """:805-809 (immiscible diffusion): the assignment of noise rows to images that minimises the total L2 distance.
+        The (B, B) distance matrix is formed on the device; ``scipy.optimize.linear_sum_assignment`` runs on the host, as
+        in the reference."""
+        from scipy.optimize import linear_sum_assignment
+
+        b = x_start.shape[0]
+        x_start = x_start.to(self.device, torch.float32).contiguous()
+        noise = noise.to(self.device, torch.float32).contiguous()
+        dist = torch.empty((b, b), device=self.device, dtype=torch.float32)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.dm_op_cdist(_lib.ptr(x_start), _lib.ptr(noise), _lib.ptr(dist), b, b, x_start[0].numel(), stream))
+        _, assign = linear_sum_assignment(dist.cpu().numpy())
+        return torch.from_numpy(assign).long()
+
+    def _assigned(self, x_start, noise):
+        """noise[assign] of :815-817 as a new device tensor."""
+        assign = self.noise_assignment(x_start, noise).contiguous()
+        out = torch.empty_like(noise)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.dm_op_gather_rows(_lib.ptr(noise), C.cast(assign.data_ptr(), C.POINTER(C.c_int64)), _lib.ptr(out),
+                                               noise.shape[0], noise[0].numel(), stream))
+        torch.cuda.current_stream(self.device).synchronize()  # `assign` is host memory read by the enqueueing call only
+        return out
+
     def q_sample(self, x_start, t, noise=None):
-        """:813-821 (immiscible noise assignment off, the reference default)."""
+        """:813-821, with the immiscible noise assignment of :815-817 when the object was built with ``immiscible=True``."""
         x_start = x_start.to(self.device, torch.float32).contiguous()
         noise = (noise.to(self.device, torch.float32).contiguous() if noise is not None
                  else self._randn(x_start.shape, _default_seed(), 0))
+        if self.immiscible:
+            noise = self._assigned(x_start, noise)
         coef = self._tcoef(t)
         out = torch.empty_like(x_start)
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -239,16 +268,17 @@ class DenoisingDiffusion:
         return out
 
     def p_losses(self, x_start, t, noise=None, offset_noise_strength=None, cond=None, *, return_model_out=False,
-                 loss_scale=1.0, accumulate=False, self_cond=None, text_emb=None):
+                 loss_scale=1.0, accumulate=False, self_cond=None, text_emb=None, offset_noise=None):
         """:823-889: returns the loss (0-dim CPU tensor); the parameter gradients stay on the model
         (``self.model.grad(name)`` / ``.grads()``) -- loss and backward are one call of the library, there is no autograd
         graph to keep.  ``loss_scale`` / ``accumulate`` are the micro-batch loop of ``Trainer.train`` (:1164-1176):
         ``loss / gradient_accumulate_every`` with the gradients added up.  With ``Unet(self_condition=True)`` half of the
         calls condition on a gradient-free prediction of x_start (:846-855; ``self_cond=True / False`` forces the branch).
-        Offset noise and the hybrid (KL) loss are not on this path."""
+        Offset noise (:830-834; ``offset_noise``: the (B, C) draw, for tests) and the immiscible noise assignment
+        (:815-817: q_sample mixes in ``noise[assign]`` while the target stays the unpermuted ``noise``, as in the
+        reference) are on this path; the hybrid (KL) loss is not."""
         if offset_noise_strength is None:
             offset_noise_strength = self.offset_noise_strength
-        assert not offset_noise_strength, "offset noise is not on the HIP training path"
         sc_mode = 0
         if self.self_condition:
             # :846-855: half of the iterations condition on the x_start a gradient-free pass predicts (self_cond= forces it)
@@ -260,6 +290,15 @@ class DenoisingDiffusion:
         b, c, h, w = x_start.shape
         noise = (noise.to(self.device, torch.float32).contiguous() if noise is not None
                  else self._randn(x_start.shape, _default_seed(), 0))
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if offset_noise_strength and offset_noise_strength > 0.0:
+            offs = (offset_noise.to(self.device, torch.float32).contiguous() if offset_noise is not None
+                    else self._randn((b, c), _default_seed(), 3))
+            assert tuple(offs.shape) == (b, c)
+            noise = noise.clone()  # the caller's tensor stays as it was
+            _lib.check(self._lib.dm_op_offset_noise(_lib.ptr(noise), _lib.ptr(offs), float(offset_noise_strength), b * c, h * w,
+                                                    stream))
+        noise_q = self._assigned(x_start, noise) if self.immiscible else None
         t_cpu = t.detach().to("cpu", torch.long).contiguous()
         coef = self._tcoef(t_cpu)
         cc = 0
@@ -271,10 +310,10 @@ class DenoisingDiffusion:
         loss = C.c_float(0.0)
         out = torch.empty_like(x_start) if return_model_out else None
         t_arr = (C.c_int64 * b)(*[int(v) for v in t_cpu.tolist()])
-        stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self._lib.dm_unet_loss_backward(
             self.model._handle, _lib.ptr(x_start), C.cast(t_arr, C.POINTER(C.c_int64)),
-            C.cast(coef.data_ptr(), C.POINTER(C.c_float)), _lib.ptr(noise), _lib.ptr(cond), cc, _lib.ptr(ctx), m, sc_mode,
+            C.cast(coef.data_ptr(), C.POINTER(C.c_float)), _lib.ptr(noise), _lib.ptr(noise_q), _lib.ptr(cond), cc,
+            _lib.ptr(ctx), m, sc_mode,
             self._objective_id,
             float(loss_scale), int(bool(accumulate)), C.byref(loss), _lib.ptr(out), b, h, w, stream))
         val = torch.tensor(loss.value, dtype=torch.float32)

@@ -322,9 +322,12 @@ int dm_unet_get_grad(dm_unet* u, const char* name, float* out_dev, void* stream)
  * image-conditional variant, concatenated behind x in front of init_conv (DD/denoising_diffusion_image_conditional.py:51-55,
  * p_losses :251-311).  ctx (optional): the text embeddings (B, ctx_tokens, text_emb_dim) of the text-conditional variant
  * (DD/denoising_diffusion_text_conditional.py:131-214, p_losses :476-542), concat or cross-attention per the handle's
- * text_mode.  The call synchronises the stream. */
+ * text_mode.  noise_q (optional): the noise q_sample mixes in when it is not `noise` itself -- with immiscible=True the
+ * reference's q_sample re-assigns the noise rows inside (:815-817) while p_losses keeps the unpermuted tensor as the
+ * target (:865).  The call synchronises the stream. */
 int dm_unet_loss_backward(dm_unet* u, const float* x_start, const int64_t* t_host, const float* coef_host,
-                          const float* noise, const float* cond, int cond_channels, const float* ctx, int ctx_tokens,
+                          const float* noise, const float* noise_q, const float* cond, int cond_channels, const float* ctx,
+                          int ctx_tokens,
                           int self_cond, int objective, float loss_scale, int accumulate, float* loss_out_host,
                           float* model_out, int B, int H, int W, void* stream);
 /* The rest of one Trainer.train iteration (:1178-1190) on device-resident state: the master parameters, the Adam moments and
@@ -361,6 +364,13 @@ int dm_op_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t c
 /* q_sample (:813-821) on its own: out = coef[b][0] * x_start + coef[b][1] * noise, coef_host (B, 8) as above */
 int dm_op_q_sample(const float* x_start, const float* noise, const float* coef_host, float* out, int B, int per_sample,
                    void* stream);
+/* offset noise (:830-834): noise[b][c][:] += strength * offset[b][c]  (noise (B, C, H, W) in place, offset (B, C)) */
+int dm_op_offset_noise(float* noise, const float* offset, float strength, int BC, int HW, void* stream);
+/* immiscible diffusion's noise assignment (:805-817): out[i][j] = || x[i] - y[j] ||_2 over D floats (torch.cdist of the
+ * flattened batches; the caller runs scipy's linear_sum_assignment on it, as the reference does, on the host) and the row
+ * gather dst[i] = src[idx[i]] (idx: n host indices) */
+int dm_op_cdist(const float* x, const float* y, float* out, int n, int m, int64_t D, void* stream);
+int dm_op_gather_rows(const float* src, const int64_t* idx_host, float* dst, int n, int64_t D, void* stream);
 
 /* Backward of the single operators above (what autograd computes for the reference module), for parity tests of each
  * piece of the training step.  All tensors NCHW fp32 device pointers; gradient outputs have the shape of the tensor they

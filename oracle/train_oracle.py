@@ -1,12 +1,12 @@
 """ORACLE -- test infrastructure, not product code.
 
 CPU restatement of the reference's training loss and of its gradients: ``q_sample`` and ``p_losses``
-(DD/denoising_diffusion.py:813-821, :823-889; hybrid_loss / offset noise / immiscible assignment off, as in every
-shipped config) over ``oracle.unet_oracle.unet_forward``, differentiated by torch autograd on the CPU.  Only ``tests/``,
+(DD/denoising_diffusion.py:813-821, :823-889, with offset noise :830-834 and the immiscible noise assignment :805-817;
+hybrid_loss off) over ``oracle.unet_oracle.unet_forward``, differentiated by torch autograd on the CPU.  Only ``tests/``,
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module.
 
-Pinned by ``tests/golden/train.pt``: loss and parameter-gradient digests of the reference's own
-``p_losses(...).backward()`` (tests/golden/make_golden_train.py); ``tests/test_oracle_golden.py`` holds this module to
+Pinned by ``tests/golden/train.pt`` / ``train_noise.pt``: loss and parameter-gradient digests of the reference's own
+``p_losses(...).backward()`` (tests/golden/make_golden_train.py, make_golden_train_noise.py); ``tests/test_oracle_golden.py`` holds this module to
 them.
 
 DD = denoising-diffusion-pytorch/denoising_diffusion/ in the reference checkout.
@@ -36,6 +36,15 @@ def q_sample(sched, x_start: torch.Tensor, t: torch.Tensor, noise: torch.Tensor)
     return a * x_start + b * noise
 
 
+def noise_assignment(x_start: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """:805-809: rows of ``noise`` assigned to the images so that the total L2 distance is smallest."""
+    from scipy.optimize import linear_sum_assignment
+
+    dist = torch.cdist(x_start.reshape(x_start.shape[0], -1), noise.reshape(noise.shape[0], -1))
+    _, assign = linear_sum_assignment(dist.cpu())
+    return torch.from_numpy(assign)
+
+
 def target_of(sched, objective: str, x_start, t, noise):
     """:864-872; predict_v :582-586."""
     if objective == "pred_noise":
@@ -60,11 +69,15 @@ def pred_x_start(sched, objective: str, x, t, out):
 
 
 def p_losses(sd: Dict[str, torch.Tensor], cfg, sched, x_start, t, noise, objective: str = "pred_noise", self_cond=False,
-             **fwd_kw):
+             offset_noise=None, offset_noise_strength=0.0, immiscible=False, **fwd_kw):
     """:823-889 with loss_weight from the schedule buffers (ones for the default ``ddpm=True``, :532-533).
     ``self_cond`` (``Unet(self_condition=True)``): the branch of :846-855 the reference takes for half of the iterations --
-    a gradient-free forward pass predicts x_start, which conditions the differentiated pass."""
-    x = q_sample(sched, x_start, t, noise)
+    a gradient-free forward pass predicts x_start, which conditions the differentiated pass.
+    ``offset_noise`` (B, C) with ``offset_noise_strength`` > 0: :830-834.  ``immiscible``: q_sample mixes in
+    ``noise[assign]`` (:815-817) while the target below stays the unpermuted noise, exactly as the reference has it."""
+    if offset_noise_strength > 0.0:
+        noise = noise + offset_noise_strength * offset_noise.reshape(*offset_noise.shape, 1, 1)
+    x = q_sample(sched, x_start, t, noise[noise_assignment(x_start, noise)] if immiscible else noise)
     if getattr(cfg, "self_condition", False) and self_cond:
         with torch.no_grad():
             det = {k: v.detach() for k, v in sd.items()}

@@ -88,6 +88,13 @@ def golden_train():
     return load_golden("train.pt")
 
 
+@pytest.fixture(scope="session")
+def golden_train_noise():
+    """The reference's p_losses(...).backward() with offset noise / with the immiscible noise assignment
+    (tests/golden/make_golden_train_noise.py)."""
+    return load_golden("train_noise.pt")
+
+
 def check_grad_digest(name: str, grad: torch.Tensor, dg: dict, tol: float):
     """A gradient against its golden digest: norm, 8 random projections, the first elements, the whole tensor if small.
     Every check is relative to the golden gradient's norm (a projection of a vector of norm n on a unit-variance random

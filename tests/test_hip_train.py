@@ -55,6 +55,34 @@ def test_loss_and_all_gradients_vs_reference_autograd(golden_train, case):
     print(case, "worst fully-stored gradient", worst)
 
 
+@pytest.mark.parametrize("case", ["offset", "immiscible"])
+def test_noise_options_vs_reference_autograd(golden_train_noise, case):
+    """Offset noise (:830-834) and immiscible diffusion (:805-817: the assignment on a device-side cdist + scipy on the
+    host, q_sample on the re-assigned rows, the unpermuted noise as the target) against the reference's own loss and
+    gradients."""
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3)
+    b = golden_train_noise[case]
+    u = dm.Unet(dim=32, dim_mults=(1, 2), channels=3, device=DEV)
+    u.load_state_dict(dm.synth_state_dict(dm.unet_param_spec(cfg), salt=41))
+    d = dm.DenoisingDiffusion(u, image_size=16, timesteps=b["T"], immiscible=case == "immiscible").train()
+    x_start = b["img"] * 2 - 1
+    if case == "offset":
+        noise = b["noise"].clone()
+        loss = d.p_losses(x_start, b["t"], noise=noise, offset_noise_strength=b["strength"], offset_noise=b["offset"])
+        assert torch.equal(noise, b["noise"])  # the caller's tensor is not modified
+    else:
+        assert d.noise_assignment(x_start, b["noise"]).tolist() == b["assign"].tolist()
+        assert rel_l2(d.q_sample(x_start, b["t"], b["noise"]).cpu(), b["x_noisy"]) < 1e-6
+        loss = d.p_losses(x_start, b["t"], noise=b["noise"])
+    print(case, "loss", float(loss), b["loss"])
+    assert abs(float(loss) - b["loss"]) <= 1e-5 * abs(b["loss"])
+    grads = d.model.grads()
+    for name, dg in b["grads"].items():
+        check_grad_digest(name, grads[name].cpu(), dg, GRAD_TOL)
+    if case == "offset":  # drawn on the device when not injected
+        assert bool(torch.isfinite(d.p_losses(x_start, b["t"], offset_noise_strength=0.1)))
+
+
 def test_forward_draws_t_and_noise(golden_train):
     """DenoisingDiffusion.forward (:892-899): img in [0, 1] -> normalize -> p_losses with random t / noise; with the
     reference's t and noise injected the loss is the reference's."""

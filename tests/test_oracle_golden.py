@@ -398,3 +398,31 @@ def test_train_loss_and_gradients(golden_train, case):
     assert set(grads) == set(b["grads"])
     for name, dg in b["grads"].items():
         check_grad_digest(name, grads[name], dg, 2e-5)
+
+
+@pytest.mark.parametrize("case", ["offset", "immiscible"])
+def test_train_noise_options(golden_train_noise, case):
+    """Offset noise (:830-834) and the immiscible noise assignment (:805-817) of the oracle's p_losses against the
+    reference's own: the assignment, q_sample, the loss and every gradient."""
+    from conftest import check_grad_digest
+    from oracle import train_oracle as to
+
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3)
+    b = golden_train_noise[case]
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=41)
+    sched = dm.make_schedule(b["T"], "linear")
+    x_start = b["img"] * 2 - 1
+    kw = {}
+    if case == "offset":
+        kw = dict(offset_noise=b["offset"], offset_noise_strength=b["strength"])
+    else:
+        assign = to.noise_assignment(x_start, b["noise"])
+        assert assign.tolist() == b["assign"].tolist() and assign.tolist() != list(range(len(assign)))
+        assert rel_l2(to.q_sample(sched, x_start, b["t"], b["noise"][assign]), b["x_noisy"]) < 1e-6
+        kw = dict(immiscible=True)
+    torch.set_num_threads(8)
+    loss, grads = to.loss_and_grads(sd, cfg, sched, x_start, b["t"], b["noise"], "pred_noise", **kw)
+    assert abs(loss - b["loss"]) <= 1e-5 * abs(b["loss"]), (loss, b["loss"])
+    for name, dg in b["grads"].items():
+        check_grad_digest(name, grads[name], dg, 2e-5)
+
