@@ -330,11 +330,22 @@ int launch_linattn_fused(const LinAttnFused& w, const float* x, float* ws, float
 size_t wgrad_ws_floats(int B, int Ho, int Wo, int Cout, int Cin, int T, int* splits_out);
 // mode: 0 3x3 pad 1 (up: nearest x2 source), 1 1x1, 2 2x2 stride 2 (Ho, Wo = OUTPUT size; the source is 2Ho x 2Wo).
 // dw: OIHW (mode 2: the (Cout, 4 C) Downsample layout); ws from wgrad_ws_floats
+// The split-K sum of one layer (out[i * T + t] (+)= sum_split partial[(split * T + t) * oc + i]).  With `defer` the launchers
+// below only describe it; the training step then sums the partial tiles of ALL its layers in one launch
+// (launch_wgrad_reduce_jobs) instead of one small launch behind every weight-gradient kernel.
+struct WgradJob {
+    const float* partial;
+    float* out;
+    long long oc;
+    int splits, T, accumulate, first_block;  // first_block: prefix sum of ceil(oc / 64) * T over the jobs
+};
 int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float* dy, int Cout, int B, int Ho, int Wo,
-                 int mode, int up, float* ws, float* dw, int accumulate, hipStream_t s);
+                 int mode, int up, float* ws, float* dw, int accumulate, hipStream_t s, WgradJob* defer = nullptr);
 size_t wgrad_naive_ws_floats(int B, int H, int Cout, int Cin, int KH, int KW, int* splits_out);
 int launch_wgrad_naive(const float* x, int x_nchw, const float* dy, int dy_nchw, int Cin, int Cout, int KH, int KW, int pad,
-                       int B, int H, int W, float* ws, float* dw, int accumulate, hipStream_t s);
+                       int B, int H, int W, float* ws, float* dw, int accumulate, hipStream_t s, WgradJob* defer = nullptr);
+// jobs_dev: n_jobs descriptors in device memory with first_block filled in, total_blocks = the last prefix
+int launch_wgrad_reduce_jobs(const WgradJob* jobs_dev, int n_jobs, int total_blocks, hipStream_t s);
 size_t norm_act_bwd_ws_floats(int B, int pix_per_image, int C);
 int launch_norm_act_bwd(const float* dy, const float* u, const float* g, const float* ss, int ss_stride, int pix_per_image,
                         float* du, float* ws, float* dg, float* dbias, float* dss, int dss_stride, int B, int C, int flags,

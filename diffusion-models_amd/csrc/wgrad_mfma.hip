@@ -223,6 +223,37 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// the same sum for a table of layers: workgroup -> job by binary search over the block prefix, then as above
+__global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const WgradJob* __restrict__ jobs, int n_jobs) {
+    __shared__ float red[4][64];
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {  // last job whose first_block <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const WgradJob j = jobs[lo];
+    const int lb = blockIdx.x - j.first_block;
+    const int t = lb % j.T, bx = lb / j.T;
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t i = (int64_t)bx * 64 + li;
+    float s = 0.f;
+    if (i < j.oc)
+        for (int sp = q; sp < j.splits; sp += 4) s += j.partial[((int64_t)sp * j.T + t) * j.oc + i];
+    red[q][li] = s;
+    __syncthreads();
+    if (q == 0 && i < j.oc) {
+        const float v = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
+        float* o = j.out + i * j.T + t;
+        *o = j.accumulate ? *o + v : v;
+    }
+}
+int launch_wgrad_reduce_jobs(const WgradJob* jobs_dev, int n_jobs, int total_blocks, hipStream_t s) {
+    if (n_jobs <= 0) return 0;
+    hipLaunchKernelGGL(wgrad_reduce_jobs_kernel, dim3(total_blocks), dim3(256), 0, s, jobs_dev, n_jobs);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // pixel-block geometry of a (Ho, Wo) output: R rows x TW columns of one image, or NB whole images when an image has at
 // most 32 pixels (4x4 / 2x2 / 1x1 maps of the deep layers: a 16-pixel block would stage as much as it multiplies)
 struct WgradGeo {
@@ -265,7 +296,7 @@ size_t wgrad_ws_floats(int B, int Ho, int Wo, int Cout, int Cin, int T, int* spl
 
 // mode: 0 3x3 pad 1 (up: nearest x2 source), 1 1x1, 2 2x2 stride 2 (Ho, Wo = OUTPUT size; the source is 2Ho x 2Wo)
 int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float* dy, int Cout, int B, int Ho, int Wo,
-                 int mode, int up, float* ws, float* dw, int accumulate, hipStream_t s) {
+                 int mode, int up, float* ws, float* dw, int accumulate, hipStream_t s, WgradJob* defer) {
     DM_REQUIRE(C0 % 4 == 0 && C1 % 4 == 0 && Cout % 4 == 0 && C0 > 0, "wgrad: channel counts must be multiples of 4");
     DM_REQUIRE(mode >= 0 && mode <= 2 && (!up || (mode == 0 && Ho % 2 == 0 && Wo % 2 == 0)), "wgrad: mode");
     DM_REQUIRE((size_t)B * Ho * Wo * (size_t)std::max(Cout, C0 + C1) * (mode == 2 ? 4 : 1) < (1ull << 40), "wgrad: size");
@@ -310,6 +341,10 @@ int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float
     DM_CHECK_HIP(hipGetLastError());
     if (timed && prof::end(s)) return 1;
     const int64_t oc = (int64_t)Cout * p.Cin;
+    if (defer) {
+        *defer = WgradJob{ws, dw, oc, splits, T, accumulate, 0};
+        return 0;
+    }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((oc + 63) / 64), T), dim3(256), 0, s, ws, splits, T, oc, dw,
                        accumulate);
     DM_CHECK_HIP(hipGetLastError());
@@ -433,7 +468,7 @@ size_t wgrad_naive_ws_floats(int B, int H, int Cout, int Cin, int KH, int KW, in
 
 // x: NCHW when x_nchw else NHWC; dy likewise
 int launch_wgrad_naive(const float* x, int x_nchw, const float* dy, int dy_nchw, int Cin, int Cout, int KH, int KW, int pad,
-                       int B, int H, int W, float* ws, float* dw, int accumulate, hipStream_t s) {
+                       int B, int H, int W, float* ws, float* dw, int accumulate, hipStream_t s, WgradJob* defer) {
     DM_REQUIRE(KH == 2 * pad + 1 && KW == 2 * pad + 1, "naive wgrad: same-size convolutions only");
     WgradNaive p{};
     p.x = x; p.dy = dy; p.partial = ws;
@@ -453,6 +488,10 @@ int launch_wgrad_naive(const float* x, int x_nchw, const float* dy, int dy_nchw,
     else
         hipLaunchKernelGGL(wgrad_naive_kernel, dim3((n_out + 127) / 128, splits), dim3(128), 0, s, p);
     DM_CHECK_HIP(hipGetLastError());
+    if (defer) {
+        *defer = WgradJob{ws, dw, (long long)n_out, splits, 1, accumulate, 0};
+        return 0;
+    }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 63) / 64, 1), dim3(256), 0, s, ws, splits, 1, (int64_t)n_out, dw,
                        accumulate);
     DM_CHECK_HIP(hipGetLastError());
