@@ -341,6 +341,30 @@ struct WgradJob {
 };
 int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float* dy, int Cout, int B, int Ho, int Wo,
                  int mode, int up, float* ws, float* dw, int accumulate, hipStream_t s, WgradJob* defer = nullptr);
+// One layer's weight gradient as the grouped launch sees it (device table entry) and as the training step records it.
+struct WgradParams {
+    const float* in0;
+    const float* in1;
+    const float* dy;
+    float* partial;  // [split][T][Cout][Cin]
+    int C0, C1, Cin, Cout;
+    int B, Ho, Wo;   // size of dY (and of the input the convolution sees, except s2d: input is 2Ho x 2Wo)
+    int up;          // sources are (Ho/2, Wo/2), nearest-upsampled
+    int TW, R, NB;   // pixel block: NB images x R rows x TW columns (TW even), NB*R*TW <= 64; NB > 1 only for whole images
+    int tiles_x, tiles_y;
+    int n_blocks, blocks_per_split;
+    int n_ct, n_kt;  // cout / cin tiles of 64
+    int n_splits, first_wg;  // grouped launch: pixel splits of this layer, its first workgroup
+};
+struct WgradDesc {
+    const float *in0, *in1, *dy;
+    float* dw;
+    int C0, C1, Cout, B, Ho, Wo, up, accumulate;
+};
+void wgrad_group_plan(const std::vector<WgradDesc>& descs, int mode, std::vector<int>& splits, std::vector<size_t>& ws_floats);
+int wgrad_group_fill(const std::vector<WgradDesc>& descs, int mode, const std::vector<int>& splits, const std::vector<float*>& ws,
+                     std::vector<WgradParams>& table, std::vector<WgradJob>& jobs, int* total_wgs, size_t* lds_bytes);
+int launch_wgrad_group(const WgradParams* table_dev, int n_jobs, int total_wgs, size_t lds_bytes, int mode, hipStream_t s);
 size_t wgrad_naive_ws_floats(int B, int H, int Cout, int Cin, int KH, int KW, int* splits_out);
 int launch_wgrad_naive(const float* x, int x_nchw, const float* dy, int dy_nchw, int Cin, int Cout, int KH, int KW, int pad,
                        int B, int H, int W, float* ws, float* dw, int accumulate, hipStream_t s, WgradJob* defer = nullptr);

@@ -24,22 +24,9 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <vector>
 
 namespace dm {
-
-struct WgradParams {
-    const float* in0;
-    const float* in1;
-    const float* dy;
-    float* partial;  // [split][T][Cout][Cin]
-    int C0, C1, Cin, Cout;
-    int B, Ho, Wo;   // size of dY (and of the input the convolution sees, except s2d: input is 2Ho x 2Wo)
-    int up;          // sources are (Ho/2, Wo/2), nearest-upsampled
-    int TW, R, NB;   // pixel block: NB images x R rows x TW columns (TW even), NB*R*TW <= 64; NB > 1 only for whole images
-    int tiles_x, tiles_y;
-    int n_blocks, blocks_per_split;
-    int n_ct, n_kt;  // cout / cin tiles of 64
-};
 
 static constexpr int WG_SY = 64;  // floats per staged dY pixel
 static constexpr int WG_SX = 64;  // floats per staged X pixel
@@ -53,12 +40,30 @@ struct WgradMode<1> { static constexpr int T = 1, TA = 1, S = 1; };
 template <>
 struct WgradMode<2> { static constexpr int T = 4, TA = 4, S = 2; };
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p) {
+// GROUPED: one launch for a table of layers (the training step runs the weight gradients of ALL its convolutions of one
+// mode together at the end of the backward pass: the chip is filled by independent layers instead of by splitting every
+// layer's pixel range 256 ways); workgroup -> (layer, tile, split, kernel row) through the first_wg prefix.
+template <int MODE, bool GROUPED>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1, const WgradParams* __restrict__ table,
+                                                            int n_jobs) {
     constexpr int T = WgradMode<MODE>::T;    // taps of the partial layout
     constexpr int TA = WgradMode<MODE>::TA;  // taps (accumulators) of this workgroup
     constexpr int S = WgradMode<MODE>::S;
-    const int kyb = MODE == 0 ? blockIdx.z : 0;  // kernel row of this workgroup
+    int bx = blockIdx.x, split = blockIdx.y, kyb = MODE == 0 ? blockIdx.z : 0;  // tile, pixel split, kernel row
+    WgradParams p = p1;
+    if (GROUPED) {
+        int lo = 0, hi = n_jobs - 1;
+        while (lo < hi) {  // last layer whose first_wg <= blockIdx.x
+            const int mid = (lo + hi + 1) >> 1;
+            if (table[mid].first_wg <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        p = table[lo];
+        const int lb = blockIdx.x - p.first_wg, tiles = p.n_ct * p.n_kt;
+        bx = lb % tiles;
+        const int rest = lb / tiles;
+        split = rest % p.n_splits;
+        kyb = rest / p.n_splits;
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sY = smem;                // [64 px][64 couts]
     float* sX = smem + 64 * WG_SY;   // [WH * WW px][64 cins]
@@ -67,8 +72,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, k = lane >> 5;
-    const int ct = blockIdx.x % p.n_ct, kt = blockIdx.x / p.n_ct;
-    const int split = blockIdx.y;
+    const int ct = bx % p.n_ct, kt = bx / p.n_ct;
     const int TW = p.TW, R = p.R;
     const int WW = MODE == 0 ? TW + 2 : S * TW;
     const int WH = S * R;
@@ -294,13 +298,19 @@ size_t wgrad_ws_floats(int B, int Ho, int Wo, int Cout, int Cin, int T, int* spl
     return wgrad_ws_floats_mode(B, Ho, Wo, Cout, Cin, T, T == 9 ? 0 : (T == 1 ? 1 : 2), splits_out);
 }
 
-// mode: 0 3x3 pad 1 (up: nearest x2 source), 1 1x1, 2 2x2 stride 2 (Ho, Wo = OUTPUT size; the source is 2Ho x 2Wo)
-int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float* dy, int Cout, int B, int Ho, int Wo,
-                 int mode, int up, float* ws, float* dw, int accumulate, hipStream_t s, WgradJob* defer) {
+static int wgrad_taps(int mode) { return mode == 0 ? 9 : (mode == 1 ? 1 : 4); }
+static size_t wgrad_lds_bytes(const WgradParams& p, int mode) {
+    const int WW = mode == 0 ? p.TW + 2 : (mode == 2 ? 2 * p.TW : p.TW);
+    const int WH = mode == 2 ? 2 * p.R : p.R;
+    return (size_t)(64 * WG_SY + p.NB * WH * WW * WG_SX) * sizeof(float);
+}
+// geometry of one layer's weight gradient for `splits` pixel splits (ws: splits * T * Cout * Cin floats)
+static int wgrad_fill(WgradParams& p, const float* in0, int C0, const float* in1, int C1, const float* dy, int Cout, int B, int Ho,
+                      int Wo, int mode, int up, float* ws, int splits) {
     DM_REQUIRE(C0 % 4 == 0 && C1 % 4 == 0 && Cout % 4 == 0 && C0 > 0, "wgrad: channel counts must be multiples of 4");
     DM_REQUIRE(mode >= 0 && mode <= 2 && (!up || (mode == 0 && Ho % 2 == 0 && Wo % 2 == 0)), "wgrad: mode");
     DM_REQUIRE((size_t)B * Ho * Wo * (size_t)std::max(Cout, C0 + C1) * (mode == 2 ? 4 : 1) < (1ull << 40), "wgrad: size");
-    WgradParams p{};
+    p = WgradParams{};
     p.in0 = in0; p.in1 = C1 ? in1 : in0; p.dy = dy; p.partial = ws;
     p.C0 = C0; p.C1 = C1; p.Cin = C0 + C1; p.Cout = Cout;
     p.B = B; p.Ho = Ho; p.Wo = Wo; p.up = up;
@@ -311,17 +321,26 @@ int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float
     p.n_blocks = g.n_blocks;
     p.n_ct = (Cout + 63) / 64;
     p.n_kt = (p.Cin + 63) / 64;
-    const int T = mode == 0 ? 9 : (mode == 1 ? 1 : 4);
-    int splits = 1;
-    (void)wgrad_ws_floats_mode(B, Ho, Wo, Cout, p.Cin, T, mode, &splits);
     p.blocks_per_split = (p.n_blocks + splits - 1) / splits;
+    p.n_splits = splits;
     const int WW = mode == 0 ? p.TW + 2 : (mode == 2 ? 2 * p.TW : p.TW);
     const int WH = mode == 2 ? 2 * p.R : p.R;
-    const size_t lds = (size_t)(64 * WG_SY + p.NB * WH * WW * WG_SX) * sizeof(float);
-    DM_REQUIRE(lds <= 160 * 1024, "wgrad: LDS");
+    DM_REQUIRE(wgrad_lds_bytes(p, mode) <= 160 * 1024, "wgrad: LDS");
     DM_REQUIRE(p.NB * p.R * p.TW <= 64 && p.NB * WH * WW <= 16 * (mode == 0 ? 6 : (mode == 1 ? 4 : 16)) && p.TW < 4096 &&
                    WH < 4096,
                "wgrad: block larger than the staging items");
+    return 0;
+}
+
+// mode: 0 3x3 pad 1 (up: nearest x2 source), 1 1x1, 2 2x2 stride 2 (Ho, Wo = OUTPUT size; the source is 2Ho x 2Wo)
+int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float* dy, int Cout, int B, int Ho, int Wo,
+                 int mode, int up, float* ws, float* dw, int accumulate, hipStream_t s, WgradJob* defer) {
+    const int T = wgrad_taps(mode);
+    int splits = 1;
+    (void)wgrad_ws_floats_mode(B, Ho, Wo, Cout, C0 + C1, T, mode, &splits);
+    WgradParams p;
+    if (wgrad_fill(p, in0, C0, in1, C1, dy, Cout, B, Ho, Wo, mode, up, ws, splits)) return 1;
+    const size_t lds = wgrad_lds_bytes(p, mode);
     const dim3 grid(p.n_ct * p.n_kt, splits, mode == 0 ? 3 : 1);
     const bool timed = prof::enabled();
     if (timed && prof::begin("wgrad_mfma_kernel", 2.0 * T * p.Cin * Cout * (double)B * Ho * Wo,
@@ -329,14 +348,14 @@ int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float
         return 1;
     static LdsOptIn f0, f1, f2;
     if (mode == 0) {
-        if (lds_opt_in(f0, reinterpret_cast<const void*>(wgrad_mfma_kernel<0>), 1)) return 1;
-        hipLaunchKernelGGL(wgrad_mfma_kernel<0>, grid, dim3(256), lds, s, p);
+        if (lds_opt_in(f0, reinterpret_cast<const void*>(wgrad_mfma_kernel<0, false>), 1)) return 1;
+        hipLaunchKernelGGL((wgrad_mfma_kernel<0, false>), grid, dim3(256), lds, s, p, nullptr, 1);
     } else if (mode == 1) {
-        if (lds_opt_in(f1, reinterpret_cast<const void*>(wgrad_mfma_kernel<1>), 1)) return 1;
-        hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), lds, s, p);
+        if (lds_opt_in(f1, reinterpret_cast<const void*>(wgrad_mfma_kernel<1, false>), 1)) return 1;
+        hipLaunchKernelGGL((wgrad_mfma_kernel<1, false>), grid, dim3(256), lds, s, p, nullptr, 1);
     } else {
-        if (lds_opt_in(f2, reinterpret_cast<const void*>(wgrad_mfma_kernel<2>), 1)) return 1;
-        hipLaunchKernelGGL(wgrad_mfma_kernel<2>, grid, dim3(256), lds, s, p);
+        if (lds_opt_in(f2, reinterpret_cast<const void*>(wgrad_mfma_kernel<2, false>), 1)) return 1;
+        hipLaunchKernelGGL((wgrad_mfma_kernel<2, false>), grid, dim3(256), lds, s, p, nullptr, 1);
     }
     DM_CHECK_HIP(hipGetLastError());
     if (timed && prof::end(s)) return 1;
@@ -347,6 +366,67 @@ int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float
     }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((oc + 63) / 64), T), dim3(256), 0, s, ws, splits, T, oc, dw,
                        accumulate);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- grouped form: the weight gradients of many layers of one mode in one launch ---------------------------------------
+// Pass 1 (wgrad_group_plan): splits per layer such that every workgroup gets about the same number of pixel blocks and the
+// launch has about `target` workgroups; returns the floats of partial-sum workspace each layer needs.
+void wgrad_group_plan(const std::vector<WgradDesc>& descs, int mode, std::vector<int>& splits, std::vector<size_t>& ws_floats) {
+    static const int target = env_int("DM_WGRAD_GROUP_WGS", 3072);
+    const int T = wgrad_taps(mode);
+    long long units = 0;
+    std::vector<WgradGeo> geo(descs.size());
+    for (size_t j = 0; j < descs.size(); ++j) {
+        const WgradDesc& d = descs[j];
+        geo[j] = wgrad_geo(d.B, d.Ho, d.Wo, mode);
+        const int tiles = ((d.Cout + 63) / 64) * ((d.C0 + d.C1 + 63) / 64) * (mode == 0 ? 3 : 1);
+        units += (long long)tiles * geo[j].n_blocks;
+    }
+    const int bps = (int)std::max<long long>(1, (units + target - 1) / target);
+    splits.resize(descs.size());
+    ws_floats.resize(descs.size());
+    for (size_t j = 0; j < descs.size(); ++j) {
+        const int sp = (geo[j].n_blocks + bps - 1) / bps;
+        const int per = (geo[j].n_blocks + sp - 1) / sp;
+        splits[j] = (geo[j].n_blocks + per - 1) / per;
+        ws_floats[j] = (size_t)splits[j] * T * descs[j].Cout * (descs[j].C0 + descs[j].C1);
+    }
+}
+// Pass 2: the parameter table (host) of the launch and the split-K sums it leaves behind
+int wgrad_group_fill(const std::vector<WgradDesc>& descs, int mode, const std::vector<int>& splits, const std::vector<float*>& ws,
+                     std::vector<WgradParams>& table, std::vector<WgradJob>& jobs, int* total_wgs, size_t* lds_bytes) {
+    const int T = wgrad_taps(mode);
+    int first = 0;
+    size_t lds = 0;
+    table.resize(descs.size());
+    for (size_t j = 0; j < descs.size(); ++j) {
+        const WgradDesc& d = descs[j];
+        if (wgrad_fill(table[j], d.in0, d.C0, d.in1, d.C1, d.dy, d.Cout, d.B, d.Ho, d.Wo, mode, d.up, ws[j], splits[j])) return 1;
+        table[j].first_wg = first;
+        first += table[j].n_ct * table[j].n_kt * splits[j] * (mode == 0 ? 3 : 1);
+        lds = std::max(lds, wgrad_lds_bytes(table[j], mode));
+        jobs.push_back(WgradJob{ws[j], d.dw, (long long)d.Cout * (d.C0 + d.C1), splits[j], T, d.accumulate, 0});
+    }
+    *total_wgs = first;
+    *lds_bytes = lds;
+    return 0;
+}
+int launch_wgrad_group(const WgradParams* table_dev, int n_jobs, int total_wgs, size_t lds_bytes, int mode, hipStream_t s) {
+    if (n_jobs <= 0) return 0;
+    static LdsOptIn f0, f1, f2;
+    const WgradParams none{};
+    if (mode == 0) {
+        if (lds_opt_in(f0, reinterpret_cast<const void*>(wgrad_mfma_kernel<0, true>), 1)) return 1;
+        hipLaunchKernelGGL((wgrad_mfma_kernel<0, true>), dim3(total_wgs), dim3(256), lds_bytes, s, none, table_dev, n_jobs);
+    } else if (mode == 1) {
+        if (lds_opt_in(f1, reinterpret_cast<const void*>(wgrad_mfma_kernel<1, true>), 1)) return 1;
+        hipLaunchKernelGGL((wgrad_mfma_kernel<1, true>), dim3(total_wgs), dim3(256), lds_bytes, s, none, table_dev, n_jobs);
+    } else {
+        if (lds_opt_in(f2, reinterpret_cast<const void*>(wgrad_mfma_kernel<2, true>), 1)) return 1;
+        hipLaunchKernelGGL((wgrad_mfma_kernel<2, true>), dim3(total_wgs), dim3(256), lds_bytes, s, none, table_dev, n_jobs);
+    }
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
