@@ -371,12 +371,29 @@ int launch_wgrad_naive(const float* x, int x_nchw, const float* dy, int dy_nchw,
 // jobs_dev: n_jobs descriptors in device memory with first_block filled in, total_blocks = the last prefix
 int launch_wgrad_reduce_jobs(const WgradJob* jobs_dev, int n_jobs, int total_blocks, hipStream_t s);
 size_t norm_act_bwd_ws_floats(int B, int pix_per_image, int C);
+// the two reduction stages behind a norm_act_bwd_kernel / the two passes of a column sum, as deferred table entries
+struct RowgradJob {
+    const float* part;
+    float *dss, *img, *dg, *dbias;
+    int chunks, C, dss_stride, B, accumulate, first_img_block, first_fin_block;
+    int pad_;
+};
+struct ColsumJob {
+    const float* x;
+    float *ws, *out;
+    long long rows, row_stride, col_stride;
+    int C, accumulate, nb, rpb, first_part_block, first_fin_block;
+};
 int launch_norm_act_bwd(const float* dy, const float* u, const float* g, const float* ss, int ss_stride, int pix_per_image,
                         float* du, float* ws, float* dg, float* dbias, float* dss, int dss_stride, int B, int C, int flags,
-                        int accumulate, hipStream_t s);
+                        int accumulate, hipStream_t s, RowgradJob* defer = nullptr);
+void rowgrad_jobs_prefix(std::vector<RowgradJob>& jobs, int* img_blocks, int* fin_blocks);
+int launch_rowgrad_jobs(const RowgradJob* jobs_dev, int n_jobs, int img_blocks, int fin_blocks, hipStream_t s);
+void colsum_jobs_prefix(std::vector<ColsumJob>& jobs, int* part_blocks, int* fin_blocks);
+int launch_colsum_jobs(const ColsumJob* jobs_dev, int n_jobs, int n_with_partial, int part_blocks, int fin_blocks, hipStream_t s);
 size_t colsum_ws_floats(int64_t rows, int C);
 int launch_colsum(const float* x, int64_t rows, int C, int64_t row_stride, int64_t col_stride, float* ws, float* out,
-                  int accumulate, hipStream_t s);
+                  int accumulate, hipStream_t s, ColsumJob* defer = nullptr);
 int launch_colsum_nchw(const float* dy, int B, int C, int HW, float* out, int accumulate, hipStream_t s);
 int launch_act_fwd(const float* x, float* y, int64_t n, int act, hipStream_t s);  // 1 SiLU, 2 GELU (erf)
 int launch_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, hipStream_t s);

@@ -186,6 +186,81 @@ __global__ __launch_bounds__(256) void rowgrad_finish_kernel(const float* __rest
     }
 }
 
+// The two stages above for a table of layers (the training step defers the reductions behind every norm_act_bwd_kernel of
+// a backward pass to two launches in front of the time-MLP gradients): workgroup -> job through the block prefixes.
+__global__ __launch_bounds__(64) void rowgrad_image_jobs_kernel(const RowgradJob* __restrict__ jobs, int n_jobs) {
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_img_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const RowgradJob j = jobs[lo];
+    const int lb = blockIdx.x - j.first_img_block, cb = (j.C + 63) / 64;
+    const int c = (lb % cb) * 64 + threadIdx.x, b = lb / cb;
+    if (c >= j.C) return;
+    const int C = j.C;
+    float sg = 0.f, sb = 0.f, ssc = 0.f, ssh = 0.f;
+    for (int k = 0; k < j.chunks; ++k) {
+        const float* q = j.part + ((size_t)b * j.chunks + k) * 4 * C;
+        sg += q[c];
+        sb += q[C + c];
+        ssc += q[2 * C + c];
+        ssh += q[3 * C + c];
+    }
+    if (j.dss) {
+        j.dss[(size_t)b * j.dss_stride + c] = ssc;
+        j.dss[(size_t)b * j.dss_stride + C + c] = ssh;
+    }
+    j.img[((size_t)b * 2) * C + c] = sg;
+    j.img[((size_t)b * 2 + 1) * C + c] = sb;
+}
+__global__ __launch_bounds__(256) void rowgrad_finish_jobs_kernel(const RowgradJob* __restrict__ jobs, int n_jobs) {
+    __shared__ float red[2][4][64];
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_fin_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const RowgradJob j = jobs[lo];
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = (blockIdx.x - j.first_fin_block) * 64 + li, C = j.C;
+    float sg = 0.f, sb = 0.f;
+    if (c < C)
+        for (int b = q; b < j.B; b += 4) {
+            sg += j.img[((size_t)b * 2) * C + c];
+            sb += j.img[((size_t)b * 2 + 1) * C + c];
+        }
+    red[0][q][li] = sg;
+    red[1][q][li] = sb;
+    __syncthreads();
+    if (q == 0 && c < C) {
+        sg = (red[0][0][li] + red[0][1][li]) + (red[0][2][li] + red[0][3][li]);
+        sb = (red[1][0][li] + red[1][1][li]) + (red[1][2][li] + red[1][3][li]);
+        if (j.dg) j.dg[c] = j.accumulate ? j.dg[c] + sg : sg;
+        if (j.dbias) j.dbias[c] = j.accumulate ? j.dbias[c] + sb : sb;
+    }
+}
+// jobs_host gets its block prefixes here; jobs_dev must hold the same table
+void rowgrad_jobs_prefix(std::vector<RowgradJob>& jobs, int* img_blocks, int* fin_blocks) {
+    int a = 0, f = 0;
+    for (RowgradJob& j : jobs) {
+        j.first_img_block = a;
+        j.first_fin_block = f;
+        a += ((j.C + 63) / 64) * j.B;
+        f += (j.C + 63) / 64;
+    }
+    *img_blocks = a;
+    *fin_blocks = f;
+}
+int launch_rowgrad_jobs(const RowgradJob* jobs_dev, int n_jobs, int img_blocks, int fin_blocks, hipStream_t s) {
+    if (n_jobs <= 0) return 0;
+    hipLaunchKernelGGL(rowgrad_image_jobs_kernel, dim3(img_blocks), dim3(64), 0, s, jobs_dev, n_jobs);
+    DM_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rowgrad_finish_jobs_kernel, dim3(fin_blocks), dim3(256), 0, s, jobs_dev, n_jobs);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 static int pow2ceil(int v) {
     int p = 1;
     while (p < v) p <<= 1;
@@ -201,7 +276,7 @@ size_t norm_act_bwd_ws_floats(int B, int pix_per_image, int C) {
 // receives (dscale | dshift) at columns [0, 2C) of each row when the forward had a scale-shift, else nullptr.
 int launch_norm_act_bwd(const float* dy, const float* u, const float* g, const float* ss, int ss_stride, int pix_per_image,
                         float* du, float* ws, float* dg, float* dbias, float* dss, int dss_stride, int B, int C, int flags,
-                        int accumulate, hipStream_t s) {
+                        int accumulate, hipStream_t s, RowgradJob* defer) {
     DM_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "norm_act_bwd: C must be a multiple of 4, at most 1024");
     NormBwdParams p{};
     p.dy = dy; p.u = u; p.g = g; p.ss = ss; p.du = du; p.part = ws;
@@ -224,6 +299,10 @@ int launch_norm_act_bwd(const float* dy, const float* u, const float* g, const f
     }
     DM_CHECK_HIP(hipGetLastError());
     float* img = ws + (size_t)B * p.chunks * 4 * C;
+    if (defer) {
+        *defer = RowgradJob{ws, (flags & EPI_SCALE_SHIFT) ? dss : nullptr, img, dg, dbias, p.chunks, C, dss_stride, B, accumulate, 0, 0};
+        return 0;
+    }
     hipLaunchKernelGGL(rowgrad_image_kernel, dim3((C + 63) / 64, B), dim3(64), 0, s, ws, p.chunks, C,
                        (flags & EPI_SCALE_SHIFT) ? dss : nullptr, dss_stride, img);
     DM_CHECK_HIP(hipGetLastError());
@@ -269,10 +348,88 @@ __global__ __launch_bounds__(1024) void colsum_lanes_kernel(const float* __restr
         out[c] = accumulate ? out[c] + v : v;
     }
 }
+// the two passes for a table of column sums (every bias / mem_kv gradient of a backward pass in two launches)
+__global__ __launch_bounds__(256) void colsum_partial_jobs_kernel(const ColsumJob* __restrict__ jobs, int n_jobs) {
+    __shared__ float red[4][64];
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_part_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ColsumJob j = jobs[lo];  // jobs without a partial pass have nb == 0 and own no block: never selected
+    const int lb = blockIdx.x - j.first_part_block, cb = (j.C + 63) / 64;
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = (lb % cb) * 64 + li, by = lb / cb;
+    const long long r0 = (long long)by * j.rpb, r1 = min(r0 + (long long)j.rpb, j.rows);
+    float s = 0.f;
+    if (c < j.C)
+        for (long long r = r0 + q; r < r1; r += 4) s += j.x[r * j.row_stride + c * j.col_stride];
+    red[q][li] = s;
+    __syncthreads();
+    if (q == 0 && c < j.C) j.ws[(size_t)by * j.C + c] = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
+}
+__global__ __launch_bounds__(1024) void colsum_lanes_jobs_kernel(const ColsumJob* __restrict__ jobs, int n_jobs) {
+    __shared__ float red[16][64];
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_fin_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ColsumJob j = jobs[lo];
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = (blockIdx.x - j.first_fin_block) * 64 + li;
+    const float* x = j.nb > 0 ? j.ws : j.x;
+    const long long rows = j.nb > 0 ? j.nb : j.rows, rs = j.nb > 0 ? j.C : j.row_stride, cs = j.nb > 0 ? 1 : j.col_stride;
+    float s = 0.f;
+    if (c < j.C)
+        for (long long r = q; r < rows; r += 16) s += x[r * rs + c * cs];
+    red[q][li] = s;
+    __syncthreads();
+    if (q == 0 && c < j.C) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][li];
+        j.out[c] = j.accumulate ? j.out[c] + v : v;
+    }
+}
+void colsum_jobs_prefix(std::vector<ColsumJob>& jobs, int* part_blocks, int* fin_blocks) {
+    int a = 0, f = 0;
+    // jobs with a partial pass first, so that the binary search over first_part_block never lands on one without
+    std::stable_sort(jobs.begin(), jobs.end(), [](const ColsumJob& x, const ColsumJob& y) { return (x.nb > 0) > (y.nb > 0); });
+    for (ColsumJob& j : jobs) {
+        j.first_part_block = a;
+        j.first_fin_block = f;
+        a += ((j.C + 63) / 64) * j.nb;
+        f += (j.C + 63) / 64;
+    }
+    *part_blocks = a;
+    *fin_blocks = f;
+}
+int launch_colsum_jobs(const ColsumJob* jobs_dev, int n_jobs, int n_with_partial, int part_blocks, int fin_blocks, hipStream_t s) {
+    if (n_jobs <= 0) return 0;
+    if (part_blocks > 0) {
+        hipLaunchKernelGGL(colsum_partial_jobs_kernel, dim3(part_blocks), dim3(256), 0, s, jobs_dev, n_with_partial);
+        DM_CHECK_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(colsum_lanes_jobs_kernel, dim3(fin_blocks), dim3(1024), 0, s, jobs_dev, n_jobs);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 static int colsum_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(512, rows / 64)); }
 size_t colsum_ws_floats(int64_t rows, int C) { return (size_t)colsum_blocks(rows) * C; }
 int launch_colsum(const float* x, int64_t rows, int C, int64_t row_stride, int64_t col_stride, float* ws, float* out,
-                  int accumulate, hipStream_t s) {
+                  int accumulate, hipStream_t s, ColsumJob* defer) {
+    if (defer) {
+        int nb = 0, rpb = 0;
+        if (rows > 512) {
+            const int blocks = colsum_blocks(rows);
+            rpb = (int)((rows + blocks - 1) / blocks);
+            nb = (int)((rows + rpb - 1) / rpb);
+        }
+        *defer = ColsumJob{x, ws, out, (long long)rows, (long long)row_stride, (long long)col_stride, C, accumulate, nb, rpb, 0, 0};
+        return 0;
+    }
     if (rows <= 512) {
         hipLaunchKernelGGL(colsum_lanes_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, x, (int)rows, C, row_stride, col_stride,
                            out, accumulate);
