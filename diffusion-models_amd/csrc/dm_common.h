@@ -337,7 +337,7 @@ struct WgradJob {
     const float* partial;
     float* out;
     long long oc;
-    int splits, T, accumulate, first_block;  // first_block: prefix sum of ceil(oc / 64) * T over the jobs
+    int splits, T, accumulate, first_block;  // first_block: prefix sum of ceil(oc / 64) over the jobs (T <= 9)
 };
 int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float* dy, int Cout, int B, int Ho, int Wo,
                  int mode, int up, float* ws, float* dw, int accumulate, hipStream_t s, WgradJob* defer = nullptr);

@@ -227,29 +227,44 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// the same sum for a table of layers: workgroup -> job by binary search over the block prefix, then as above
+// the same sum for a table of layers: workgroup -> job by binary search over the block prefix.  One workgroup = 64
+// consecutive (cout, cin) pairs x ALL taps, so the OIHW result leaves as one contiguous run of 64 * T floats (a
+// workgroup per tap wrote 4-byte pieces 4 * T bytes apart: 0.5 ms for the 143 MB of gradients).  T >= 4: thread (pair, q)
+// owns the taps q, q + 4, .. and adds their splits in order; T < 4: the four q share the splits of one tap.
 __global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const WgradJob* __restrict__ jobs, int n_jobs) {
-    __shared__ float red[4][64];
+    __shared__ float tile[64 * 9 + 4 * 64];
     int lo = 0, hi = n_jobs - 1;
     while (lo < hi) {  // last job whose first_block <= blockIdx.x
         const int mid = (lo + hi + 1) >> 1;
         if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const WgradJob j = jobs[lo];
-    const int lb = blockIdx.x - j.first_block;
-    const int t = lb % j.T, bx = lb / j.T;
+    const int T = j.T;
     const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int64_t i = (int64_t)bx * 64 + li;
-    float s = 0.f;
-    if (i < j.oc)
-        for (int sp = q; sp < j.splits; sp += 4) s += j.partial[((int64_t)sp * j.T + t) * j.oc + i];
-    red[q][li] = s;
-    __syncthreads();
-    if (q == 0 && i < j.oc) {
-        const float v = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
-        float* o = j.out + i * j.T + t;
-        *o = j.accumulate ? *o + v : v;
+    const int64_t i0 = (int64_t)(blockIdx.x - j.first_block) * 64, i = i0 + li;
+    if (T >= 4) {
+        for (int t = q; t < T; t += 4) {
+            float s = 0.f;
+            if (i < j.oc)
+                for (int sp = 0; sp < j.splits; ++sp) s += j.partial[((int64_t)sp * T + t) * j.oc + i];
+            tile[li * T + t] = s;
+        }
+    } else {
+        float* red = tile + 64 * 9;
+        for (int t = 0; t < T; ++t) {
+            float s = 0.f;
+            if (i < j.oc)
+                for (int sp = q; sp < j.splits; sp += 4) s += j.partial[((int64_t)sp * T + t) * j.oc + i];
+            __syncthreads();
+            red[q * 64 + li] = s;
+            __syncthreads();
+            if (q == 0) tile[li * T + t] = (red[li] + red[64 + li]) + (red[128 + li] + red[192 + li]);
+        }
     }
+    __syncthreads();
+    const int64_t n = min((int64_t)64, j.oc - i0) * T;
+    float* o = j.out + i0 * T;
+    for (int k = threadIdx.x; k < n; k += 256) o[k] = j.accumulate ? o[k] + tile[k] : tile[k];
 }
 int launch_wgrad_reduce_jobs(const WgradJob* jobs_dev, int n_jobs, int total_blocks, hipStream_t s) {
     if (n_jobs <= 0) return 0;
