@@ -432,6 +432,16 @@ int launch_pack_wino4(const float* oihw, float* packed, int Cout, int Cin, hipSt
 int launch_pack_upwino(const float* oihw, float* packed, int Cout, int Cin, hipStream_t s);
 int launch_pack_pw(const float* w, float* packed, int Cout, int Cin, int s2d_C0, hipStream_t s);
 int launch_pack_init7(const float* oihw, float* packed, int Cin, hipStream_t s);
+// one job of a grouped re-pack (pack_kernels.hip: pack_jobs_kernel)
+enum PackJobKind { PJ_COPY = 0, PJ_ROT, PJ_S2D_T, PJ_WINO, PJ_WINO4, PJ_UPWINO, PJ_PW };
+struct PackJob {
+    const float* src;
+    float* dst;
+    long long n;  // threads (elements) of the job
+    int kind, Cout, Cin, a, b, first_block;  // a, b: PJ_ROT K, c_lo; PJ_PW s2d_C0
+};
+int pack_jobs_prefix(std::vector<PackJob>& jobs);
+int launch_pack_jobs(const PackJob* jobs_dev, int n_jobs, int total_blocks, hipStream_t s);
 int launch_rot_transpose(const float* w, float* out, int Cout, int Cin, int K, int c_lo, int c_n, hipStream_t s);
 int launch_s2d_transpose(const float* w, float* out, int Cout, int C, hipStream_t s);
 // table_dev: device array of {long long src_off; float* dst; long long n;}: dst[i] = param[src_off + i]

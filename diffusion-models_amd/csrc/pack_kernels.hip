@@ -65,10 +65,9 @@ __global__ void fold_taps_kernel(const float* __restrict__ oihw, float* __restri
 }
 
 // wino_pack_weights: U = G g G^T (4x4) -> [chunk of 8 cin][xi 16][Cout][8]; one thread per (cout, cin)
-__global__ void pack_wino_kernel(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin) {
+__device__ __forceinline__ void pack_wino_elem(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin,
+                                               int64_t i) {
 #pragma clang fp contract(off)  // the host packer (x86-64 baseline) rounds every product and sum separately
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)Cout * Cin) return;
     const int co = (int)(i / Cin), ci = (int)(i % Cin);
     const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     const float* gk = oihw + i * 9;
@@ -83,11 +82,14 @@ __global__ void pack_wino_kernel(const float* __restrict__ oihw, float* __restri
         }
 }
 
-// wino4_pack_weights: U = G g G^T (6x6) -> [chunk][wave 4][slot 9][cout tile][kq 4][n 16][gq 4][st 2]
-__global__ void pack_wino4_kernel(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin) {
-#pragma clang fp contract(off)  // the host packer (x86-64 baseline) rounds every product and sum separately
+__global__ void pack_wino_kernel(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)Cout * Cin) return;
+    if (i < (int64_t)Cout * Cin) pack_wino_elem(oihw, packed, Cout, Cin, i);
+}
+// wino4_pack_weights: U = G g G^T (6x6) -> [chunk][wave 4][slot 9][cout tile][kq 4][n 16][gq 4][st 2]
+__device__ __forceinline__ void pack_wino4_elem(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin,
+                                                int64_t i) {
+#pragma clang fp contract(off)  // the host packer (x86-64 baseline) rounds every product and sum separately
     const int co = (int)(i / Cin), ci = (int)(i % Cin);
     const double G[6][3] = {{0.25, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                             {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
@@ -110,11 +112,14 @@ __global__ void pack_wino4_kernel(const float* __restrict__ oihw, float* __restr
             }
 }
 
-// upwino_pack_weights: G = [1 0 0; 1 1 1; 0 0 1] -> [chunk][xi 9][cout tile][kq 4][n 16][gq 4][st 2]
-__global__ void pack_upwino_kernel(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin) {
-#pragma clang fp contract(off)  // the host packer (x86-64 baseline) rounds every product and sum separately
+__global__ void pack_wino4_kernel(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)Cout * Cin) return;
+    if (i < (int64_t)Cout * Cin) pack_wino4_elem(oihw, packed, Cout, Cin, i);
+}
+// upwino_pack_weights: G = [1 0 0; 1 1 1; 0 0 1] -> [chunk][xi 9][cout tile][kq 4][n 16][gq 4][st 2]
+__device__ __forceinline__ void pack_upwino_elem(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin,
+                                                 int64_t i) {
+#pragma clang fp contract(off)  // the host packer (x86-64 baseline) rounds every product and sum separately
     const int co = (int)(i / Cin), ci = (int)(i % Cin);
     const double G[3][3] = {{1, 0, 0}, {1, 1, 1}, {0, 0, 1}};
     const float* gk = oihw + i * 9;
@@ -130,11 +135,14 @@ __global__ void pack_upwino_kernel(const float* __restrict__ oihw, float* __rest
         }
 }
 
+__global__ void pack_upwino_kernel(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)Cout * Cin) pack_upwino_elem(oihw, packed, Cout, Cin, i);
+}
 // pw_pack_weights: (Cout, Cin) -> [chunk of 16][cout tile of 16][lane = 16 kq + l15][j 4];  s2d: the (Cout, C0, 2, 2)
 // Downsample weight read as (Cout, 4 C0) with K index sub * C0 + c
-__global__ void pack_pw_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin, int s2d_C0) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)Cout * Cin) return;
+__device__ __forceinline__ void pack_pw_elem(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin,
+                                             int s2d_C0, int64_t i) {
     const int co = (int)(i / Cin), ci = (int)(i % Cin);
     float v;
     if (s2d_C0) {
@@ -148,6 +156,10 @@ __global__ void pack_pw_kernel(const float* __restrict__ w, float* __restrict__ 
     packed[(((size_t)chunk * (Cout / 16) + t) * 64 + kq * 16 + l15) * 4 + j] = v;
 }
 
+__global__ void pack_pw_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin, int s2d_C0) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)Cout * Cin) pack_pw_elem(w, packed, Cout, Cin, s2d_C0, i);
+}
 // init7_pack_weights: (64, Cin, 7, 7) -> [k padded to a multiple of 4][l15][t]
 __global__ void pack_init7_kernel(const float* __restrict__ oihw, float* __restrict__ packed, int Cin, int KP) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,21 +169,27 @@ __global__ void pack_init7_kernel(const float* __restrict__ oihw, float* __restr
 }
 
 // (c_n, Cout, K, K) <- 180-degree rotation + channel-role swap of rows [c_lo, c_lo + c_n) of an OIHW (Cout, Cin, K, K)
-__global__ void rot_transpose_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int K, int c_lo,
-                                     int c_n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)c_n * Cout * K * K) return;
+__device__ __forceinline__ void rot_transpose_elem(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
+                                                   int K, int c_lo, int64_t i) {
     const int kx = (int)(i % K), ky = (int)((i / K) % K), o = (int)((i / (K * K)) % Cout), c = (int)(i / ((int64_t)K * K * Cout));
     out[i] = w[(((size_t)o * Cin + c_lo + c) * K + (K - 1 - ky)) * K + (K - 1 - kx)];
 }
-// Downsample input gradient as a 1x1 convolution Cout -> 4C: out[(sub * C + c)][o] = w[o][c * 4 + sub]
-__global__ void s2d_transpose_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int C) {
+__global__ void rot_transpose_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int K, int c_lo,
+                                     int c_n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)4 * C * Cout) return;
+    if (i < (int64_t)c_n * Cout * K * K) rot_transpose_elem(w, out, Cout, Cin, K, c_lo, i);
+}
+// Downsample input gradient as a 1x1 convolution Cout -> 4C: out[(sub * C + c)][o] = w[o][c * 4 + sub]
+__device__ __forceinline__ void s2d_transpose_elem(const float* __restrict__ w, float* __restrict__ out, int Cout, int C,
+                                                   int64_t i) {
     const int o = (int)(i % Cout), c = (int)((i / Cout) % C), sub = (int)(i / ((int64_t)Cout * C));
     out[i] = w[(size_t)o * 4 * C + c * 4 + sub];
 }
 
+__global__ void s2d_transpose_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)4 * C * Cout) s2d_transpose_elem(w, out, Cout, C, i);
+}
 // all raw parameter copies of a re-pack (biases, gains, mem_kv, time MLP, the concatenated ResnetBlock.mlp rows) in ONE
 // launch: blockIdx.y = table entry, the entry's floats are spread over blockIdx.x
 struct ScatterEntry {
@@ -189,6 +207,43 @@ int launch_scatter_copy(const float* param, const void* table_dev, int n_entries
     const int bx = (int)std::max<long long>(1, std::min<long long>(64, (max_n + 1023) / 1024));
     hipLaunchKernelGGL(scatter_copy_kernel, dim3(bx, n_entries), dim3(256), 0, s, param,
                        static_cast<const ScatterEntry*>(table_dev));
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- grouped re-pack: one launch for a table of (source, destination, layout) jobs.  After an optimiser step the training
+// loop rebuilds every packed buffer its shapes use in two launches (the rotated / transposed sources of the input-gradient
+// layers first, then the packs) instead of one or two small launches in front of each convolution.
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, int n_jobs) {
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackJob j = jobs[lo];
+    const int64_t i = (int64_t)(blockIdx.x - j.first_block) * 256 + threadIdx.x;
+    if (i >= j.n) return;
+    switch (j.kind) {
+        case PJ_ROT: rot_transpose_elem(j.src, j.dst, j.Cout, j.Cin, j.a, j.b, i); break;
+        case PJ_S2D_T: s2d_transpose_elem(j.src, j.dst, j.Cout, j.Cin, i); break;
+        case PJ_WINO: pack_wino_elem(j.src, j.dst, j.Cout, j.Cin, i); break;
+        case PJ_WINO4: pack_wino4_elem(j.src, j.dst, j.Cout, j.Cin, i); break;
+        case PJ_UPWINO: pack_upwino_elem(j.src, j.dst, j.Cout, j.Cin, i); break;
+        case PJ_PW: pack_pw_elem(j.src, j.dst, j.Cout, j.Cin, j.a, i); break;
+        default: j.dst[i] = j.src[i]; break;  // PJ_COPY
+    }
+}
+int pack_jobs_prefix(std::vector<PackJob>& jobs) {
+    int first = 0;
+    for (PackJob& j : jobs) {
+        j.first_block = first;
+        first += (int)((j.n + 255) / 256);
+    }
+    return first;
+}
+int launch_pack_jobs(const PackJob* jobs_dev, int n_jobs, int total_blocks, hipStream_t s) {
+    if (n_jobs <= 0 || total_blocks <= 0) return 0;
+    hipLaunchKernelGGL(pack_jobs_kernel, dim3(total_blocks), dim3(256), 0, s, jobs_dev, n_jobs);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
