@@ -221,16 +221,37 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const PackJob j = jobs[lo];
-    const int64_t i = (int64_t)(blockIdx.x - j.first_block) * 256 + threadIdx.x;
-    if (i >= j.n) return;
+    const int64_t t = (int64_t)(blockIdx.x - j.first_block) * 256 + threadIdx.x;
+    if (t >= j.n) return;
+    // The element functions take (cout, cin) as i = cout * Cin + cin.  Here consecutive threads take the elements that are
+    // neighbours in the PACKED layout, so every plane of a Winograd pack leaves as 256-byte runs (one thread per OIHW
+    // element in OIHW order wrote 32-byte pieces).
     switch (j.kind) {
-        case PJ_ROT: rot_transpose_elem(j.src, j.dst, j.Cout, j.Cin, j.a, j.b, i); break;
-        case PJ_S2D_T: s2d_transpose_elem(j.src, j.dst, j.Cout, j.Cin, i); break;
-        case PJ_WINO: pack_wino_elem(j.src, j.dst, j.Cout, j.Cin, i); break;
-        case PJ_WINO4: pack_wino4_elem(j.src, j.dst, j.Cout, j.Cin, i); break;
-        case PJ_UPWINO: pack_upwino_elem(j.src, j.dst, j.Cout, j.Cin, i); break;
-        case PJ_PW: pack_pw_elem(j.src, j.dst, j.Cout, j.Cin, j.a, i); break;
-        default: j.dst[i] = j.src[i]; break;  // PJ_COPY
+        case PJ_ROT: rot_transpose_elem(j.src, j.dst, j.Cout, j.Cin, j.a, j.b, t); break;
+        case PJ_S2D_T: s2d_transpose_elem(j.src, j.dst, j.Cout, j.Cin, t); break;
+        case PJ_WINO: {  // [chunk of 8][xi][Cout][8]
+            const int cc = (int)(t & 7), co = (int)((t >> 3) % j.Cout), chunk = (int)((t >> 3) / j.Cout);
+            pack_wino_elem(j.src, j.dst, j.Cout, j.Cin, (int64_t)co * j.Cin + chunk * 8 + cc);
+            break;
+        }
+        case PJ_WINO4:
+        case PJ_UPWINO: {  // [chunk][..][cout tile of 64][kq 4][n 16][gq 4][st 2]
+            const int st = (int)(t & 1), gq = (int)((t >> 1) & 3), n = (int)((t >> 3) & 15), kq = (int)((t >> 7) & 3);
+            const int64_t rest = t >> 9;
+            const int tiles = j.Cout / 64, ct = (int)(rest % tiles), chunk = (int)(rest / tiles);
+            const int64_t i = (int64_t)(ct * 64 + 16 * gq + n) * j.Cin + chunk * 8 + 2 * kq + st;
+            if (j.kind == PJ_WINO4) pack_wino4_elem(j.src, j.dst, j.Cout, j.Cin, i);
+            else pack_upwino_elem(j.src, j.dst, j.Cout, j.Cin, i);
+            break;
+        }
+        case PJ_PW: {  // [chunk of 16][cout tile of 16][kq 4][l15 16][j 4]
+            const int jj = (int)(t & 3), l15 = (int)((t >> 2) & 15), kq = (int)((t >> 6) & 3);
+            const int64_t rest = t >> 8;
+            const int tiles = j.Cout / 16, t16 = (int)(rest % tiles), chunk = (int)(rest / tiles);
+            pack_pw_elem(j.src, j.dst, j.Cout, j.Cin, j.a, (int64_t)(t16 * 16 + l15) * j.Cin + chunk * 16 + 4 * kq + jj);
+            break;
+        }
+        default: j.dst[t] = j.src[t]; break;  // PJ_COPY
     }
 }
 int pack_jobs_prefix(std::vector<PackJob>& jobs) {
