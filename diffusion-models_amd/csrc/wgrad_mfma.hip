@@ -39,6 +39,16 @@ template <>
 struct WgradMode<1> { static constexpr int T = 1, TA = 1, S = 1; };
 template <>
 struct WgradMode<2> { static constexpr int T = 4, TA = 4, S = 2; };
+// 3x3 in the Winograd domain, F(3x3, 2x2): per 2x2 tile of dY and its 4x4 input patch
+//     dW = G^T [ sum_tiles (A dY A^T) (.) (B^T X B) ] G      A = [1 0; 1 1; 1 -1; 0 -1]   (4 x 2)
+//     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]          G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
+// (the transposition of the F(2x2, 3x3) algorithm of winograd_mfma.hip: same B^T, A and G change roles): 16 products per
+// tile and (cout, cin) instead of 36.  The K index of the MFMA is a pair of TILES; a lane forms the transformed dY and X
+// values of its tile from 4 + 12 LDS reads with +-1 coefficients; a workgroup owns two of the four transform rows
+// (blockIdx.z), i.e. 8 accumulators; the partial sums stay in the transformed domain (T = 16) and the reduce kernel applies
+// G^T . G.  Even image sizes only.
+template <>
+struct WgradMode<3> { static constexpr int T = 16, TA = 8, S = 1; };
 
 // GROUPED: one launch for a table of layers (the training step runs the weight gradients of ALL its convolutions of one
 // mode together at the end of the backward pass: the chip is filled by independent layers instead of by splitting every
@@ -49,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
     constexpr int T = WgradMode<MODE>::T;    // taps of the partial layout
     constexpr int TA = WgradMode<MODE>::TA;  // taps (accumulators) of this workgroup
     constexpr int S = WgradMode<MODE>::S;
-    int bx = blockIdx.x, split = blockIdx.y, kyb = MODE == 0 ? blockIdx.z : 0;  // tile, pixel split, kernel row
+    int bx = blockIdx.x, split = blockIdx.y, kyb = (MODE == 0 || MODE == 3) ? blockIdx.z : 0;  // tile, pixel split, kernel row / transform-row pair
     WgradParams p = p1;
     if (GROUPED) {
         int lo = 0, hi = n_jobs - 1;
@@ -74,8 +84,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
     const int l31 = lane & 31, k = lane >> 5;
     const int ct = bx % p.n_ct, kt = bx / p.n_ct;
     const int TW = p.TW, R = p.R;
-    const int WW = MODE == 0 ? TW + 2 : S * TW;
-    const int WH = S * R;
+    const int WW = (MODE == 0 || MODE == 3) ? TW + 2 : S * TW;
+    const int WH = MODE == 3 ? R + 2 : S * R;
     const int Hs = MODE == 2 ? 2 * p.Ho : (p.up ? p.Ho / 2 : p.Ho);  // source tensor size
     const int Ws = MODE == 2 ? 2 * p.Wo : (p.up ? p.Wo / 2 : p.Wo);
 
@@ -89,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
     //      coordinates do: the divisions are done once, a block costs additions and bounds checks.  The items of the NEXT
     //      block are loaded into registers before the MFMA loop of the current one (one workgroup hides its own staging).
     constexpr int YI = 4;                                      // dY: 64 px x 16 quads / 256 threads
-    constexpr int XI = MODE == 0 ? 6 : (MODE == 1 ? 4 : 16);   // X window items (upper bound, checked by the launcher)
+    constexpr int XI = MODE == 0 ? 6 : (MODE == 1 ? 4 : (MODE == 2 ? 16 : 9));  // X window items (upper bound, checked by the launcher)
     const int NB = p.NB;
     const int q4 = 4 * (tid & 15);
     int ypos[YI], xpos[XI];  // (image << 24) | (row << 12) | column inside the block / window, -1: no item
@@ -136,8 +146,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
                 const int b = b0 + (xpos[j] >> 24), wy = (xpos[j] >> 12) & 0xFFF, wx = xpos[j] & 0xFFF;
                 int sy, sx;
                 bool ok;
-                if (MODE == 0) {
-                    const int uy = y0 - 1 + kyb + wy, ux = x0 - 1 + wx;
+                if (MODE == 0 || MODE == 3) {
+                    const int uy = y0 - 1 + (MODE == 0 ? kyb : 0) + wy, ux = x0 - 1 + wx;
                     ok = uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo;
                     sy = p.up ? uy >> 1 : uy;
                     sx = p.up ? ux >> 1 : ux;
@@ -167,6 +177,44 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
         // ---- MFMA: K = pixel pairs (2 cp + k) of every row of every image of the block
         const float* ya = sY + wo * 32 + l31;
         const float* xb = sX + wc * 32 + l31;
+        if (MODE == 3) {
+            const int tpr = TW >> 1, tpi = (R >> 1) * tpr, ntiles = NB * tpi;
+            for (int kk = 0; 2 * kk < ntiles; ++kk) {
+                const int tau_raw = 2 * kk + k;
+                const bool live = tau_raw < ntiles;
+                const int tau = live ? tau_raw : 0;  // a dead half step multiplies zeros with tile 0's (finite) values
+                const int nb = tau / tpi, rem = tau - nb * tpi, ty = rem / tpr, tx = rem - ty * tpr;
+                const float* yp = ya + ((nb * R + 2 * ty) * TW + 2 * tx) * WG_SY;
+                float d00 = yp[0], d01 = yp[WG_SY], d10 = yp[TW * WG_SY], d11 = yp[(TW + 1) * WG_SY];
+                if (!live) d00 = d01 = d10 = d11 = 0.f;
+                // rows 2 kyb, 2 kyb + 1 of A dY:  [d0; d0 + d1]  or  [d0 - d1; -d1]
+                const float p0 = kyb ? d00 - d10 : d00, p1 = kyb ? d01 - d11 : d01;
+                const float q0 = kyb ? -d10 : d00 + d10, q1 = kyb ? -d11 : d01 + d11;
+                const float av[8] = {p0, p0 + p1, p0 - p1, -p1, q0, q0 + q1, q0 - q1, -q1};
+                // input rows 0..2 (kyb = 0) or 1..3 (kyb = 1) of the 4x4 patch
+                const float* xp = xb + (size_t)(nb * WH * WW + (2 * ty + kyb) * WW + 2 * tx) * WG_SX;
+                float x0[4], x1[4], x2[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    x0[c] = xp[c * WG_SX];
+                    x1[c] = xp[(WW + c) * WG_SX];
+                    x2[c] = xp[(2 * WW + c) * WG_SX];
+                }
+                float bv[8];
+                {   // B^T rows: 0: r0 - r2, 1: r1 + r2 | 2: r2' - r1' = x1 - x0 here, 3: r1' - r3' = x0 - x2 here
+                    float y0[4], y1[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        y0[c] = kyb ? x1[c] - x0[c] : x0[c] - x2[c];
+                        y1[c] = kyb ? x0[c] - x2[c] : x1[c] + x2[c];
+                    }
+                    bv[0] = y0[0] - y0[2]; bv[1] = y0[1] + y0[2]; bv[2] = y0[2] - y0[1]; bv[3] = y0[1] - y0[3];
+                    bv[4] = y1[0] - y1[2]; bv[5] = y1[1] + y1[2]; bv[6] = y1[2] - y1[1]; bv[7] = y1[1] - y1[3];
+                }
+#pragma unroll
+                for (int t = 0; t < TA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc[t], 0, 0, 0);
+            }
+        } else
         for (int nb = 0; nb < NB; ++nb)
         for (int r = 0; r < R; ++r) {
             for (int cp = 0; cp < TW / 2; ++cp) {
@@ -202,46 +250,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int co = ct * 64 + wo * 32 + 8 * (v >> 2) + 4 * k + (v & 3);
-                if (co < p.Cout) p.partial[(((size_t)split * T + kyb * 3 + t) * p.Cout + co) * p.Cin + ci] = acc[t][v];
+                if (co < p.Cout) p.partial[(((size_t)split * T + kyb * TA + t) * p.Cout + co) * p.Cin + ci] = acc[t][v];
             }
     }
 }
 
 // out[(o * Cin + c) * T + t] (= | +=) sum_split partial[split][t][o][c]: OIHW for 3x3 / 1x1, and the (Cout, 4 C) layout of
-// the Downsample weight (index c*4 + p1*2 + p2) for T = 4.  grid (ceil(oc / 64), T), 256 threads = 64 elements x 4 split
-// lanes: lane q sums the splits q, q + 4, ... (128 consecutive bytes per split row), the four meet in LDS in a fixed order.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int T, int64_t oc,
-                                                           float* __restrict__ out, int accumulate) {
-    __shared__ float red[4][64];
-    const int li = threadIdx.x & 63, q = threadIdx.x >> 6, t = blockIdx.y;
-    const int64_t i = (int64_t)blockIdx.x * 64 + li;
-    float s = 0.f;
-    if (i < oc)
-        for (int sp = q; sp < splits; sp += 4) s += partial[((int64_t)sp * T + t) * oc + i];
-    red[q][li] = s;
-    __syncthreads();
-    if (q == 0 && i < oc) {
-        const float v = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
-        float* o = out + i * T + t;
-        *o = accumulate ? *o + v : v;
-    }
-}
-
-// the same sum for a table of layers: workgroup -> job by binary search over the block prefix.  One workgroup = 64
-// consecutive (cout, cin) pairs x ALL taps, so the OIHW result leaves as one contiguous run of 64 * T floats (a
-// workgroup per tap wrote 4-byte pieces 4 * T bytes apart: 0.5 ms for the 143 MB of gradients).  T >= 4: thread (pair, q)
-// owns the taps q, q + 4, .. and adds their splits in order; T < 4: the four q share the splits of one tap.
-__global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const WgradJob* __restrict__ jobs, int n_jobs) {
-    __shared__ float tile[64 * 9 + 4 * 64];
-    int lo = 0, hi = n_jobs - 1;
-    while (lo < hi) {  // last job whose first_block <= blockIdx.x
-        const int mid = (lo + hi + 1) >> 1;
-        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-    const WgradJob j = jobs[lo];
+// the Downsample weight (index c*4 + p1*2 + p2) for T = 4.  One workgroup = 64 consecutive (cout, cin) pairs x ALL taps, so
+// the result leaves as one contiguous run of 64 * T floats (a workgroup per tap wrote 4-byte pieces 4 * T bytes apart:
+// 0.5 ms for the 143 MB of gradients).  T >= 4: thread (pair, q) owns the taps q, q + 4, .. and adds their splits in order;
+// T < 4: the four q share the splits of one tap.  T = 16: the partial sums are in the Winograd domain (mode 3): the sixteen
+// sums M[i][j] of a pair become its nine taps dW = G^T M G.  Fixed summation order throughout (no atomics).
+__device__ __forceinline__ void wgrad_reduce_block(const WgradJob& j, int lb, float* tile) {
     const int T = j.T;
     const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int64_t i0 = (int64_t)(blockIdx.x - j.first_block) * 64, i = i0 + li;
+    const int64_t i0 = (int64_t)lb * 64, i = i0 + li;
     if (T >= 4) {
         for (int t = q; t < T; t += 4) {
             float s = 0.f;
@@ -250,7 +273,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const WgradJob* 
             tile[li * T + t] = s;
         }
     } else {
-        float* red = tile + 64 * 9;
+        float* red = tile + 64 * 16;
         for (int t = 0; t < T; ++t) {
             float s = 0.f;
             if (i < j.oc)
@@ -262,9 +285,42 @@ __global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const WgradJob* 
         }
     }
     __syncthreads();
-    const int64_t n = min((int64_t)64, j.oc - i0) * T;
+    const int pairs = (int)min((int64_t)64, j.oc - i0);
+    if (T == 16) {
+        float* o = j.out + i0 * 9;
+        for (int k = threadIdx.x; k < pairs * 9; k += 256) {
+            const int pr = k / 9, uv = k - pr * 9, u = uv / 3, v = uv - u * 3;
+            const float* M = tile + pr * 16;
+            // column u of G: (1, 1/2, 1/2, 0), (0, 1/2, -1/2, 0), (0, 1/2, 1/2, 1)
+            float r[4];  // r[jj] = sum_i G[i][u] M[i][jj]
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float m0 = M[jj], m1 = M[4 + jj], m2 = M[8 + jj], m3 = M[12 + jj];
+                r[jj] = u == 0 ? m0 + 0.5f * (m1 + m2) : (u == 1 ? 0.5f * (m1 - m2) : 0.5f * (m1 + m2) + m3);
+            }
+            const float val = v == 0 ? r[0] + 0.5f * (r[1] + r[2]) : (v == 1 ? 0.5f * (r[1] - r[2]) : 0.5f * (r[1] + r[2]) + r[3]);
+            o[k] = j.accumulate ? o[k] + val : val;
+        }
+        return;
+    }
+    const int64_t n = (int64_t)pairs * T;
     float* o = j.out + i0 * T;
     for (int k = threadIdx.x; k < n; k += 256) o[k] = j.accumulate ? o[k] + tile[k] : tile[k];
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradJob j) {
+    __shared__ float tile[64 * 16 + 4 * 64];
+    wgrad_reduce_block(j, blockIdx.x, tile);
+}
+// the same sum for a table of layers: workgroup -> job by binary search over the block prefix
+__global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const WgradJob* __restrict__ jobs, int n_jobs) {
+    __shared__ float tile[64 * 16 + 4 * 64];
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {  // last job whose first_block <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const WgradJob j = jobs[lo];
+    wgrad_reduce_block(j, blockIdx.x - j.first_block, tile);
 }
 int launch_wgrad_reduce_jobs(const WgradJob* jobs_dev, int n_jobs, int total_blocks, hipStream_t s) {
     if (n_jobs <= 0) return 0;
@@ -275,19 +331,22 @@ int launch_wgrad_reduce_jobs(const WgradJob* jobs_dev, int n_jobs, int total_blo
 
 // pixel-block geometry of a (Ho, Wo) output: R rows x TW columns of one image, or NB whole images when an image has at
 // most 32 pixels (4x4 / 2x2 / 1x1 maps of the deep layers: a 16-pixel block would stage as much as it multiplies)
+static int wgrad_items(int mode) { return mode == 0 ? 6 : (mode == 1 ? 4 : (mode == 2 ? 16 : 9)); }
+static int wgrad_zdim(int mode) { return mode == 0 ? 3 : (mode == 3 ? 2 : 1); }
 struct WgradGeo {
     int TW, R, NB, tiles_x, tiles_y, n_blocks;
 };
 static WgradGeo wgrad_geo(int B, int Ho, int Wo, int mode) {
     WgradGeo g{};
-    g.TW = std::min((Wo + 1) & ~1, 64);
+    g.TW = std::min((Wo + 1) & ~1, mode == 3 ? 32 : 64);
     g.R = std::max(1, std::min(64 / g.TW, Ho));
+    if (mode == 3) g.R = std::max(2, g.R & ~1);  // whole 2x2 tiles
     g.tiles_x = (Wo + g.TW - 1) / g.TW;
     g.tiles_y = (Ho + g.R - 1) / g.R;
     g.NB = 1;
     if (g.tiles_x == 1 && g.tiles_y == 1) {
-        const int win = mode == 0 ? g.R * (g.TW + 2) : (mode == 2 ? 4 : 1) * g.R * g.TW;
-        const int items = 16 * (mode == 0 ? 6 : (mode == 1 ? 4 : 16));
+        const int win = mode == 0 ? g.R * (g.TW + 2) : (mode == 3 ? (g.R + 2) * (g.TW + 2) : (mode == 2 ? 4 : 1) * g.R * g.TW);
+        const int items = 16 * wgrad_items(mode);
         g.NB = std::max(1, std::min(std::min(64 / (g.R * g.TW), items / win), B));
     }
     g.n_blocks = ((B + g.NB - 1) / g.NB) * g.tiles_x * g.tiles_y;
@@ -296,7 +355,7 @@ static WgradGeo wgrad_geo(int B, int Ho, int Wo, int mode) {
 
 static size_t wgrad_ws_floats_mode(int B, int Ho, int Wo, int Cout, int Cin, int T, int mode, int* splits_out) {
     const WgradGeo g = wgrad_geo(B, Ho, Wo, mode);
-    const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64) * (mode == 0 ? 3 : 1);
+    const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64) * wgrad_zdim(mode);
     // A workgroup hides its own staging (the next block is loaded during the MFMAs), so the split count only has to fill
     // the chip; every split writes a full [T][Cout][Cin] partial tile that the reduce kernel reads back.
     static const int min_bps = env_int("DM_WGRAD_MIN_BLOCKS", 2);
@@ -310,20 +369,21 @@ static size_t wgrad_ws_floats_mode(int B, int Ho, int Wo, int Cout, int Cin, int
     return (size_t)splits * T * Cout * Cin;
 }
 size_t wgrad_ws_floats(int B, int Ho, int Wo, int Cout, int Cin, int T, int* splits_out) {
-    return wgrad_ws_floats_mode(B, Ho, Wo, Cout, Cin, T, T == 9 ? 0 : (T == 1 ? 1 : 2), splits_out);
+    return wgrad_ws_floats_mode(B, Ho, Wo, Cout, Cin, T, T == 9 ? 0 : (T == 1 ? 1 : (T == 4 ? 2 : 3)), splits_out);
 }
 
-static int wgrad_taps(int mode) { return mode == 0 ? 9 : (mode == 1 ? 1 : 4); }
+static int wgrad_taps(int mode) { return mode == 0 ? 9 : (mode == 1 ? 1 : (mode == 2 ? 4 : 16)); }
 static size_t wgrad_lds_bytes(const WgradParams& p, int mode) {
-    const int WW = mode == 0 ? p.TW + 2 : (mode == 2 ? 2 * p.TW : p.TW);
-    const int WH = mode == 2 ? 2 * p.R : p.R;
+    const int WW = (mode == 0 || mode == 3) ? p.TW + 2 : (mode == 2 ? 2 * p.TW : p.TW);
+    const int WH = mode == 3 ? p.R + 2 : (mode == 2 ? 2 * p.R : p.R);
     return (size_t)(64 * WG_SY + p.NB * WH * WW * WG_SX) * sizeof(float);
 }
 // geometry of one layer's weight gradient for `splits` pixel splits (ws: splits * T * Cout * Cin floats)
 static int wgrad_fill(WgradParams& p, const float* in0, int C0, const float* in1, int C1, const float* dy, int Cout, int B, int Ho,
                       int Wo, int mode, int up, float* ws, int splits) {
     DM_REQUIRE(C0 % 4 == 0 && C1 % 4 == 0 && Cout % 4 == 0 && C0 > 0, "wgrad: channel counts must be multiples of 4");
-    DM_REQUIRE(mode >= 0 && mode <= 2 && (!up || (mode == 0 && Ho % 2 == 0 && Wo % 2 == 0)), "wgrad: mode");
+    DM_REQUIRE(mode >= 0 && mode <= 3 && (!up || ((mode == 0 || mode == 3) && Ho % 2 == 0 && Wo % 2 == 0)), "wgrad: mode");
+    DM_REQUIRE(mode != 3 || (Ho % 2 == 0 && Wo % 2 == 0), "wgrad: the Winograd form needs even image sizes");
     DM_REQUIRE((size_t)B * Ho * Wo * (size_t)std::max(Cout, C0 + C1) * (mode == 2 ? 4 : 1) < (1ull << 40), "wgrad: size");
     p = WgradParams{};
     p.in0 = in0; p.in1 = C1 ? in1 : in0; p.dy = dy; p.partial = ws;
@@ -338,11 +398,10 @@ static int wgrad_fill(WgradParams& p, const float* in0, int C0, const float* in1
     p.n_kt = (p.Cin + 63) / 64;
     p.blocks_per_split = (p.n_blocks + splits - 1) / splits;
     p.n_splits = splits;
-    const int WW = mode == 0 ? p.TW + 2 : (mode == 2 ? 2 * p.TW : p.TW);
-    const int WH = mode == 2 ? 2 * p.R : p.R;
+    const int WW = (mode == 0 || mode == 3) ? p.TW + 2 : (mode == 2 ? 2 * p.TW : p.TW);
+    const int WH = mode == 3 ? p.R + 2 : (mode == 2 ? 2 * p.R : p.R);
     DM_REQUIRE(wgrad_lds_bytes(p, mode) <= 160 * 1024, "wgrad: LDS");
-    DM_REQUIRE(p.NB * p.R * p.TW <= 64 && p.NB * WH * WW <= 16 * (mode == 0 ? 6 : (mode == 1 ? 4 : 16)) && p.TW < 4096 &&
-                   WH < 4096,
+    DM_REQUIRE(p.NB * p.R * p.TW <= 64 && p.NB * WH * WW <= 16 * wgrad_items(mode) && p.TW < 4096 && WH < 4096,
                "wgrad: block larger than the staging items");
     return 0;
 }
@@ -356,15 +415,18 @@ int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float
     WgradParams p;
     if (wgrad_fill(p, in0, C0, in1, C1, dy, Cout, B, Ho, Wo, mode, up, ws, splits)) return 1;
     const size_t lds = wgrad_lds_bytes(p, mode);
-    const dim3 grid(p.n_ct * p.n_kt, splits, mode == 0 ? 3 : 1);
+    const dim3 grid(p.n_ct * p.n_kt, splits, wgrad_zdim(mode));
     const bool timed = prof::enabled();
     if (timed && prof::begin("wgrad_mfma_kernel", 2.0 * T * p.Cin * Cout * (double)B * Ho * Wo,
                              4.0 * ((double)B * Ho * Wo * (p.Cin * (mode == 2 ? 4 : 1) + Cout) + (double)T * p.Cin * Cout), s))
         return 1;
-    static LdsOptIn f0, f1, f2;
+    static LdsOptIn f0, f1, f2, f3;
     if (mode == 0) {
         if (lds_opt_in(f0, reinterpret_cast<const void*>(wgrad_mfma_kernel<0, false>), 1)) return 1;
         hipLaunchKernelGGL((wgrad_mfma_kernel<0, false>), grid, dim3(256), lds, s, p, nullptr, 1);
+    } else if (mode == 3) {
+        if (lds_opt_in(f3, reinterpret_cast<const void*>(wgrad_mfma_kernel<3, false>), 1)) return 1;
+        hipLaunchKernelGGL((wgrad_mfma_kernel<3, false>), grid, dim3(256), lds, s, p, nullptr, 1);
     } else if (mode == 1) {
         if (lds_opt_in(f1, reinterpret_cast<const void*>(wgrad_mfma_kernel<1, false>), 1)) return 1;
         hipLaunchKernelGGL((wgrad_mfma_kernel<1, false>), grid, dim3(256), lds, s, p, nullptr, 1);
@@ -379,8 +441,8 @@ int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float
         *defer = WgradJob{ws, dw, oc, splits, T, accumulate, 0};
         return 0;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((oc + 63) / 64), T), dim3(256), 0, s, ws, splits, T, oc, dw,
-                       accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((oc + 63) / 64)), dim3(256), 0, s,
+                       WgradJob{ws, dw, oc, splits, T, accumulate, 0});
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -396,7 +458,7 @@ void wgrad_group_plan(const std::vector<WgradDesc>& descs, int mode, std::vector
     for (size_t j = 0; j < descs.size(); ++j) {
         const WgradDesc& d = descs[j];
         geo[j] = wgrad_geo(d.B, d.Ho, d.Wo, mode);
-        const int tiles = ((d.Cout + 63) / 64) * ((d.C0 + d.C1 + 63) / 64) * (mode == 0 ? 3 : 1);
+        const int tiles = ((d.Cout + 63) / 64) * ((d.C0 + d.C1 + 63) / 64) * wgrad_zdim(mode);
         units += (long long)tiles * geo[j].n_blocks;
     }
     const int bps = (int)std::max<long long>(1, (units + target - 1) / target);
@@ -420,7 +482,7 @@ int wgrad_group_fill(const std::vector<WgradDesc>& descs, int mode, const std::v
         const WgradDesc& d = descs[j];
         if (wgrad_fill(table[j], d.in0, d.C0, d.in1, d.C1, d.dy, d.Cout, d.B, d.Ho, d.Wo, mode, d.up, ws[j], splits[j])) return 1;
         table[j].first_wg = first;
-        first += table[j].n_ct * table[j].n_kt * splits[j] * (mode == 0 ? 3 : 1);
+        first += table[j].n_ct * table[j].n_kt * splits[j] * wgrad_zdim(mode);
         lds = std::max(lds, wgrad_lds_bytes(table[j], mode));
         jobs.push_back(WgradJob{ws[j], d.dw, (long long)d.Cout * (d.C0 + d.C1), splits[j], T, d.accumulate, 0});
     }
@@ -430,11 +492,14 @@ int wgrad_group_fill(const std::vector<WgradDesc>& descs, int mode, const std::v
 }
 int launch_wgrad_group(const WgradParams* table_dev, int n_jobs, int total_wgs, size_t lds_bytes, int mode, hipStream_t s) {
     if (n_jobs <= 0) return 0;
-    static LdsOptIn f0, f1, f2;
+    static LdsOptIn f0, f1, f2, f3;
     const WgradParams none{};
     if (mode == 0) {
         if (lds_opt_in(f0, reinterpret_cast<const void*>(wgrad_mfma_kernel<0, true>), 1)) return 1;
         hipLaunchKernelGGL((wgrad_mfma_kernel<0, true>), dim3(total_wgs), dim3(256), lds_bytes, s, none, table_dev, n_jobs);
+    } else if (mode == 3) {
+        if (lds_opt_in(f3, reinterpret_cast<const void*>(wgrad_mfma_kernel<3, true>), 1)) return 1;
+        hipLaunchKernelGGL((wgrad_mfma_kernel<3, true>), dim3(total_wgs), dim3(256), lds_bytes, s, none, table_dev, n_jobs);
     } else if (mode == 1) {
         if (lds_opt_in(f1, reinterpret_cast<const void*>(wgrad_mfma_kernel<1, true>), 1)) return 1;
         hipLaunchKernelGGL((wgrad_mfma_kernel<1, true>), dim3(total_wgs), dim3(256), lds_bytes, s, none, table_dev, n_jobs);
@@ -587,8 +652,8 @@ int launch_wgrad_naive(const float* x, int x_nchw, const float* dy, int dy_nchw,
         *defer = WgradJob{ws, dw, (long long)n_out, splits, 1, accumulate, 0};
         return 0;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 63) / 64, 1), dim3(256), 0, s, ws, splits, 1, (int64_t)n_out, dw,
-                       accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 63) / 64), dim3(256), 0, s,
+                       WgradJob{ws, dw, (long long)n_out, splits, 1, accumulate, 0});
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
