@@ -75,8 +75,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
         kyb = rest / p.n_splits;
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sY = smem;                // [64 px][64 couts]
-    float* sX = smem + 64 * WG_SY;   // [WH * WW px][64 cins]
+    int2* tile_off = reinterpret_cast<int2*>(smem);  // [32] (mode 3): float offsets of the tiles of a pixel block
+    float* sY = smem + 64;           // [64 px][64 couts]
+    float* sX = sY + 64 * WG_SY;     // [WH * WW px][64 cins]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,6 +90,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
     const int Hs = MODE == 2 ? 2 * p.Ho : (p.up ? p.Ho / 2 : p.Ho);  // source tensor size
     const int Ws = MODE == 2 ? 2 * p.Wo : (p.up ? p.Wo / 2 : p.Wo);
 
+    if (MODE == 3) {  // inside the staged dY tile / X window; the first __syncthreads() of the block loop orders this
+        const int tpr = TW >> 1, tpi = (R >> 1) * tpr;
+        if (tid < 32) {
+            const int nb = tid / tpi, rem = tid - nb * tpi, ty = rem / tpr, tx = rem - ty * tpr;
+            tile_off[tid] = make_int2(((nb * R + 2 * ty) * TW + 2 * tx) * WG_SY,
+                                      (nb * WH * WW + (2 * ty + kyb) * WW + 2 * tx) * WG_SX);
+        }
+    }
     f32x16 acc[TA];
 #pragma unroll
     for (int t = 0; t < TA; ++t)
@@ -178,13 +187,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
         const float* ya = sY + wo * 32 + l31;
         const float* xb = sX + wc * 32 + l31;
         if (MODE == 3) {
-            const int tpr = TW >> 1, tpi = (R >> 1) * tpr, ntiles = NB * tpi;
+            // (tried: the row pair as a compile-time constant through two launches -- no per-value selects, but every input
+            // staged by two launches: 8.9 against 8.8 ms per loss+backward; reading the next pair of tiles ahead of the
+            // MFMAs needs 16 registers more than the 256 a two-per-CU workgroup has: 104 spills)
+            const int ntiles = NB * (R >> 1) * (TW >> 1);
             for (int kk = 0; 2 * kk < ntiles; ++kk) {
                 const int tau_raw = 2 * kk + k;
                 const bool live = tau_raw < ntiles;
-                const int tau = live ? tau_raw : 0;  // a dead half step multiplies zeros with tile 0's (finite) values
-                const int nb = tau / tpi, rem = tau - nb * tpi, ty = rem / tpr, tx = rem - ty * tpr;
-                const float* yp = ya + ((nb * R + 2 * ty) * TW + 2 * tx) * WG_SY;
+                const int2 off = tile_off[live ? tau_raw : 0];  // a dead half step multiplies zeros with tile 0's (finite) values
+                const float* yp = ya + off.x;
                 float d00 = yp[0], d01 = yp[WG_SY], d10 = yp[TW * WG_SY], d11 = yp[(TW + 1) * WG_SY];
                 if (!live) d00 = d01 = d10 = d11 = 0.f;
                 // rows 2 kyb, 2 kyb + 1 of A dY:  [d0; d0 + d1]  or  [d0 - d1; -d1]
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
                 const float q0 = kyb ? -d10 : d00 + d10, q1 = kyb ? -d11 : d01 + d11;
                 const float av[8] = {p0, p0 + p1, p0 - p1, -p1, q0, q0 + q1, q0 - q1, -q1};
                 // input rows 0..2 (kyb = 0) or 1..3 (kyb = 1) of the 4x4 patch
-                const float* xp = xb + (size_t)(nb * WH * WW + (2 * ty + kyb) * WW + 2 * tx) * WG_SX;
+                const float* xp = xb + off.y;
                 float x0[4], x1[4], x2[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -376,7 +387,7 @@ static int wgrad_taps(int mode) { return mode == 0 ? 9 : (mode == 1 ? 1 : (mode 
 static size_t wgrad_lds_bytes(const WgradParams& p, int mode) {
     const int WW = (mode == 0 || mode == 3) ? p.TW + 2 : (mode == 2 ? 2 * p.TW : p.TW);
     const int WH = mode == 3 ? p.R + 2 : (mode == 2 ? 2 * p.R : p.R);
-    return (size_t)(64 * WG_SY + p.NB * WH * WW * WG_SX) * sizeof(float);
+    return (size_t)(64 + 64 * WG_SY + p.NB * WH * WW * WG_SX) * sizeof(float);
 }
 // geometry of one layer's weight gradient for `splits` pixel splits (ws: splits * T * Cout * Cin floats)
 static int wgrad_fill(WgradParams& p, const float* in0, int C0, const float* in1, int C1, const float* dy, int Cout, int B, int Ho,
