@@ -53,3 +53,28 @@ def test_model_goldens_with_the_forked_step():
 def test_model_goldens_without_any_winograd():
     """... and with every Winograd-family kernel off (the direct implicit-GEMM kernel takes all 3x3 layers)."""
     _run_models(dict(DM_NO_WINOGRAD="1"))
+
+
+TRAIN_CASES = ("test_loss_and_all_gradients_vs_reference_autograd and (small_d32 or mid_d64 or full_b8) or "
+               "test_training_steps_vs_torch_adam or test_checkpoint_round_trip or test_text_conditional_training_step")
+
+
+def _run_training(env_extra):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_train.py"), "-q", "-x", "-m",
+                        "gpu", "-k", TRAIN_CASES, "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
+def test_training_goldens_with_one_launch_per_layer():
+    """The gradient goldens of the reference's autograd, the three-iteration Adam loop and the checkpoint round trip with the
+    per-layer forms of everything the training step batches by default: one weight-gradient launch and one split-K sum per
+    layer (no grouped launch, no deferred reductions), the direct 3x3 weight gradient instead of the Winograd-domain one,
+    lazy instead of grouped re-packing."""
+    _run_training(dict(DM_WGRAD_NO_DEFER="1", DM_WGRAD_NO_WINO="1", DM_NO_BATCH_REPACK="1"))
+
+
+def test_training_goldens_grouped_without_winograd():
+    """... and the grouped launches with the direct (row-split) 3x3 weight gradient."""
+    _run_training(dict(DM_WGRAD_NO_WINO="1"))
