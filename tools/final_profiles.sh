@@ -16,3 +16,6 @@ echo "== b8 stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_b8 -o s -- python3 tools/step_time.py --batch 8 --size 64 > gpurun_out/${tag}_b8.log 2>&1
 rm -f gpurun_out/${tag}_b8/*kernel_trace.csv; tail -1 gpurun_out/${tag}_b8.log
 echo "== vae"; python3 tools/vae_time.py > gpurun_out/${tag}_vae.txt 2>&1; tail -3 gpurun_out/${tag}_vae.txt
+echo "== training step stats"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_train -o s -- python3 tools/train_time.py --batch 64 --steps 10 > gpurun_out/${tag}_train.log 2>&1
+rm -f gpurun_out/${tag}_train/*kernel_trace.csv; python3 tools/train_time.py --batch 64 --steps 10 > gpurun_out/${tag}_train_time.txt 2>&1; tail -2 gpurun_out/${tag}_train_time.txt
