@@ -138,3 +138,25 @@ def test_lds_opt_in_is_tracked_per_device():
         assert "static bool attr" not in text, path
         if "hipFuncSetAttribute" in text:
             assert os.path.basename(path) == "dm_common.h", path  # only lds_opt_in() calls it
+
+
+def test_parameter_order_is_the_reference_optimizers():
+    """``torch.optim.Adam(model.parameters())`` numbers its per-parameter state by ``parameters()`` order; the checkpoints
+    of ``train.save_checkpoint`` ('opt') rely on ``unet_param_spec`` listing the parameters in exactly that order
+    (fixture: tests/golden/make_golden_param_order.py, names from the reference's modules)."""
+    import json
+    import os
+
+    from diffusion_models_amd.spec import UnetConfig, unet_param_spec
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "param_order.json")) as f:
+        want = json.load(f)
+    cases = {
+        "unet_d64": UnetConfig(),
+        "unet_d32_selfcond": UnetConfig(dim=32, dim_mults=(1, 2), channels=3, self_condition=True),
+        "unet_text_cross": UnetConfig(text_condition=True, use_cross_attn=True),
+        "unet_text_concat": UnetConfig(text_condition=True),
+    }
+    for key, cfg in cases.items():
+        assert [n for n, _ in unet_param_spec(cfg)] == want[key], key
+
