@@ -266,6 +266,136 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
     }
 }
 
+// ---- mode 3, the kernel that runs it: the TRANSFORMED tiles are staged.  Thread (tile, channel quad) of the workgroup
+// loads its own 3x4-pixel piece of the 4x4 input patch and its 2x2 dY tile straight from global memory (prefetched one pixel
+// block ahead, as above), applies the two +-1 transforms once, and stores the eight values of its transform-row pair as
+// [frequency][tile][channel] in LDS (64 KB for both operands: two workgroups per CU).  The MFMA loop is then one LDS read per
+// operand and nothing else -- the version that transformed inside the loop (4 + 12 raw reads and ~40 VALU operations per
+// 8 MFMAs, every wave redoing its neighbours' transforms) ran at 0.37 of the peak by executed products.
+template <bool GROUPED>
+__global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WgradParams p1, const WgradParams* __restrict__ table,
+                                                            int n_jobs) {
+    constexpr int T = 16, TA = 8;
+    int bx = blockIdx.x, split = blockIdx.y, zi = blockIdx.z;  // tile, pixel split, transform-row pair
+    WgradParams p = p1;
+    if (GROUPED) {
+        int lo = 0, hi = n_jobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (table[mid].first_wg <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        p = table[lo];
+        const int lb = blockIdx.x - p.first_wg, tiles = p.n_ct * p.n_kt;
+        bx = lb % tiles;
+        const int rest = lb / tiles;
+        split = rest % p.n_splits;
+        zi = rest / p.n_splits;
+    }
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sYt = smem;                  // [8 freq][16 tiles][64 couts]
+    float* sXt = smem + TA * 16 * 64;   // [8 freq][16 tiles][64 cins]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, k = lane >> 5;
+    const int ct = bx % p.n_ct, kt = bx / p.n_ct;
+    const int TW = p.TW, R = p.R, NB = p.NB;
+    const int Hs = p.up ? p.Ho / 2 : p.Ho, Ws = p.up ? p.Wo / 2 : p.Wo;  // source tensor size
+
+    f32x16 acc[TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    // this thread's staging item: tile (image nb, tile row ty, tile column tx of the pixel block) x channel quad
+    const int tile = tid >> 4, q4 = 4 * (tid & 15);
+    const int tpr = TW >> 1, tpi = (R >> 1) * tpr, ntiles = NB * tpi;
+    const bool tile_ok = tile < ntiles;
+    const int nb = tile / tpi, trem = tile - nb * tpi, ty = trem / tpr, tx = trem - ty * tpr;
+    const int co_s = ct * 64 + q4, ci_s = kt * 64 + q4;
+    const bool co_ok = co_s < p.Cout, ci_ok = ci_s < p.Cin;
+    const bool src1 = ci_s >= p.C0;
+    const float* xsrc = src1 ? p.in1 + (ci_s - p.C0) : p.in0 + ci_s;
+    const int xC = src1 ? p.C1 : p.C0;
+    const int per_img = p.tiles_x * p.tiles_y;
+    const f32x4 zero4 = make_f32x4(0.f, 0.f, 0.f, 0.f);
+
+    f32x4 yr[4], xr[12];  // dY tile (row-major 2x2), input patch rows zi .. zi + 2 (row-major 3x4)
+    auto load_block = [&](int blk) {
+        const int bg = blk / per_img, rem = blk - bg * per_img;
+        const int b = bg * NB + nb;
+        const int y0 = (rem / p.tiles_x) * R + 2 * ty, x0 = (rem % p.tiles_x) * TW + 2 * tx;
+        const bool img_ok = tile_ok && b < p.B;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = y0 + (j >> 1), x = x0 + (j & 1);
+            yr[j] = (img_ok && co_ok && y < p.Ho && x < p.Wo)
+                        ? *reinterpret_cast<const f32x4*>(p.dy + ((size_t)(b * p.Ho + y) * p.Wo + x) * p.Cout + co_s)
+                        : zero4;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int uy = y0 - 1 + zi + a, ux = x0 - 1 + c;
+                const bool ok = img_ok && ci_ok && uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo;
+                const int sy = p.up ? uy >> 1 : uy, sx = p.up ? ux >> 1 : ux;
+                xr[a * 4 + c] = ok ? *reinterpret_cast<const f32x4*>(xsrc + ((size_t)(b * Hs + sy) * Ws + sx) * xC) : zero4;
+            }
+    };
+
+    const int blk0 = split * p.blocks_per_split;
+    const int blk1 = min(blk0 + p.blocks_per_split, p.n_blocks);
+    if (blk0 < blk1) load_block(blk0);
+    for (int blk = blk0; blk < blk1; ++blk) {
+        __syncthreads();  // the previous block's MFMA loop is done with the tiles
+        {
+            // rows 2 zi, 2 zi + 1 of A dY:  [d0; d0 + d1]  or  [d0 - d1; -d1];  then the same on the columns
+            const f32x4 p0 = zi ? yr[0] - yr[2] : yr[0], p1 = zi ? yr[1] - yr[3] : yr[1];
+            const f32x4 q0 = zi ? zero4 - yr[2] : yr[0] + yr[2], q1 = zi ? zero4 - yr[3] : yr[1] + yr[3];
+            const f32x4 av[8] = {p0, p0 + p1, p0 - p1, zero4 - p1, q0, q0 + q1, q0 - q1, zero4 - q1};
+            float* dst = sYt + tile * 64 + q4;
+#pragma unroll
+            for (int f = 0; f < TA; ++f) *reinterpret_cast<f32x4*>(dst + f * 16 * 64) = av[f];
+            // B^T rows: 0: r0 - r2, 1: r1 + r2 | 2: r2' - r1' = x1 - x0 here, 3: r1' - r3' = x0 - x2 here; then the columns
+            f32x4 y0v[4], y1v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                y0v[c] = zi ? xr[4 + c] - xr[c] : xr[c] - xr[8 + c];
+                y1v[c] = zi ? xr[c] - xr[8 + c] : xr[4 + c] + xr[8 + c];
+            }
+            const f32x4 bv[8] = {y0v[0] - y0v[2], y0v[1] + y0v[2], y0v[2] - y0v[1], y0v[1] - y0v[3],
+                                 y1v[0] - y1v[2], y1v[1] + y1v[2], y1v[2] - y1v[1], y1v[1] - y1v[3]};
+            float* dsx = sXt + tile * 64 + q4;
+#pragma unroll
+            for (int f = 0; f < TA; ++f) *reinterpret_cast<f32x4*>(dsx + f * 16 * 64) = bv[f];
+        }
+        __syncthreads();
+        if (blk + 1 < blk1) load_block(blk + 1);  // in flight during the MFMAs below
+        const float* ya = sYt + wo * 32 + l31;
+        const float* xb = sXt + wc * 32 + l31;
+        for (int kk = 0; 2 * kk < ntiles; ++kk) {
+            const int t2 = (2 * kk + k) * 64;  // slots of tiles >= ntiles hold zeros
+#pragma unroll
+            for (int f = 0; f < TA; ++f)
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[f * 16 * 64 + t2], xb[f * 16 * 64 + t2], acc[f], 0, 0, 0);
+        }
+    }
+    // ---- partial tile: D[i][j], j = lane % 32 (cin), i = 8 (v / 4) + 4 (lane / 32) + v % 4 (cout)
+    const int ci = kt * 64 + wc * 32 + l31;
+    if (ci < p.Cin) {
+#pragma unroll
+        for (int t = 0; t < TA; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int co = ct * 64 + wo * 32 + 8 * (v >> 2) + 4 * k + (v & 3);
+                if (co < p.Cout) p.partial[(((size_t)split * T + zi * TA + t) * p.Cout + co) * p.Cin + ci] = acc[t][v];
+            }
+    }
+}
+
 // out[(o * Cin + c) * T + t] (= | +=) sum_split partial[split][t][o][c]: OIHW for 3x3 / 1x1, and the (Cout, 4 C) layout of
 // the Downsample weight (index c*4 + p1*2 + p2) for T = 4.  One workgroup = 64 consecutive (cout, cin) pairs x ALL taps, so
 // the result leaves as one contiguous run of 64 * T floats (a workgroup per tap wrote 4-byte pieces 4 * T bytes apart:
@@ -356,9 +486,9 @@ static WgradGeo wgrad_geo(int B, int Ho, int Wo, int mode) {
     g.tiles_y = (Ho + g.R - 1) / g.R;
     g.NB = 1;
     if (g.tiles_x == 1 && g.tiles_y == 1) {
-        const int win = mode == 0 ? g.R * (g.TW + 2) : (mode == 3 ? (g.R + 2) * (g.TW + 2) : (mode == 2 ? 4 : 1) * g.R * g.TW);
+        const int win = mode == 0 ? g.R * (g.TW + 2) : (mode == 2 ? 4 : 1) * g.R * g.TW;
         const int items = 16 * wgrad_items(mode);
-        g.NB = std::max(1, std::min(std::min(64 / (g.R * g.TW), items / win), B));
+        g.NB = std::max(1, std::min(std::min(64 / (g.R * g.TW), mode == 3 ? 64 : items / win), B));
     }
     g.n_blocks = ((B + g.NB - 1) / g.NB) * g.tiles_x * g.tiles_y;
     return g;
@@ -385,8 +515,9 @@ size_t wgrad_ws_floats(int B, int Ho, int Wo, int Cout, int Cin, int T, int* spl
 
 static int wgrad_taps(int mode) { return mode == 0 ? 9 : (mode == 1 ? 1 : (mode == 2 ? 4 : 16)); }
 static size_t wgrad_lds_bytes(const WgradParams& p, int mode) {
-    const int WW = (mode == 0 || mode == 3) ? p.TW + 2 : (mode == 2 ? 2 * p.TW : p.TW);
-    const int WH = mode == 3 ? p.R + 2 : (mode == 2 ? 2 * p.R : p.R);
+    if (mode == 3) return (size_t)2 * 8 * 16 * 64 * sizeof(float);  // transformed dY and X tiles
+    const int WW = mode == 0 ? p.TW + 2 : (mode == 2 ? 2 * p.TW : p.TW);
+    const int WH = mode == 2 ? 2 * p.R : p.R;
     return (size_t)(64 + 64 * WG_SY + p.NB * WH * WW * WG_SX) * sizeof(float);
 }
 // geometry of one layer's weight gradient for `splits` pixel splits (ws: splits * T * Cout * Cin floats)
@@ -409,11 +540,12 @@ static int wgrad_fill(WgradParams& p, const float* in0, int C0, const float* in1
     p.n_kt = (p.Cin + 63) / 64;
     p.blocks_per_split = (p.n_blocks + splits - 1) / splits;
     p.n_splits = splits;
-    const int WW = (mode == 0 || mode == 3) ? p.TW + 2 : (mode == 2 ? 2 * p.TW : p.TW);
-    const int WH = mode == 3 ? p.R + 2 : (mode == 2 ? 2 * p.R : p.R);
+    const int WW = mode == 0 ? p.TW + 2 : (mode == 2 ? 2 * p.TW : p.TW);
+    const int WH = mode == 2 ? 2 * p.R : p.R;
     DM_REQUIRE(wgrad_lds_bytes(p, mode) <= 160 * 1024, "wgrad: LDS");
-    DM_REQUIRE(p.NB * p.R * p.TW <= 64 && p.NB * WH * WW <= 16 * wgrad_items(mode) && p.TW < 4096 && WH < 4096,
+    DM_REQUIRE(p.NB * p.R * p.TW <= 64 && (mode == 3 || p.NB * WH * WW <= 16 * wgrad_items(mode)) && p.TW < 4096 && WH < 4096,
                "wgrad: block larger than the staging items");
+    DM_REQUIRE(mode != 3 || (p.R % 2 == 0 && p.TW % 2 == 0), "wgrad: the Winograd form works on whole 2x2 tiles");
     return 0;
 }
 
@@ -436,8 +568,8 @@ int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float
         if (lds_opt_in(f0, reinterpret_cast<const void*>(wgrad_mfma_kernel<0, false>), 1)) return 1;
         hipLaunchKernelGGL((wgrad_mfma_kernel<0, false>), grid, dim3(256), lds, s, p, nullptr, 1);
     } else if (mode == 3) {
-        if (lds_opt_in(f3, reinterpret_cast<const void*>(wgrad_mfma_kernel<3, false>), 1)) return 1;
-        hipLaunchKernelGGL((wgrad_mfma_kernel<3, false>), grid, dim3(256), lds, s, p, nullptr, 1);
+        if (lds_opt_in(f3, reinterpret_cast<const void*>(wgrad_wino_kernel<false>), 1)) return 1;
+        hipLaunchKernelGGL((wgrad_wino_kernel<false>), grid, dim3(256), lds, s, p, nullptr, 1);
     } else if (mode == 1) {
         if (lds_opt_in(f1, reinterpret_cast<const void*>(wgrad_mfma_kernel<1, false>), 1)) return 1;
         hipLaunchKernelGGL((wgrad_mfma_kernel<1, false>), grid, dim3(256), lds, s, p, nullptr, 1);
@@ -509,8 +641,8 @@ int launch_wgrad_group(const WgradParams* table_dev, int n_jobs, int total_wgs, 
         if (lds_opt_in(f0, reinterpret_cast<const void*>(wgrad_mfma_kernel<0, true>), 1)) return 1;
         hipLaunchKernelGGL((wgrad_mfma_kernel<0, true>), dim3(total_wgs), dim3(256), lds_bytes, s, none, table_dev, n_jobs);
     } else if (mode == 3) {
-        if (lds_opt_in(f3, reinterpret_cast<const void*>(wgrad_mfma_kernel<3, true>), 1)) return 1;
-        hipLaunchKernelGGL((wgrad_mfma_kernel<3, true>), dim3(total_wgs), dim3(256), lds_bytes, s, none, table_dev, n_jobs);
+        if (lds_opt_in(f3, reinterpret_cast<const void*>(wgrad_wino_kernel<true>), 1)) return 1;
+        hipLaunchKernelGGL((wgrad_wino_kernel<true>), dim3(total_wgs), dim3(256), lds_bytes, s, none, table_dev, n_jobs);
     } else if (mode == 1) {
         if (lds_opt_in(f1, reinterpret_cast<const void*>(wgrad_mfma_kernel<1, true>), 1)) return 1;
         hipLaunchKernelGGL((wgrad_mfma_kernel<1, true>), dim3(total_wgs), dim3(256), lds_bytes, s, none, table_dev, n_jobs);
