@@ -39,16 +39,6 @@ template <>
 struct WgradMode<1> { static constexpr int T = 1, TA = 1, S = 1; };
 template <>
 struct WgradMode<2> { static constexpr int T = 4, TA = 4, S = 2; };
-// 3x3 in the Winograd domain, F(3x3, 2x2): per 2x2 tile of dY and its 4x4 input patch
-//     dW = G^T [ sum_tiles (A dY A^T) (.) (B^T X B) ] G      A = [1 0; 1 1; 1 -1; 0 -1]   (4 x 2)
-//     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]          G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
-// (the transposition of the F(2x2, 3x3) algorithm of winograd_mfma.hip: same B^T, A and G change roles): 16 products per
-// tile and (cout, cin) instead of 36.  The K index of the MFMA is a pair of TILES; a lane forms the transformed dY and X
-// values of its tile from 4 + 12 LDS reads with +-1 coefficients; a workgroup owns two of the four transform rows
-// (blockIdx.z), i.e. 8 accumulators; the partial sums stay in the transformed domain (T = 16) and the reduce kernel applies
-// G^T . G.  Even image sizes only.
-template <>
-struct WgradMode<3> { static constexpr int T = 16, TA = 8, S = 1; };
 
 // GROUPED: one launch for a table of layers (the training step runs the weight gradients of ALL its convolutions of one
 // mode together at the end of the backward pass: the chip is filled by independent layers instead of by splitting every
@@ -59,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
     constexpr int T = WgradMode<MODE>::T;    // taps of the partial layout
     constexpr int TA = WgradMode<MODE>::TA;  // taps (accumulators) of this workgroup
     constexpr int S = WgradMode<MODE>::S;
-    int bx = blockIdx.x, split = blockIdx.y, kyb = (MODE == 0 || MODE == 3) ? blockIdx.z : 0;  // tile, pixel split, kernel row / transform-row pair
+    int bx = blockIdx.x, split = blockIdx.y, kyb = MODE == 0 ? blockIdx.z : 0;  // tile, pixel split, kernel row
     WgradParams p = p1;
     if (GROUPED) {
         int lo = 0, hi = n_jobs - 1;
@@ -75,9 +65,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
         kyb = rest / p.n_splits;
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    int2* tile_off = reinterpret_cast<int2*>(smem);  // [32] (mode 3): float offsets of the tiles of a pixel block
-    float* sY = smem + 64;           // [64 px][64 couts]
-    float* sX = sY + 64 * WG_SY;     // [WH * WW px][64 cins]
+    float* sY = smem;                // [64 px][64 couts]
+    float* sX = smem + 64 * WG_SY;   // [WH * WW px][64 cins]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,19 +74,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
     const int l31 = lane & 31, k = lane >> 5;
     const int ct = bx % p.n_ct, kt = bx / p.n_ct;
     const int TW = p.TW, R = p.R;
-    const int WW = (MODE == 0 || MODE == 3) ? TW + 2 : S * TW;
-    const int WH = MODE == 3 ? R + 2 : S * R;
+    const int WW = MODE == 0 ? TW + 2 : S * TW;
+    const int WH = S * R;
     const int Hs = MODE == 2 ? 2 * p.Ho : (p.up ? p.Ho / 2 : p.Ho);  // source tensor size
     const int Ws = MODE == 2 ? 2 * p.Wo : (p.up ? p.Wo / 2 : p.Wo);
 
-    if (MODE == 3) {  // inside the staged dY tile / X window; the first __syncthreads() of the block loop orders this
-        const int tpr = TW >> 1, tpi = (R >> 1) * tpr;
-        if (tid < 32) {
-            const int nb = tid / tpi, rem = tid - nb * tpi, ty = rem / tpr, tx = rem - ty * tpr;
-            tile_off[tid] = make_int2(((nb * R + 2 * ty) * TW + 2 * tx) * WG_SY,
-                                      (nb * WH * WW + (2 * ty + kyb) * WW + 2 * tx) * WG_SX);
-        }
-    }
     f32x16 acc[TA];
 #pragma unroll
     for (int t = 0; t < TA; ++t)
@@ -108,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
     //      coordinates do: the divisions are done once, a block costs additions and bounds checks.  The items of the NEXT
     //      block are loaded into registers before the MFMA loop of the current one (one workgroup hides its own staging).
     constexpr int YI = 4;                                      // dY: 64 px x 16 quads / 256 threads
-    constexpr int XI = MODE == 0 ? 6 : (MODE == 1 ? 4 : (MODE == 2 ? 16 : 9));  // X window items (upper bound, checked by the launcher)
+    constexpr int XI = MODE == 0 ? 6 : (MODE == 1 ? 4 : 16);   // X window items (upper bound, checked by the launcher)
     const int NB = p.NB;
     const int q4 = 4 * (tid & 15);
     int ypos[YI], xpos[XI];  // (image << 24) | (row << 12) | column inside the block / window, -1: no item
@@ -155,8 +136,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
                 const int b = b0 + (xpos[j] >> 24), wy = (xpos[j] >> 12) & 0xFFF, wx = xpos[j] & 0xFFF;
                 int sy, sx;
                 bool ok;
-                if (MODE == 0 || MODE == 3) {
-                    const int uy = y0 - 1 + (MODE == 0 ? kyb : 0) + wy, ux = x0 - 1 + wx;
+                if (MODE == 0) {
+                    const int uy = y0 - 1 + kyb + wy, ux = x0 - 1 + wx;
                     ok = uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo;
                     sy = p.up ? uy >> 1 : uy;
                     sx = p.up ? ux >> 1 : ux;
@@ -186,46 +167,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
         // ---- MFMA: K = pixel pairs (2 cp + k) of every row of every image of the block
         const float* ya = sY + wo * 32 + l31;
         const float* xb = sX + wc * 32 + l31;
-        if (MODE == 3) {
-            // (tried: the row pair as a compile-time constant through two launches -- no per-value selects, but every input
-            // staged by two launches: 8.9 against 8.8 ms per loss+backward; reading the next pair of tiles ahead of the
-            // MFMAs needs 16 registers more than the 256 a two-per-CU workgroup has: 104 spills)
-            const int ntiles = NB * (R >> 1) * (TW >> 1);
-            for (int kk = 0; 2 * kk < ntiles; ++kk) {
-                const int tau_raw = 2 * kk + k;
-                const bool live = tau_raw < ntiles;
-                const int2 off = tile_off[live ? tau_raw : 0];  // a dead half step multiplies zeros with tile 0's (finite) values
-                const float* yp = ya + off.x;
-                float d00 = yp[0], d01 = yp[WG_SY], d10 = yp[TW * WG_SY], d11 = yp[(TW + 1) * WG_SY];
-                if (!live) d00 = d01 = d10 = d11 = 0.f;
-                // rows 2 kyb, 2 kyb + 1 of A dY:  [d0; d0 + d1]  or  [d0 - d1; -d1]
-                const float p0 = kyb ? d00 - d10 : d00, p1 = kyb ? d01 - d11 : d01;
-                const float q0 = kyb ? -d10 : d00 + d10, q1 = kyb ? -d11 : d01 + d11;
-                const float av[8] = {p0, p0 + p1, p0 - p1, -p1, q0, q0 + q1, q0 - q1, -q1};
-                // input rows 0..2 (kyb = 0) or 1..3 (kyb = 1) of the 4x4 patch
-                const float* xp = xb + off.y;
-                float x0[4], x1[4], x2[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    x0[c] = xp[c * WG_SX];
-                    x1[c] = xp[(WW + c) * WG_SX];
-                    x2[c] = xp[(2 * WW + c) * WG_SX];
-                }
-                float bv[8];
-                {   // B^T rows: 0: r0 - r2, 1: r1 + r2 | 2: r2' - r1' = x1 - x0 here, 3: r1' - r3' = x0 - x2 here
-                    float y0[4], y1[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        y0[c] = kyb ? x1[c] - x0[c] : x0[c] - x2[c];
-                        y1[c] = kyb ? x0[c] - x2[c] : x1[c] + x2[c];
-                    }
-                    bv[0] = y0[0] - y0[2]; bv[1] = y0[1] + y0[2]; bv[2] = y0[2] - y0[1]; bv[3] = y0[1] - y0[3];
-                    bv[4] = y1[0] - y1[2]; bv[5] = y1[1] + y1[2]; bv[6] = y1[2] - y1[1]; bv[7] = y1[1] - y1[3];
-                }
-#pragma unroll
-                for (int t = 0; t < TA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc[t], 0, 0, 0);
-            }
-        } else
         for (int nb = 0; nb < NB; ++nb)
         for (int r = 0; r < R; ++r) {
             for (int cp = 0; cp < TW / 2; ++cp) {
@@ -266,12 +207,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradParams p1
     }
 }
 
-// ---- mode 3, the kernel that runs it: the TRANSFORMED tiles are staged.  Thread (tile, channel quad) of the workgroup
+// ---- mode 3: 3x3 in the Winograd domain, F(3x3, 2x2): per 2x2 tile of dY and its 4x4 input patch
+//     dW = G^T [ sum_tiles (A dY A^T) (.) (B^T X B) ] G      A = [1 0; 1 1; 1 -1; 0 -1]   (4 x 2)
+//     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]          G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
+// (the transposition of the F(2x2, 3x3) algorithm of winograd_mfma.hip: same B^T, A and G change roles): 16 products per
+// tile and (cout, cin) instead of 36.  The K index of the MFMA is a pair of TILES; a workgroup owns two of the four
+// transform rows (blockIdx.z), i.e. 8 accumulators of 16 registers; the partial sums stay in the transformed domain
+// (T = 16) and the reduce kernel applies G^T . G.  Even image sizes only.
+// The TRANSFORMED tiles are staged.  Thread (tile, channel quad) of the workgroup
 // loads its own 3x4-pixel piece of the 4x4 input patch and its 2x2 dY tile straight from global memory (prefetched one pixel
 // block ahead, as above), applies the two +-1 transforms once, and stores the eight values of its transform-row pair as
 // [frequency][tile][channel] in LDS (64 KB for both operands: two workgroups per CU).  The MFMA loop is then one LDS read per
 // operand and nothing else -- the version that transformed inside the loop (4 + 12 raw reads and ~40 VALU operations per
-// 8 MFMAs, every wave redoing its neighbours' transforms) ran at 0.37 of the peak by executed products.
+// 8 MFMAs, every wave redoing its neighbours' transforms) ran at 0.37 of the peak by executed products, this one at 0.49
+// (also tried there: the row pair as a compile-time constant through two launches -- every input staged twice, no gain).
 template <bool GROUPED>
 __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WgradParams p1, const WgradParams* __restrict__ table,
                                                             int n_jobs) {
@@ -472,7 +421,7 @@ int launch_wgrad_reduce_jobs(const WgradJob* jobs_dev, int n_jobs, int total_blo
 
 // pixel-block geometry of a (Ho, Wo) output: R rows x TW columns of one image, or NB whole images when an image has at
 // most 32 pixels (4x4 / 2x2 / 1x1 maps of the deep layers: a 16-pixel block would stage as much as it multiplies)
-static int wgrad_items(int mode) { return mode == 0 ? 6 : (mode == 1 ? 4 : (mode == 2 ? 16 : 9)); }
+static int wgrad_items(int mode) { return mode == 0 ? 6 : (mode == 1 ? 4 : 16); }  // mode 3 stages per tile, not per window item
 static int wgrad_zdim(int mode) { return mode == 0 ? 3 : (mode == 3 ? 2 : 1); }
 struct WgradGeo {
     int TW, R, NB, tiles_x, tiles_y, n_blocks;
@@ -518,7 +467,7 @@ static size_t wgrad_lds_bytes(const WgradParams& p, int mode) {
     if (mode == 3) return (size_t)2 * 8 * 16 * 64 * sizeof(float);  // transformed dY and X tiles
     const int WW = mode == 0 ? p.TW + 2 : (mode == 2 ? 2 * p.TW : p.TW);
     const int WH = mode == 2 ? 2 * p.R : p.R;
-    return (size_t)(64 + 64 * WG_SY + p.NB * WH * WW * WG_SX) * sizeof(float);
+    return (size_t)(64 * WG_SY + p.NB * WH * WW * WG_SX) * sizeof(float);
 }
 // geometry of one layer's weight gradient for `splits` pixel splits (ws: splits * T * Cout * Cin floats)
 static int wgrad_fill(WgradParams& p, const float* in0, int C0, const float* in1, int C1, const float* dy, int Cout, int B, int Ho,
