@@ -353,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WgradParams p1
 // sums M[i][j] of a pair become its nine taps dW = G^T M G.  Fixed summation order throughout (no atomics).
 __device__ __forceinline__ void wgrad_reduce_block(const WgradJob& j, int lb, float* tile) {
     const int T = j.T;
+    const int TS = T == 16 ? 17 : T;  // row stride of the staged sums (16 would put every second pair on the same bank)
     const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int64_t i0 = (int64_t)lb * 64, i = i0 + li;
     if (T >= 4) {
@@ -360,10 +361,10 @@ __device__ __forceinline__ void wgrad_reduce_block(const WgradJob& j, int lb, fl
             float s = 0.f;
             if (i < j.oc)
                 for (int sp = 0; sp < j.splits; ++sp) s += j.partial[((int64_t)sp * T + t) * j.oc + i];
-            tile[li * T + t] = s;
+            tile[li * TS + t] = s;
         }
     } else {
-        float* red = tile + 64 * 16;
+        float* red = tile + 64 * 17;
         for (int t = 0; t < T; ++t) {
             float s = 0.f;
             if (i < j.oc)
@@ -380,7 +381,7 @@ __device__ __forceinline__ void wgrad_reduce_block(const WgradJob& j, int lb, fl
         float* o = j.out + i0 * 9;
         for (int k = threadIdx.x; k < pairs * 9; k += 256) {
             const int pr = k / 9, uv = k - pr * 9, u = uv / 3, v = uv - u * 3;
-            const float* M = tile + pr * 16;
+            const float* M = tile + pr * TS;
             // column u of G: (1, 1/2, 1/2, 0), (0, 1/2, -1/2, 0), (0, 1/2, 1/2, 1)
             float r[4];  // r[jj] = sum_i G[i][u] M[i][jj]
 #pragma unroll
@@ -398,12 +399,12 @@ __device__ __forceinline__ void wgrad_reduce_block(const WgradJob& j, int lb, fl
     for (int k = threadIdx.x; k < n; k += 256) o[k] = j.accumulate ? o[k] + tile[k] : tile[k];
 }
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradJob j) {
-    __shared__ float tile[64 * 16 + 4 * 64];
+    __shared__ float tile[64 * 17 + 4 * 64];
     wgrad_reduce_block(j, blockIdx.x, tile);
 }
 // the same sum for a table of layers: workgroup -> job by binary search over the block prefix
 __global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const WgradJob* __restrict__ jobs, int n_jobs) {
-    __shared__ float tile[64 * 16 + 4 * 64];
+    __shared__ float tile[64 * 17 + 4 * 64];
     int lo = 0, hi = n_jobs - 1;
     while (lo < hi) {  // last job whose first_block <= blockIdx.x
         const int mid = (lo + hi + 1) >> 1;

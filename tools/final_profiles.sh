@@ -19,3 +19,6 @@ echo "== vae"; python3 tools/vae_time.py > gpurun_out/${tag}_vae.txt 2>&1; tail 
 echo "== training step stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_train -o s -- python3 tools/train_time.py --batch 64 --steps 10 > gpurun_out/${tag}_train.log 2>&1
 rm -f gpurun_out/${tag}_train/*kernel_trace.csv; python3 tools/train_time.py --batch 64 --steps 10 > gpurun_out/${tag}_train_time.txt 2>&1; tail -2 gpurun_out/${tag}_train_time.txt
+echo "== training step pmc"
+PMC_CMD="python3 tools/train_time.py --batch 64 --steps 3" bash tools/pmc_run.sh ${tag}_trainpmc
+python3 tools/pmc_summary.py gpurun_out/${tag}_trainpmc > gpurun_out/${tag}_train_pmc.json
