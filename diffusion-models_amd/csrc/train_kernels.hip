@@ -17,6 +17,19 @@ namespace dm {
 // the rows of the workgroup's chunk (one image), combined through LDS in a fixed order, and written as partial sums
 // [image][chunk][4][C]; rowgrad_reduce_kernel finishes them (deterministic: no atomics).
 // ---------------------------------------------------------------------------------------
+// Philox4x32-10 (the dropout masks below and in norm_act_bwd_kernel)
+__device__ __forceinline__ void philox4(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
 struct NormBwdParams {
     const float* dy;
     const float* u;
@@ -26,6 +39,10 @@ struct NormBwdParams {
     float* part;       // [B][chunks][4][C]: dg, dbias, dscale, dshift
     int C, C4, LPR, NV, ss_stride, flags;
     int pix_per_image, rows_per_chunk, chunks;
+    // nn.Dropout between the activation and this kernel's input gradient: dy is multiplied by the mask of the forward pass
+    // (dropout_kernel below: Philox keyed by (seed, stream, flat float4 index)), recomputed here instead of a separate pass
+    float drop_p, drop_inv_keep;
+    uint64_t drop_seed, drop_stream;
 };
 
 template <int NV>
@@ -65,6 +82,14 @@ __global__ __launch_bounds__(256) void norm_act_bwd_kernel(const NormBwdParams p
             const int c4 = sub + LPR * v;
             uv[v] = (cv[v] && rv) ? *reinterpret_cast<const f32x4*>(p.u + base + 4 * c4) : z;
             dv[v] = (cv[v] && rv) ? *reinterpret_cast<const f32x4*>(p.dy + base + 4 * c4) : z;
+            if (p.drop_p > 0.f) {
+                const uint64_t i4 = (uint64_t)(base >> 2) + c4;
+                uint32_t c[4] = {(uint32_t)i4, (uint32_t)(i4 >> 32), (uint32_t)p.drop_stream, (uint32_t)(p.drop_stream >> 32)};
+                philox4(c, (uint32_t)p.drop_seed, (uint32_t)(p.drop_seed >> 32));
+                float* q = reinterpret_cast<float*>(&dv[v]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = ((float)c[j] * 2.3283064365386963e-10f >= p.drop_p) ? q[j] * p.drop_inv_keep : 0.f;
+            }
             ssq += uv[v].x * uv[v].x + uv[v].y * uv[v].y + uv[v].z * uv[v].z + uv[v].w * uv[v].w;
         }
         for (int m = 1; m < LPR; m <<= 1) ssq += __shfl_xor(ssq, m);
@@ -276,9 +301,12 @@ size_t norm_act_bwd_ws_floats(int B, int pix_per_image, int C) {
 // receives (dscale | dshift) at columns [0, 2C) of each row when the forward had a scale-shift, else nullptr.
 int launch_norm_act_bwd(const float* dy, const float* u, const float* g, const float* ss, int ss_stride, int pix_per_image,
                         float* du, float* ws, float* dg, float* dbias, float* dss, int dss_stride, int B, int C, int flags,
-                        int accumulate, hipStream_t s, RowgradJob* defer) {
+                        int accumulate, hipStream_t s, RowgradJob* defer, float drop_p, uint64_t drop_seed,
+                        uint64_t drop_stream) {
     DM_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "norm_act_bwd: C must be a multiple of 4, at most 1024");
+    DM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "norm_act_bwd: dropout probability");
     NormBwdParams p{};
+    p.drop_p = drop_p; p.drop_inv_keep = 1.0f / (1.0f - drop_p); p.drop_seed = drop_seed; p.drop_stream = drop_stream;
     p.dy = dy; p.u = u; p.g = g; p.ss = ss; p.du = du; p.part = ws;
     p.C = C; p.C4 = C / 4;
     p.LPR = std::min(64, pow2ceil(p.C4));
@@ -509,18 +537,6 @@ int launch_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int ac
 // nn.Dropout(p) of Block.forward in training mode (DD/denoising_diffusion.py:111,121): out = x * keep / (1 - p) [+ add],
 // keep ~ Bernoulli(1 - p) from Philox4x32-10 keyed by (seed, stream, element index / 4).  The backward pass applies the
 // SAME mask to the gradient, recomputed from the key (nothing is stored).  x == nullptr writes the mask factor itself.
-__device__ __forceinline__ void philox4(uint32_t c[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
 __global__ void dropout_kernel(const float* __restrict__ x, const float* __restrict__ add, float* __restrict__ out, int64_t n4,
                                float p, float inv_keep, uint64_t seed, uint64_t stream) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -15,8 +15,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--size", type=int, default=32)
+ap.add_argument("--dropout", type=float, default=0.0)
 args = ap.parse_args()
-u = dm.Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=3, device="cuda:0")
+u = dm.Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=3, dropout=args.dropout, device="cuda:0")
 u.load_state_dict(dm.synth_state_dict(u.param_spec(), salt=0))
 d = dm.DenoisingDiffusion(u, image_size=args.size, timesteps=1000).train()
 img = torch.rand(args.batch, 3, args.size, args.size, device="cuda:0")
