@@ -410,6 +410,9 @@ int launch_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, float
                         int accumulate, hipStream_t s);
 int launch_mlp_rows_wgrad(const float* dy, int ldy, const float* x, int ldx, float* const* dw_rows, float* const* db_rows,
                           int R, int I, int O, int accumulate, hipStream_t s);
+int launch_lincomb(const float* x, const float* y, const float* coef_dev, float* out, int B, int64_t per_sample, int mode,
+                   int clamp, hipStream_t s);
+int launch_mask_mix(const float* a, const float* b, const float* mask, float* out, int64_t n, hipStream_t s);
 int launch_offset_noise(float* noise, const float* offset, float strength, int BC, int HW, hipStream_t s);
 int launch_cdist(const float* x, const float* y, float* out, int n, int m, int64_t D, hipStream_t s);
 size_t linear_dgrad_ws_floats(int R, int I, int O);

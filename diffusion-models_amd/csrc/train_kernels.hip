@@ -851,6 +851,40 @@ int launch_cdist(const float* x, const float* y, float* out, int n, int m, int64
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
+// The elementwise helpers of DenoisingDiffusion (predict_start_from_noise / predict_noise_from_start / predict_v /
+// predict_start_from_v / the posterior mean, DD/denoising_diffusion.py:570-601) with per-sample coefficients c = coef[b][0..1]:
+//   mode 0: out = c0 * x + c1 * y        mode 1: out = (c0 * x - y) / c1        clamp: to [-1, 1] afterwards
+// and the guide mix of ddim_sample_guided (:754): out = a * mask + b * (1 - mask).  Roundings as the reference's expressions.
+__global__ void lincomb_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ coef,
+                               float* __restrict__ out, int64_t per_sample, int64_t n, int mode, int clamp) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float c0 = coef[2 * (i / per_sample)], c1 = coef[2 * (i / per_sample) + 1];
+    float v = mode == 0 ? c0 * x[i] + c1 * y[i] : (c0 * x[i] - y[i]) / c1;
+    if (clamp) v = fminf(fmaxf(v, -1.f), 1.f);
+    out[i] = v;
+}
+int launch_lincomb(const float* x, const float* y, const float* coef_dev, float* out, int B, int64_t per_sample, int mode,
+                   int clamp, hipStream_t s) {
+    const int64_t n = (int64_t)B * per_sample;
+    hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, coef_dev, out, per_sample, n, mode,
+                       clamp);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+__global__ void mask_mix_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ mask,
+                                float* __restrict__ out, int64_t n) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = a[i] * mask[i] + b[i] * (1.0f - mask[i]);
+}
+int launch_mask_mix(const float* a, const float* b, const float* mask, float* out, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(mask_mix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, mask, out, n);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 int launch_q_sample(const float* x_start, const float* noise, const float* coef_dev, float* x, int B, int per_sample,
                     hipStream_t s) {
     const int64_t n = (int64_t)B * per_sample;

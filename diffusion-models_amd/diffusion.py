@@ -23,6 +23,8 @@ the unsharded batch bit for bit.
 """
 from __future__ import annotations
 
+from collections import namedtuple
+
 import ctypes as C
 import os
 import pickle
@@ -45,6 +47,9 @@ def _identity(t, *a, **k):
 def _default_seed() -> int:
     """A Philox key from torch's global CPU generator (reproducible under torch.manual_seed)."""
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+ModelPrediction = namedtuple("ModelPrediction", ["pred_noise", "pred_x_start"])  # :33
 
 
 class DenoisingDiffusion:
@@ -375,6 +380,143 @@ class DenoisingDiffusion:
         return self._run(DDPM, tuple(x1.shape), times, coefs, [ti > 0 for ti in times], False, noise, seed, x_init=img,
                          unnormalize=False)
 
+    # -- the elementwise helpers and model_predictions / p_mean_variance as callable methods ------------------------
+    def _bt(self, t, b: int) -> torch.Tensor:
+        """(B,) CPU long timesteps from an int or a tensor."""
+        if isinstance(t, torch.Tensor):
+            t = t.detach().to("cpu", torch.long).reshape(-1)
+            return t.expand(b).contiguous() if t.numel() == 1 else t
+        return torch.full((b,), int(t), dtype=torch.long)
+
+    def _lincomb(self, x, y, name0, name1, t, mode=0, clamp=False, neg1=False):
+        """mode 0: extract(name0, t) * x (+|-) extract(name1, t) * y;  mode 1: (extract(name0, t) * x - y) / extract(name1, t)."""
+        x = x.to(self.device, torch.float32).contiguous()
+        y = y.to(self.device, torch.float32).contiguous()
+        assert x.shape == y.shape
+        bt = self._bt(t, x.shape[0])
+        c0, c1 = self._sched[name0][bt], self._sched[name1][bt]
+        coef = torch.stack([c0, -c1 if neg1 else c1], dim=1).to(torch.float32).contiguous()
+        out = torch.empty_like(x)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.dm_op_lincomb(_lib.ptr(x), _lib.ptr(y), C.cast(coef.data_ptr(), C.POINTER(C.c_float)), _lib.ptr(out),
+                                           x.shape[0], x[0].numel(), mode, int(bool(clamp)), stream))
+        return out
+
+    def _ext(self, name, t, x):
+        """``extract(buffer, t, x.shape)`` (:394-397) on the device."""
+        bt = self._bt(t, x.shape[0])
+        return self._sched[name][bt].reshape(-1, *((1,) * (x.dim() - 1))).to(self.device)
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        """:570-574."""
+        return self._lincomb(x_t, noise, "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", t, neg1=True)
+
+    def predict_noise_from_start(self, x_t, t, x0):
+        """:576-580."""
+        return self._lincomb(x_t, x0, "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", t, mode=1)
+
+    def predict_v(self, x_start, t, noise):
+        """:582-586."""
+        return self._lincomb(noise, x_start, "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", t, neg1=True)
+
+    def predict_start_from_v(self, x_t, t, v):
+        """:588-592."""
+        return self._lincomb(x_t, v, "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", t, neg1=True)
+
+    def q_posterior(self, x_start, x_t, t):
+        """:594-601: (posterior_mean, posterior_variance, posterior_log_variance_clipped)."""
+        mean = self._lincomb(x_start, x_t, "posterior_mean_coef1", "posterior_mean_coef2", t)
+        return mean, self._ext("posterior_variance", t, x_t), self._ext("posterior_log_variance_clipped", t, x_t)
+
+    @torch.inference_mode()
+    def model_predictions(self, x, t, x_self_cond=None, clip_x_start=False, rederive_pred_noise=False, **cond_kw):
+        """:603-626: ``ModelPrediction(pred_noise, pred_x_start)`` for per-sample timesteps ``t`` (a (B,) tensor, or an int)."""
+        x = x.to(self.device, torch.float32).contiguous()
+        bt = self._bt(t, x.shape[0])
+        if self.self_condition:
+            cond_kw = dict(cond_kw, x_self_cond=x_self_cond)
+        else:
+            assert x_self_cond is None, "the model was built without self_condition"
+        out = self._eps(x, bt.to(self.device), **cond_kw)
+        clamp = bool(clip_x_start)
+        if self.objective == "pred_noise":
+            pred_noise = out
+            x_start = self._lincomb(x, out, "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", bt, clamp=clamp, neg1=True)
+            if clip_x_start and rederive_pred_noise:
+                pred_noise = self.predict_noise_from_start(x, bt, x_start)
+        elif self.objective == "pred_x0":
+            x_start = out.clamp(-1.0, 1.0) if clamp else out
+            pred_noise = self.predict_noise_from_start(x, bt, x_start)
+        else:
+            x_start = self._lincomb(x, out, "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", bt, clamp=clamp, neg1=True)
+            pred_noise = self.predict_noise_from_start(x, bt, x_start)
+        return ModelPrediction(pred_noise, x_start)
+
+    @torch.inference_mode()
+    def p_mean_variance(self, x, t, x_self_cond=None, clip_denoised=True, **cond_kw):
+        """:628-636: (model_mean, posterior_variance, posterior_log_variance, x_start)."""
+        x = x.to(self.device, torch.float32).contiguous()
+        x_start = self.model_predictions(x, t, x_self_cond, clip_x_start=bool(clip_denoised), **cond_kw).pred_x_start
+        mean, var, logvar = self.q_posterior(x_start, x, t)
+        return mean, var, logvar, x_start
+
+    @torch.inference_mode()
+    def ddim_sample_guided(self, shape, sampling_timesteps=None, guide=None, mask=None, clip_denoised=True, *, noise=None,
+                           seed=None):
+        """:711-781: the DDIM loop with the raw model output as pred_noise (x_start clipped, the noise NOT re-derived) and,
+        after every update, ``img = img * mask + q_sample(guide, time) * (1 - mask)``.  Eager (one U-Net forward and four
+        elementwise kernels per step).  The reference also opens a matplotlib figure per step (:760-777); that side effect
+        is not reproduced.  ``noise`` draws in the reference's order: x_T, then per step the update's noise and, with a
+        guide, q_sample's."""
+        if sampling_timesteps is None:
+            sampling_timesteps = self.sampling_timesteps
+        shape = tuple(int(v) for v in shape)
+        b = shape[0]
+        if seed is None:
+            seed = _default_seed()
+        draws = [0]
+
+        def draw():
+            draws[0] += 1
+            return (noise(shape).to(self.device, torch.float32).contiguous() if noise is not None
+                    else self._randn(shape, seed, (1 << 21) + draws[0]))
+
+        ac = self._sched["alphas_cumprod"]
+        times = torch.linspace(-1, self.num_timesteps - 1, steps=sampling_timesteps + 1)
+        times = list(reversed(times.int().tolist()))
+        img = draw()
+        if guide is not None:
+            guide = guide.to(self.device, torch.float32).contiguous()
+            mask_full = mask.to(self.device, torch.float32).expand(shape).contiguous()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        x_start = None
+        for time, time_next in zip(times[:-1], times[1:]):
+            pred_noise, x_start = self.model_predictions(img, time, x_start if self.self_condition else None,
+                                                         clip_x_start=clip_denoised)
+            if time_next < 0:
+                img = x_start
+                continue
+            alpha, alpha_next = ac[time], ac[time_next]
+            sigma = self.ddim_sampling_eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+            c = (1 - alpha_next - sigma ** 2).sqrt()
+            z = draw()
+
+            def comb(x, y, c0, c1):
+                coef = torch.tensor([[float(c0), float(c1)]] * b, dtype=torch.float32).contiguous()
+                out = torch.empty_like(x)
+                _lib.check(self._lib.dm_op_lincomb(_lib.ptr(x), _lib.ptr(y), C.cast(coef.data_ptr(), C.POINTER(C.c_float)),
+                                                   _lib.ptr(out), b, x[0].numel(), 0, 0, stream))
+                return out
+
+            img = comb(comb(x_start, pred_noise, alpha_next.sqrt(), c), z, 1.0, sigma)
+            if guide is not None:
+                guide_t = self.q_sample(guide, torch.full((b,), time, dtype=torch.long), draw())
+                out = torch.empty_like(img)
+                _lib.check(self._lib.dm_op_mask_mix(_lib.ptr(img), _lib.ptr(guide_t), _lib.ptr(mask_full), _lib.ptr(out),
+                                                    img.numel(), stream))
+                img = out
+        return (img + 1) * 0.5  # unnormalize_to_zero_to_one, whatever auto_normalize says (:779)
+
     def _eps(self, x, bt, **cond_kw):
         """The U-Net call of ``model_predictions`` (:603-606); subclasses thread their condition through ``cond_kw``."""
         return self.model(x, bt, **cond_kw)
@@ -482,6 +624,16 @@ class TextConditionalDenoisingDiffusion(DenoisingDiffusion):
     __call__ = forward
 
     @torch.inference_mode()
+    def model_predictions(self, x, t, text_emb=None, x_self_cond=None, clip_x_start=False, rederive_pred_noise=False):
+        """denoising_diffusion_text_conditional.py:274-297 (positional order: x, t, text_emb, x_self_cond)."""
+        kw = {"text_emb": text_emb} if text_emb is not None else {}
+        return super().model_predictions(x, t, x_self_cond, clip_x_start, rederive_pred_noise, **kw)
+
+    def p_mean_variance(self, x, t, text_emb=None, x_self_cond=None, clip_denoised=True):
+        """:299-307."""
+        kw = {"text_emb": text_emb} if text_emb is not None else {}
+        return super().p_mean_variance(x, t, x_self_cond, clip_denoised, **kw)
+
     def p_sample(self, x, t: int, text_emb=None, x_self_cond=None, *, noise=None):
         """denoising_diffusion_text_conditional.py:310-317 (the reference's positional order: x, t, text_emb)."""
         return self._p_sample(x, t, noise, {"text_emb": text_emb} if text_emb is not None else {}, x_self_cond)
@@ -555,6 +707,16 @@ class ImageConditionalDenoisingDiffusion(DenoisingDiffusion):
         return self.p_losses(self.normalize(img.to(self.device, torch.float32)), t, *args, cond=cond, **kwargs)
 
     __call__ = forward
+
+    def model_predictions(self, x, t, cond=None, x_self_cond=None, clip_x_start=False, rederive_pred_noise=False):
+        """denoising_diffusion_image_conditional.py:78-102 (positional order: x, t, cond, x_self_cond)."""
+        assert cond is not None, "the image-conditional U-Net needs cond="
+        return super().model_predictions(x, t, x_self_cond, clip_x_start, rederive_pred_noise, cond=cond)
+
+    def p_mean_variance(self, x, t, cond=None, x_self_cond=None, clip_denoised=True):
+        """:104-112."""
+        assert cond is not None, "the image-conditional U-Net needs cond="
+        return super().p_mean_variance(x, t, x_self_cond, clip_denoised, cond=cond)
 
     @torch.inference_mode()
     def p_sample(self, x, t: int, cond=None, x_self_cond=None, *, noise=None):

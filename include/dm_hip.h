@@ -364,6 +364,14 @@ int dm_op_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t c
 /* q_sample (:813-821) on its own: out = coef[b][0] * x_start + coef[b][1] * noise, coef_host (B, 8) as above */
 int dm_op_q_sample(const float* x_start, const float* noise, const float* coef_host, float* out, int B, int per_sample,
                    void* stream);
+/* The elementwise helpers of DenoisingDiffusion as callable methods -- predict_start_from_noise, predict_noise_from_start,
+ * predict_v, predict_start_from_v, the posterior mean of q_posterior (DD/denoising_diffusion.py:570-601), and through them
+ * model_predictions (:603-626) / p_mean_variance (:628-636) with per-sample timesteps: coef_host (B, 2) = the two values
+ * `extract` gathers;  mode 0: out = c0 * x + c1 * y;  mode 1: out = (c0 * x - y) / c1;  clamp != 0: to [-1, 1] afterwards.
+ * dm_op_mask_mix: out = a * mask + b * (1 - mask), the guide step of ddim_sample_guided (:754); all (n) device floats. */
+int dm_op_lincomb(const float* x, const float* y, const float* coef_host, float* out, int B, int64_t per_sample, int mode,
+                  int clamp, void* stream);
+int dm_op_mask_mix(const float* a, const float* b, const float* mask, float* out, int64_t n, void* stream);
 /* offset noise (:830-834): noise[b][c][:] += strength * offset[b][c]  (noise (B, C, H, W) in place, offset (B, C)) */
 int dm_op_offset_noise(float* noise, const float* offset, float strength, int BC, int HW, void* stream);
 /* immiscible diffusion's noise assignment (:805-817): out[i][j] = || x[i] - y[j] ||_2 over D floats (torch.cdist of the

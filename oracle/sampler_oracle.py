@@ -172,3 +172,73 @@ def interpolate(model: Model, sched, x1, x2, t: int, lam: float, noise: Callable
         z = noise(x1.shape) if i > 0 else None
         img, _ = p_sample(model, sched, img, i, z)
     return img
+
+
+# ---- the prediction helpers with per-sample timesteps, and the guided DDIM loop ---------------------------------------
+def _ext(sched, name: str, t: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """``extract`` (DD/denoising_diffusion.py:394-397): gather + reshape to (B, 1, 1, 1)."""
+    return sched[name][t].reshape(-1, *((1,) * (x.dim() - 1)))
+
+
+def model_predictions(model: Model, sched, x, t: torch.Tensor, objective: str = "pred_noise", x_self_cond=None,
+                      clip_x_start: bool = False, rederive_pred_noise: bool = False):
+    """DD/denoising_diffusion.py:603-626 with a (B,) tensor of timesteps: (pred_noise, pred_x_start)."""
+    out = _call(model, x, t, x_self_cond)
+    clip = (lambda v: v.clamp(-1.0, 1.0)) if clip_x_start else (lambda v: v)
+    rc, rm = _ext(sched, "sqrt_recip_alphas_cumprod", t, x), _ext(sched, "sqrt_recipm1_alphas_cumprod", t, x)
+    if objective == "pred_noise":
+        pred_noise = out
+        x_start = clip(rc * x - rm * out)
+        if clip_x_start and rederive_pred_noise:
+            pred_noise = (rc * x - x_start) / rm
+    elif objective == "pred_x0":
+        x_start = clip(out)
+        pred_noise = (rc * x - x_start) / rm
+    else:
+        x_start = clip(_ext(sched, "sqrt_alphas_cumprod", t, x) * x - _ext(sched, "sqrt_one_minus_alphas_cumprod", t, x) * out)
+        pred_noise = (rc * x - x_start) / rm
+    return pred_noise, x_start
+
+
+def q_posterior(sched, x_start, x_t, t: torch.Tensor):
+    """:594-601."""
+    mean = _ext(sched, "posterior_mean_coef1", t, x_t) * x_start + _ext(sched, "posterior_mean_coef2", t, x_t) * x_t
+    return mean, _ext(sched, "posterior_variance", t, x_t), _ext(sched, "posterior_log_variance_clipped", t, x_t)
+
+
+def p_mean_variance(model: Model, sched, x, t: torch.Tensor, objective: str = "pred_noise", x_self_cond=None,
+                    clip_denoised: bool = True):
+    """:628-636."""
+    _, x_start = model_predictions(model, sched, x, t, objective, x_self_cond)
+    if clip_denoised:
+        x_start = x_start.clamp(-1.0, 1.0)
+    mean, var, logvar = q_posterior(sched, x_start, x, t)
+    return mean, var, logvar, x_start
+
+
+@torch.inference_mode()
+def ddim_sample_guided(model: Model, sched, shape, noise: Callable, sampling_timesteps: int, eta: float = 0.0, guide=None,
+                       mask=None, clip_denoised: bool = True, objective: str = "pred_noise", self_condition: bool = False):
+    """:711-781 without the matplotlib figures: pred_noise is NOT re-derived from the clipped x_start, and after every update
+    ``img = img * mask + q_sample(guide, time) * (1 - mask)`` (the reference diffuses the guide to ``time``, not ``time_next``)."""
+    T = sched["betas"].shape[0]
+    img = noise(shape)
+    ac = sched["alphas_cumprod"]
+    x_start = None
+    for t, t_next in ddim_pairs(T, sampling_timesteps):
+        bt = torch.full((shape[0],), t, dtype=torch.long)
+        sc = x_start if self_condition else None
+        pred_noise, x_start = model_predictions(model, sched, img, bt, objective, sc, clip_x_start=clip_denoised)
+        if t_next < 0:
+            img = x_start
+            continue
+        alpha, alpha_next = ac[t], ac[t_next]
+        sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+        c = (1 - alpha_next - sigma ** 2).sqrt()
+        z = noise(shape)
+        img = x_start * alpha_next.sqrt() + c * pred_noise + sigma * z
+        if guide is not None:
+            guide_t = sched["sqrt_alphas_cumprod"][t] * guide + sched["sqrt_one_minus_alphas_cumprod"][t] * noise(shape)
+            img = img * mask + guide_t * (1 - mask)
+    return (img + 1) * 0.5
+

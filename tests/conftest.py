@@ -95,6 +95,13 @@ def golden_train_noise():
     return load_golden("train_noise.pt")
 
 
+@pytest.fixture(scope="session")
+def golden_guided():
+    """The reference's model_predictions / p_mean_variance / q_posterior / predict_* with per-sample timesteps and its
+    ddim_sample_guided (tests/golden/make_golden_guided.py)."""
+    return load_golden("guided.pt")
+
+
 def check_grad_digest(name: str, grad: torch.Tensor, dg: dict, tol: float):
     """A gradient against its golden digest: norm, 8 random projections, the first elements, the whole tensor if small.
     Every check is relative to the golden gradient's norm (a projection of a vector of norm n on a unit-variance random

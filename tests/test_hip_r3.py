@@ -172,3 +172,36 @@ def test_interpolate(golden_r3):
     err = rel_l2(got, b["y"])
     print("interpolate", err)
     assert err < LOOP_TOL
+
+
+def test_prediction_helpers_and_guided_ddim(golden_guided):
+    """model_predictions / p_mean_variance / q_posterior / predict_* as callable methods with per-sample timesteps (all three
+    objectives) and ddim_sample_guided (DD/denoising_diffusion.py:570-636, :711-781) against the reference's own outputs."""
+    u, _ = _unet(UnetConfig(dim=64, dim_mults=(1, 2), channels=3), 31)
+    for obj in ("pred_noise", "pred_x0", "pred_v"):
+        b = golden_guided[f"pred_{obj}"]
+        d = dm.DenoisingDiffusion(u, image_size=16, timesteps=1000, objective=obj)
+        p = d.model_predictions(b["x"], b["t"])
+        assert rel_l2(p.pred_noise.cpu(), b["pred_noise"]) < FWD_TOL and rel_l2(p.pred_x_start.cpu(), b["pred_x_start"]) < FWD_TOL
+        p = d.model_predictions(b["x"], b["t"], clip_x_start=True, rederive_pred_noise=True)
+        assert rel_l2(p.pred_noise.cpu(), b["pred_noise_clip"]) < FWD_TOL
+        assert rel_l2(p.pred_x_start.cpu(), b["pred_x_start_clip"]) < FWD_TOL
+        mean, var, logvar, xs = d.p_mean_variance(b["x"], b["t"])
+        assert rel_l2(mean.cpu(), b["mean"]) < FWD_TOL and rel_l2(xs.cpu(), b["x_start"]) < FWD_TOL
+        assert torch.equal(var.cpu(), b["var"]) and torch.equal(logvar.cpu(), b["logvar"]) and var.shape == (4, 1, 1, 1)
+        # the pure elementwise helpers are bit-exact (same roundings as the reference's expressions)
+        for name in ("predict_v", "predict_start_from_v", "predict_noise_from_start", "predict_start_from_noise"):
+            got = getattr(d, name)(b["x"], b["t"], b["other"]).cpu()
+            assert torch.equal(got, b[name]), (obj, name, rel_l2(got, b[name]))
+        m2, v2, l2 = d.q_posterior(b["x_start"], b["x"], b["t"])
+        assert rel_l2(m2.cpu(), b["mean"]) < 1e-6
+    b = golden_guided["guided"]
+    d = dm.DenoisingDiffusion(u, image_size=16, timesteps=1000, sampling_timesteps=b["S"], ddim_sampling_eta=b["eta"])
+    y = d.ddim_sample_guided(b["shape"], guide=b["guide"], mask=b["mask"], noise=so.NoiseStream(b["seed"])).cpu()
+    err = rel_l2(y, b["y"])
+    print("ddim_sample_guided", err)
+    assert err < LOOP_TOL
+    y = d.ddim_sample_guided(b["shape"], noise=so.NoiseStream(b["seed_noguide"])).cpu()
+    assert rel_l2(y, b["y_noguide"]) < LOOP_TOL
+    assert bool(torch.isfinite(d.ddim_sample_guided(b["shape"], guide=b["guide"], mask=b["mask"])).all())  # device noise
+

@@ -426,3 +426,30 @@ def test_train_noise_options(golden_train_noise, case):
     for name, dg in b["grads"].items():
         check_grad_digest(name, grads[name], dg, 2e-5)
 
+
+def test_prediction_helpers_and_guided_ddim(golden_guided):
+    """oracle/sampler_oracle.py: model_predictions / p_mean_variance / q_posterior with a batch of different timesteps for the
+    three objectives, and ddim_sample_guided (with and without a guide), against the reference's own outputs."""
+    from oracle import sampler_oracle as so
+
+    cfg = UnetConfig(dim=64, dim_mults=(1, 2), channels=3)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=31)
+    sched = dm.make_schedule(1000, "linear")
+    model = lambda x, t: uo.unet_forward(sd, cfg, x, t)  # noqa: E731
+    torch.set_num_threads(8)
+    with torch.inference_mode():
+        for obj in ("pred_noise", "pred_x0", "pred_v"):
+            b = golden_guided[f"pred_{obj}"]
+            pn, xs = so.model_predictions(model, sched, b["x"], b["t"], obj)
+            assert rel_l2(pn, b["pred_noise"]) < 1e-5 and rel_l2(xs, b["pred_x_start"]) < 1e-5, obj
+            pn, xs = so.model_predictions(model, sched, b["x"], b["t"], obj, clip_x_start=True, rederive_pred_noise=True)
+            assert rel_l2(pn, b["pred_noise_clip"]) < 1e-5 and rel_l2(xs, b["pred_x_start_clip"]) < 1e-5, obj
+            mean, var, logvar, xs = so.p_mean_variance(model, sched, b["x"], b["t"], obj)
+            assert rel_l2(mean, b["mean"]) < 1e-5 and torch.equal(var, b["var"]) and torch.equal(logvar, b["logvar"]), obj
+            assert rel_l2(xs, b["x_start"]) < 1e-5
+    b = golden_guided["guided"]
+    y = so.ddim_sample_guided(model, sched, b["shape"], so.NoiseStream(b["seed"]), b["S"], b["eta"], b["guide"], b["mask"])
+    assert rel_l2(y, b["y"]) < 1e-4
+    y = so.ddim_sample_guided(model, sched, b["shape"], so.NoiseStream(b["seed_noguide"]), b["S"], b["eta"])
+    assert rel_l2(y, b["y_noguide"]) < 1e-4
+
