@@ -160,3 +160,24 @@ def test_parameter_order_is_the_reference_optimizers():
     for key, cfg in cases.items():
         assert [n for n, _ in unet_param_spec(cfg)] == want[key], key
 
+
+def test_method_surface_of_the_mirrored_classes():
+    """Every public method / property the reference defines on the classes this package mirrors exists here under the same
+    name (fixture: names collected from the reference's classes by tests/golden/make_golden_param_order.py).  Not mirrored,
+    by design: the Lightning training / logging hooks of the VAE (VAE training is out of scope) and its
+    codebook / checkpoint conveniences."""
+    import json
+    import os
+
+    import diffusion_models_amd as dm
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "api_surface.json")) as f:
+        want = json.load(f)
+    out_of_scope = {"VQModel": {"_validation_step", "configure_optimizers", "decode_code", "ema_scope", "forward", "get_input",
+                                "get_last_layer", "init_from_ckpt", "log_images", "on_train_batch_end", "to_rgb",
+                                "training_step", "validation_step"}}
+    for cls, names in want.items():
+        ours = set(dir(getattr(dm, cls)))
+        missing = set(names) - ours - out_of_scope.get(cls, set())
+        assert not missing, (cls, sorted(missing))
+
