@@ -211,6 +211,15 @@ class VQModel:
     def decode(self, quant):
         return self.decoder.decode(quant)
 
+    def forward(self, input, return_pred_indices=False):
+        """autoencoder.py:123-128: encode, quantize, decode -> (dec, diff[, indices]); the commitment loss ``diff`` is a
+        training quantity and comes back as ``None``."""
+        quant, diff, (_, _, ind) = self.encode(input)
+        dec = self.decode(quant)
+        return (dec, diff, ind) if return_pred_indices else (dec, diff)
+
+    __call__ = forward
+
     def decoded_shape(self, latent_chw):
         return self.decoder.decoded_shape(latent_chw)
 

@@ -113,6 +113,10 @@ def test_vq_coco(golden_r3):
     err = rel_l2(vae.encode_to_prequant(b["x"]).cpu(), b["prequant"])
     print("vq_coco encode_to_prequant", err)
     assert err < FWD_TOL
+    # VQModel.forward (autoencoder.py:123-128) = decode(encode(x)[0]), with the code indices on request
+    dec, diff, ind = vae(b["x"], return_pred_indices=True)
+    quant, _, (_, _, ind2) = vae.encode(b["x"])
+    assert diff is None and torch.equal(ind, ind2) and torch.equal(dec, vae.decode(quant)) and len(vae(b["x"])) == 2
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
