@@ -362,6 +362,9 @@ class DenoisingDiffusion:
         """:786-803: diffuse x1 and x2 to step t, mix them with weight lam, run the reverse loop from t - 1 down to 0.
         Like the reference it returns the image as the loop leaves it (no unnormalize).  ``noise`` draws, in the
         reference's order: q_sample(x1), q_sample(x2), then one per reverse step with i > 0."""
+        return self._interpolate(x1, x2, t, lam, noise, seed)
+
+    def _interpolate(self, x1, x2, t, lam, noise, seed, text_emb=None, cond=None):
         assert x1.shape == x2.shape
         b = x1.shape[0]
         t = self.num_timesteps - 1 if t is None else int(t)
@@ -377,8 +380,8 @@ class DenoisingDiffusion:
         times_all, coefs_all = self._ddpm_tables()  # row i is step T-1-i
         first = self.num_timesteps - t             # the row of step t - 1
         times, coefs = times_all[first:], coefs_all[first:]
-        return self._run(DDPM, tuple(x1.shape), times, coefs, [ti > 0 for ti in times], False, noise, seed, x_init=img,
-                         unnormalize=False)
+        return self._run(DDPM, tuple(x1.shape), times, coefs, [ti > 0 for ti in times], False, noise, seed, text_emb=text_emb,
+                         cond=cond, x_init=img, unnormalize=False)
 
     # -- the elementwise helpers and model_predictions / p_mean_variance as callable methods ------------------------
     def _bt(self, t, b: int) -> torch.Tensor:
@@ -624,6 +627,11 @@ class TextConditionalDenoisingDiffusion(DenoisingDiffusion):
     __call__ = forward
 
     @torch.inference_mode()
+    @torch.inference_mode()
+    def interpolate(self, x1, x2, t=None, text_emb=None, lam=0.5, *, noise=None, seed=None):
+        """denoising_diffusion_text_conditional.py:456-473 (positional order: x1, x2, t, text_emb, lam)."""
+        return self._interpolate(x1, x2, t, lam, noise, seed, text_emb=text_emb)
+
     def model_predictions(self, x, t, text_emb=None, x_self_cond=None, clip_x_start=False, rederive_pred_noise=False):
         """denoising_diffusion_text_conditional.py:274-297 (positional order: x, t, text_emb, x_self_cond)."""
         kw = {"text_emb": text_emb} if text_emb is not None else {}
@@ -707,6 +715,12 @@ class ImageConditionalDenoisingDiffusion(DenoisingDiffusion):
         return self.p_losses(self.normalize(img.to(self.device, torch.float32)), t, *args, cond=cond, **kwargs)
 
     __call__ = forward
+
+    @torch.inference_mode()
+    def interpolate(self, x1, x2, t=None, cond=None, lam=0.5, *, noise=None, seed=None):
+        """denoising_diffusion_image_conditional.py:232-249 (positional order: x1, x2, t, cond, lam)."""
+        assert cond is not None, "the image-conditional U-Net needs cond="
+        return self._interpolate(x1, x2, t, lam, noise, seed, cond=self._cond(x1.shape[0], cond))
 
     def model_predictions(self, x, t, cond=None, x_self_cond=None, clip_x_start=False, rederive_pred_noise=False):
         """denoising_diffusion_image_conditional.py:78-102 (positional order: x, t, cond, x_self_cond)."""

@@ -183,10 +183,29 @@ class VQModel:
     """``VQModel`` of the reference restricted to inference: ``encode`` / ``encode_to_prequant`` / ``decode`` over one
     ``state_dict`` (autoencoder.py:14-121)."""
 
-    def __init__(self, ddconfig: Dict, n_embed: int, embed_dim: int, device="cuda:0", **_ignored):
+    def __init__(self, ddconfig: Dict, lossconfig=None, n_embed: int = None, embed_dim: int = None, ckpt_path=None,
+                 ignore_keys=(), image_key="image", colorize_nlabels=None, monitor=None, batch_resize_range=None,
+                 scheduler_config=None, lr_g_factor=1.0, remap=None, sane_index_shape=False, use_ema=False, *,
+                 device="cuda:0"):
+        """The reference's positional order (autoencoder.py:15-31: ddconfig, lossconfig, n_embed, embed_dim, ...).  The loss
+        network, the Lightning / EMA / scheduler options are training-only and ignored; ``ckpt_path`` loads the state dict
+        (``load_vae_checkpoint``: ``weights_only=True``) minus the keys that start with one of ``ignore_keys``."""
+        assert n_embed is not None and embed_dim is not None, "n_embed and embed_dim are required"
+        assert remap is None and not sane_index_shape, "remap / sane_index_shape are not on the HIP path"
+        self.image_key = image_key
         self.encoder = VQEncoder(ddconfig, embed_dim, n_embed, device=device)
         self.decoder = VQDecoder(ddconfig, embed_dim, device=device)
         self.device = torch.device(device)
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
+
+    def init_from_ckpt(self, path, ignore_keys=()):
+        """autoencoder.py:78-91 through the safe loader of checkpoint.py."""
+        from .checkpoint import load_vae_checkpoint
+
+        sd = {k: v for k, v in load_vae_checkpoint(path).items() if not any(k.startswith(ik) for ik in ignore_keys)}
+        self.load_state_dict(sd, strict=False)
+        return self
 
     def eval(self):
         return self

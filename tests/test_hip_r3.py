@@ -209,3 +209,47 @@ def test_prediction_helpers_and_guided_ddim(golden_guided):
     assert rel_l2(y, b["y_noguide"]) < LOOP_TOL
     assert bool(torch.isfinite(d.ddim_sample_guided(b["shape"], guide=b["guide"], mask=b["mask"])).all())  # device noise
 
+
+def test_conditional_interpolate_and_vqmodel_ckpt_path(tmp_path):
+    """``interpolate`` of the text- / image-conditional classes (positional order x1, x2, t, text_emb | cond, lam;
+    denoising_diffusion_text_conditional.py:456-473, denoising_diffusion_image_conditional.py:232-249) against the oracle's
+    loop with the condition closed over, and ``VQModel(ddconfig, lossconfig, n_embed, embed_dim, ckpt_path, ignore_keys)``
+    (autoencoder.py:15-31, :78-91) loading a Lightning-style checkpoint."""
+    cfg = UnetConfig(dim=64, dim_mults=(1, 2), channels=3, text_condition=True)
+    u, sd = _unet(cfg, 33)
+    d = dm.TextConditionalDenoisingDiffusion(model=u, image_size=16, timesteps=50)
+    g = torch.Generator().manual_seed(9)
+    x1, x2 = torch.rand((2, 3, 16, 16), generator=g) * 2 - 1, torch.rand((2, 3, 16, 16), generator=g) * 2 - 1
+    emb = torch.randn((2, 512), generator=g)
+    sched = dm.make_schedule(50, "linear")
+    with torch.inference_mode():
+        want = so.interpolate(lambda x, t: uo.unet_forward(sd, cfg, x, t, text_emb=emb), sched, x1, x2, 12, 0.3, so.NoiseStream(77))
+    got = d.interpolate(x1, x2, 12, emb, 0.3, noise=so.NoiseStream(77)).cpu()
+    err = rel_l2(got, want)
+    print("text-conditional interpolate", err)
+    assert err < LOOP_TOL
+    icfg = UnetConfig(dim=64, dim_mults=(1, 2), channels=3, cond_channels=3)
+    isd = dm.synth_state_dict(dm.unet_param_spec(icfg), salt=34)
+    iu = dm.Unet(dim=64, dim_mults=(1, 2), channels=3, cond_channels=3, device=DEV)
+    iu.load_state_dict(isd)
+    di = dm.ImageConditionalDenoisingDiffusion(iu, image_size=16, timesteps=50)
+    cond = torch.rand((2, 3, 16, 16), generator=g)
+    with torch.inference_mode():
+        want = so.interpolate(lambda x, t: uo.unet_forward(isd, icfg, x, t, cond=cond), sched, x1, x2, 12, 0.3, so.NoiseStream(78))
+    got = di.interpolate(x1, x2, 12, cond, 0.3, noise=so.NoiseStream(78)).cpu()
+    err = rel_l2(got, want)
+    print("image-conditional interpolate", err)
+    assert err < LOOP_TOL
+    # VQModel from a checkpoint file, reference argument order
+    ddc = dict(ch=64, out_ch=3, in_channels=3, ch_mult=(1, 2), num_res_blocks=2, attn_resolutions=(), resolution=32,
+               z_channels=3, double_z=False)
+    vsd = dm.synth_state_dict(encoder_param_spec(EncoderConfig(n_embed=8192)) + dm.decoder_param_spec(DecoderConfig()), salt=21)
+    extra = dict(vsd, **{"loss.discriminator.main.0.weight": torch.zeros(3)})
+    path = tmp_path / "vq.ckpt"
+    torch.save({"state_dict": extra}, str(path))
+    a = dm.VQModel(ddc, None, 8192, 3, str(path), ["loss"], device=DEV)
+    b = dm.VQModel(ddc, n_embed=8192, embed_dim=3, device=DEV)
+    b.load_state_dict(vsd)
+    z = torch.randn((2, 3, 16, 16), generator=g)
+    assert torch.equal(a.decode(z), b.decode(z))
+

@@ -174,7 +174,7 @@ def test_method_surface_of_the_mirrored_classes():
     with open(os.path.join(os.path.dirname(__file__), "golden", "api_surface.json")) as f:
         want = json.load(f)
     out_of_scope = {"VQModel": {"_validation_step", "configure_optimizers", "decode_code", "ema_scope", "get_input",
-                                "get_last_layer", "init_from_ckpt", "log_images", "on_train_batch_end", "to_rgb",
+                                "get_last_layer", "log_images", "on_train_batch_end", "to_rgb",
                                 "training_step", "validation_step"}}
     for cls, names in want.items():
         ours = set(dir(getattr(dm, cls)))
