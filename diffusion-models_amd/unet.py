@@ -312,7 +312,21 @@ class Unet:
         t = t.to(device=self.device, dtype=torch.float32).contiguous()
         return t, t.shape[1]
 
-    def forward(self, x, time, x_self_cond=None, text_emb=None, cond=None):
+    def forward(self, x, time, *args, x_self_cond=None, text_emb=None, cond=None):
+        """One class stands for the reference's three ``Unet`` classes, whose positional orders differ:
+        ``forward(x, time, x_self_cond)`` (denoising_diffusion.py:349), ``forward(x, time, text_emb, x_self_cond)`` for the
+        text-conditional one (denoising_diffusion_text_conditional.py:131) and keyword-only ``cond`` / ``x_self_cond`` for
+        the image-conditional one (denoising_diffusion_image_conditional.py:51).  Extra positional arguments are read in
+        the order of the variant this object was built as."""
+        if args:
+            order = ("text_emb", "x_self_cond") if self.text_condition else ("x_self_cond",)
+            assert self.cfg.cond_channels == 0, "the image-conditional Unet takes cond / x_self_cond by keyword only"
+            assert len(args) <= len(order), "too many positional arguments"
+            given = dict(x_self_cond=x_self_cond, text_emb=text_emb)
+            for name, val in zip(order, args):
+                assert given[name] is None, f"{name} given twice"
+                given[name] = val
+            x_self_cond, text_emb = given["x_self_cond"], given["text_emb"]
         if not self._loaded:
             raise RuntimeError("load_state_dict() must be called before forward()")
         f = self.downsample_factor

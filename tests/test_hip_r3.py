@@ -88,6 +88,8 @@ def test_ldm_coco_text_shapes(golden_r3):
     err = rel_l2(u(b["x"], b["t"], text_emb=b["ctx"]).cpu(), b["y"])
     print("unet_text_full_8", err)
     assert err < FWD_TOL
+    # the text-conditional Unet's positional order is (x, time, text_emb, x_self_cond)
+    assert torch.equal(u(b["x"], b["t"], b["ctx"]), u(b["x"], b["t"], text_emb=b["ctx"]))
     d = dm.TextConditionalDenoisingDiffusion(model=u, image_size=8, timesteps=1000, sampling_timesteps=4,
                                              auto_normalize=False)
     b = golden_r3["text8_ddim4"]
