@@ -19,6 +19,7 @@ from .diffusion import (  # noqa: F401
     ImageConditionalDenoisingDiffusion,
     ImageConditionalLatentDiffusion,
     LatentDiffusion,
+    ModelPrediction,
     TextConditionalDenoisingDiffusion,
     TextConditionalLatentDiffusion,
 )
