@@ -64,31 +64,49 @@ class EMA:
         return out
 
     def load_state_dict(self, sd):
-        self.initted = bool(sd["initted"])
-        self.step = int(sd["step"])
+        """``ema.load_state_dict(data['ema'])`` as ``Trainer.load`` (:1127) and the sampling scripts
+        (denoising-diffusion-pytorch/sampling.py:157-159) call it.  On a model in training mode the averaged parameters go
+        into the device-resident EMA state; on an inference-only model (the sampling scripts) they go straight into
+        ``ema_model``, which is then ready to sample."""
+        self.initted = bool(sd["initted"]) if "initted" in sd else True
+        self.step = int(sd["step"]) if "step" in sd else 1
         pre = "ema_model.model."
-        if self.step > 0:
-            self.online_model.model.load_ema_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
-        self._ema_model_step = -1
+        averaged = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        if not averaged:
+            raise KeyError(f"state dict has no '{pre}*' entries")
+        if getattr(self.online_model.model, "_training", False):
+            if self.step > 0:
+                self.online_model.model.load_ema_state_dict(averaged)
+            self._ema_model_step = -1
+        else:
+            self._make_ema_model().model.load_state_dict(averaged)
+            self._ema_model_step = self.step
         return self
 
-    @property
-    def ema_model(self):
-        """A sampler holding the EMA weights (a second U-Net handle, refreshed when the EMA state has moved on)."""
-        from .diffusion import DenoisingDiffusion
+    def _make_ema_model(self):
+        """A shallow copy of the online diffusion object (same class, schedule, VAE, options) around a second U-Net handle
+        of the same variant -- what ``copy.deepcopy(model)`` is to ``ema_pytorch.EMA``."""
+        import copy
+
         from .unet import Unet
 
         d = self.online_model
         if self._ema_model is None:
             cfg = d.model.cfg
             unet = Unet(dim=cfg.dim, init_dim=cfg.init_dim, out_dim=cfg.out_dim, dim_mults=cfg.dim_mults, channels=cfg.channels,
-                        sinusoidal_pos_emb_theta=cfg.sinusoidal_pos_emb_theta, attn_dim_head=cfg.attn_dim_head,
-                        attn_heads=cfg.attn_heads, full_attn=cfg.full_attn, device=d.device)
-            self._ema_model = DenoisingDiffusion(
-                unet, image_size=d.image_size, timesteps=d.num_timesteps,
-                sampling_timesteps=d.sampling_timesteps if d.is_ddim_sampling else None, objective=d.objective,
-                ddim_sampling_eta=d.ddim_sampling_eta, auto_normalize=bool(d._unnormalize_flag), use_graph=d.use_graph)
-            self._ema_model._sched = d._sched
+                        self_condition=cfg.self_condition, sinusoidal_pos_emb_theta=cfg.sinusoidal_pos_emb_theta,
+                        attn_dim_head=cfg.attn_dim_head, attn_heads=cfg.attn_heads, full_attn=cfg.full_attn,
+                        text_condition=cfg.text_condition, text_emb_dim=cfg.text_emb_dim, use_cross_attn=cfg.use_cross_attn,
+                        cond_channels=cfg.cond_channels, device=d.device)
+            self._ema_model = copy.copy(d)
+            self._ema_model.model = unet
+        return self._ema_model
+
+    @property
+    def ema_model(self):
+        """A sampler holding the EMA weights (a second U-Net handle, refreshed when the EMA state has moved on)."""
+        d = self.online_model
+        self._make_ema_model()
         if self._ema_model_step != self.step:
             if self.step == 0:
                 raise RuntimeError("EMA.update() has not run yet")

@@ -254,6 +254,21 @@ def test_checkpoint_round_trip_and_torch_adam_reads_the_optimiser_state(tmp_path
         diff = [k for k in a if not torch.equal(a[k], b[k])]
         assert not diff, (which, diff[:3])
     assert d2.model._lib.dm_unet_adam_step(d2.model._handle, -1) == 3
+    # the sampling scripts' use (sampling.py:157-159): an inference-only object, EMA(...).load_state_dict(data['ema']),
+    # ema.ema_model.sample(...) -- the same images as the EMA model of the run that wrote the file
+    from oracle import sampler_oracle as so
+
+    u3 = dm.Unet(dim=cfg.dim, dim_mults=cfg.dim_mults, channels=3, device=DEV)
+    u3.load_state_dict(initial)
+    d3 = dm.DenoisingDiffusion(u3, image_size=16, timesteps=1000, sampling_timesteps=2)
+    ema3 = dm.EMA(d3, beta=0.995, update_every=1)
+    ema3.load_state_dict(data["ema"])
+    ema3.ema_model.eval()
+    ema_fresh = dm.EMA(d2, beta=0.995, update_every=1, update_after_step=0)
+    ema_fresh.load_state_dict(data["ema"])  # training-mode object: into the device-resident EMA state
+    a3 = ema3.ema_model.ddim_sample((2, 3, 16, 16), sampling_timesteps=2, noise=so.NoiseStream(4))
+    b3 = ema_fresh.ema_model.ddim_sample((2, 3, 16, 16), sampling_timesteps=2, noise=so.NoiseStream(4))
+    assert torch.equal(a3, b3) and bool(torch.isfinite(a3).all())
     # (3) the host copies of `d` still hold the initial weights; loading them back must reach the device all the same
     d.model.load_state_dict(initial)
     back = d.model.state_dict()
