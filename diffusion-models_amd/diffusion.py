@@ -124,6 +124,21 @@ class DenoisingDiffusion:
     def eval(self):
         return self
 
+    def to(self, device=None, *args, **kwargs):
+        """``module.to(device)`` of the reference's scripts: the handle was created on its device (``device=`` of the
+        constructor) and cannot move; the same device (or a dtype / no device) is accepted and ignored."""
+        if isinstance(device, (str, torch.device)) and torch.device(device).type == "cuda":
+            want = torch.device(device)
+            have = torch.device(self.device)
+            if want.index is not None and want.index != (have.index or 0):
+                raise RuntimeError(f"this object lives on {have}; construct it with device={want!s}")
+        elif isinstance(device, (str, torch.device)) and torch.device(device).type != "cuda":
+            raise RuntimeError("the HIP path has no CPU fallback")
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else f"cuda:{device}" if isinstance(device, int) else device)
+
     def sample_shape(self):
         """(C, H, W) of one sample as ``sample()`` returns it (``dist.sample_global`` builds empty shards from it)."""
         (h, w), c = self.image_size, self.channels

@@ -114,6 +114,21 @@ class Unet:
     def param_spec(self):
         return unet_param_spec(self.cfg)
 
+    def to(self, device=None, *args, **kwargs):
+        """``module.to(device)`` of the reference's scripts: the handle was created on its device (``device=`` of the
+        constructor) and cannot move; the same device (or a dtype / no device) is accepted and ignored."""
+        if isinstance(device, (str, torch.device)) and torch.device(device).type == "cuda":
+            want = torch.device(device)
+            have = torch.device(self.device)
+            if want.index is not None and want.index != (have.index or 0):
+                raise RuntimeError(f"this object lives on {have}; construct it with device={want!s}")
+        elif isinstance(device, (str, torch.device)) and torch.device(device).type != "cuda":
+            raise RuntimeError("the HIP path has no CPU fallback")
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else f"cuda:{device}" if isinstance(device, int) else device)
+
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
         """Accepts ``Unet.state_dict()`` of the reference (same names, OIHW / [out,in] layouts).
 

@@ -364,3 +364,16 @@ def test_image_conditional_latent_diffusion():
     print("imgcond latent", err)
     assert err < LOOP_TOL
 
+
+def test_module_like_to_and_cuda():
+    """``.to(device)`` / ``.cuda()`` / ``.eval()`` as the reference's scripts chain them: accepted on the object's own device,
+    refused elsewhere (no CPU fallback, no silent move)."""
+    u = dm.Unet(dim=64, dim_mults=(1, 2), channels=3, device=DEV)
+    assert u.to(DEV) is u and u.to("cuda") is u and u.cuda() is u and u.to(torch.float32) is u
+    d = dm.DenoisingDiffusion(u, image_size=16, timesteps=10)
+    assert d.to(torch.device(DEV)).eval() is d and d.cuda(0) is d
+    with pytest.raises(RuntimeError):
+        u.to("cpu")
+    with pytest.raises(RuntimeError):
+        d.to("cuda:5")
+
