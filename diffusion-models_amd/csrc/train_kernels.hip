@@ -36,6 +36,7 @@ struct NormBwdParams {
     const float* g;
     const float* ss;   // scale = ss[b * ss_stride + c], shift = ss[b * ss_stride + C + c]; nullptr: none
     float* du;
+    const float* add;  // optional: du = (gradient through the norm) + add (the residual branch of `attn(x) + x`)
     float* part;       // [B][chunks][4][C]: dg, dbias, dscale, dshift
     int C, C4, LPR, NV, ss_stride, flags;
     int pix_per_image, rows_per_chunk, chunks;
@@ -144,7 +145,10 @@ __global__ __launch_bounds__(256) void norm_act_bwd_kernel(const NormBwdParams p
                 op[j] = (dnp[j] - np[j] * dot) * rinv;
                 ab[j] += op[j];
             }
-            if (cv[v] && rv) *reinterpret_cast<f32x4*>(p.du + base + 4 * (sub + LPR * v)) = o;
+            if (cv[v] && rv) {
+                if (p.add) o += *reinterpret_cast<const f32x4*>(p.add + base + 4 * (sub + LPR * v));
+                *reinterpret_cast<f32x4*>(p.du + base + 4 * (sub + LPR * v)) = o;
+            }
         }
     }
     // ---- combine the row groups of the workgroup in a fixed order
@@ -164,6 +168,84 @@ __global__ __launch_bounds__(256) void norm_act_bwd_kernel(const NormBwdParams p
         float s = 0.f;
         for (int gi = 0; gi < groups; ++gi) s += red[(size_t)gi * 4 * p.C + i];
         p.part[((size_t)b * p.chunks + chunk) * 4 * p.C + i] = s;
+    }
+}
+
+// The forward of the same Block in training mode with dropout, in one pass over the rows (the sampling path's landing kernel
+// followed by dropout_kernel otherwise):  y = dropout(silu(norm(u) * g * sqrt(C) * (scale + 1) + shift)) [+ residual].
+// Same row mapping as norm_act_bwd_kernel; the mask is the one dropout_kernel / norm_act_bwd_kernel form from
+// (seed, stream, flat float4 index).  grid (chunks, B).
+struct NormFwdParams {
+    const float* u;
+    const float* g;
+    const float* ss;
+    const float* residual;
+    float* y;
+    int C, C4, LPR, ss_stride, flags, pix_per_image, rows_per_chunk;
+    float drop_p, drop_inv_keep;
+    uint64_t drop_seed, drop_stream;
+};
+template <int NV>
+__global__ __launch_bounds__(256) void norm_act_drop_kernel(const NormFwdParams p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int LPR = p.LPR, RPW = 64 / LPR;
+    const int sub = lane % LPR, rg = lane / LPR;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int row_lo = chunk * p.rows_per_chunk, row_hi = min(row_lo + p.rows_per_chunk, p.pix_per_image);
+    const float sqrtC = sqrtf((float)p.C);
+    const bool has_ss = p.ss != nullptr && (p.flags & EPI_SCALE_SHIFT);
+    f32x4 gq[NV], sc[NV], sh[NV];
+    bool cv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c4 = sub + LPR * v;
+        cv[v] = c4 < p.C4;
+        const f32x4 z = make_f32x4(0.f, 0.f, 0.f, 0.f), one = make_f32x4(1.f, 1.f, 1.f, 1.f);
+        gq[v] = (cv[v] && p.g) ? *reinterpret_cast<const f32x4*>(p.g + 4 * c4) : one;
+        sc[v] = (cv[v] && has_ss) ? *reinterpret_cast<const f32x4*>(p.ss + (size_t)b * p.ss_stride + 4 * c4) : z;
+        sh[v] = (cv[v] && has_ss) ? *reinterpret_cast<const f32x4*>(p.ss + (size_t)b * p.ss_stride + p.C + 4 * c4) : z;
+    }
+    for (int r0 = row_lo + wave * RPW; r0 < row_hi; r0 += 4 * RPW) {
+        const int r = r0 + rg;
+        const bool rv = r < row_hi;
+        const size_t base = ((size_t)b * p.pix_per_image + (rv ? r : row_lo)) * p.C;
+        f32x4 uv[NV];
+        float ssq = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            uv[v] = (cv[v] && rv) ? *reinterpret_cast<const f32x4*>(p.u + base + 4 * (sub + LPR * v)) : make_f32x4(0.f, 0.f, 0.f, 0.f);
+            ssq += uv[v].x * uv[v].x + uv[v].y * uv[v].y + uv[v].z * uv[v].z + uv[v].w * uv[v].w;
+        }
+        for (int m = 1; m < LPR; m <<= 1) ssq += __shfl_xor(ssq, m);
+        const float rinv = 1.0f / fmaxf(sqrtf(ssq), 1e-12f);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c4 = sub + LPR * v;
+            f32x4 o;
+            float* op = reinterpret_cast<float*>(&o);
+            const float* un = reinterpret_cast<const float*>(&uv[v]);
+            const float* gg = reinterpret_cast<const float*>(&gq[v]);
+            const float* s1 = reinterpret_cast<const float*>(&sc[v]);
+            const float* s2 = reinterpret_cast<const float*>(&sh[v]);
+            uint32_t c[4] = {0, 0, 0, 0};
+            if (p.drop_p > 0.f) {
+                const uint64_t i4 = (uint64_t)(base >> 2) + c4;
+                c[0] = (uint32_t)i4; c[1] = (uint32_t)(i4 >> 32); c[2] = (uint32_t)p.drop_stream; c[3] = (uint32_t)(p.drop_stream >> 32);
+                philox4(c, (uint32_t)p.drop_seed, (uint32_t)(p.drop_seed >> 32));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float w = un[j] * rinv * gg[j] * sqrtC;
+                const float val = has_ss ? w * (s1[j] + 1.0f) + s2[j] : w;
+                float a = val / (1.0f + __expf(-val));
+                if (p.drop_p > 0.f) a = ((float)c[j] * 2.3283064365386963e-10f >= p.drop_p) ? a * p.drop_inv_keep : 0.f;
+                op[j] = a;
+            }
+            if (cv[v] && rv) {
+                if (p.residual) o += *reinterpret_cast<const f32x4*>(p.residual + base + 4 * c4);
+                *reinterpret_cast<f32x4*>(p.y + base + 4 * c4) = o;
+            }
+        }
     }
 }
 
@@ -302,12 +384,12 @@ size_t norm_act_bwd_ws_floats(int B, int pix_per_image, int C) {
 int launch_norm_act_bwd(const float* dy, const float* u, const float* g, const float* ss, int ss_stride, int pix_per_image,
                         float* du, float* ws, float* dg, float* dbias, float* dss, int dss_stride, int B, int C, int flags,
                         int accumulate, hipStream_t s, RowgradJob* defer, float drop_p, uint64_t drop_seed,
-                        uint64_t drop_stream) {
+                        uint64_t drop_stream, const float* add) {
     DM_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "norm_act_bwd: C must be a multiple of 4, at most 1024");
     DM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "norm_act_bwd: dropout probability");
     NormBwdParams p{};
     p.drop_p = drop_p; p.drop_inv_keep = 1.0f / (1.0f - drop_p); p.drop_seed = drop_seed; p.drop_stream = drop_stream;
-    p.dy = dy; p.u = u; p.g = g; p.ss = ss; p.du = du; p.part = ws;
+    p.dy = dy; p.u = u; p.g = g; p.ss = ss; p.du = du; p.part = ws; p.add = add;
     p.C = C; p.C4 = C / 4;
     p.LPR = std::min(64, pow2ceil(p.C4));
     p.NV = (p.C4 + p.LPR - 1) / p.LPR;
@@ -335,6 +417,32 @@ int launch_norm_act_bwd(const float* dy, const float* u, const float* g, const f
                        (flags & EPI_SCALE_SHIFT) ? dss : nullptr, dss_stride, img);
     DM_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(rowgrad_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, s, img, B, C, dg, dbias, accumulate);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// RMSNorm -> (scale + 1, shift) -> SiLU -> dropout [+ residual] of a training-mode Block: u, y, residual [B * pix][C]
+int launch_norm_act_drop(const float* u, const float* g, const float* ss, int ss_stride, int pix_per_image, const float* residual,
+                         float* y, int B, int C, int flags, float drop_p, uint64_t drop_seed, uint64_t drop_stream, hipStream_t s) {
+    DM_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "norm_act_drop: C must be a multiple of 4, at most 1024");
+    DM_REQUIRE((flags & EPI_NORM) && (flags & EPI_SILU) && drop_p >= 0.f && drop_p < 1.f, "norm_act_drop: a Block's epilogue");
+    NormFwdParams p{};
+    p.u = u; p.g = g; p.ss = ss; p.residual = residual; p.y = y;
+    p.C = C; p.C4 = C / 4;
+    p.LPR = std::min(64, pow2ceil(p.C4));
+    const int NV = (p.C4 + p.LPR - 1) / p.LPR;
+    p.ss_stride = ss_stride; p.flags = flags; p.pix_per_image = pix_per_image;
+    int chunks = std::max(1, std::min(pix_per_image / 16, (1024 + B - 1) / B));
+    p.rows_per_chunk = (pix_per_image + chunks - 1) / chunks;
+    chunks = (pix_per_image + p.rows_per_chunk - 1) / p.rows_per_chunk;
+    p.drop_p = drop_p; p.drop_inv_keep = 1.0f / (1.0f - drop_p); p.drop_seed = drop_seed; p.drop_stream = drop_stream;
+    const dim3 grid(chunks, B);
+    switch (NV) {
+        case 1: hipLaunchKernelGGL(norm_act_drop_kernel<1>, grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL(norm_act_drop_kernel<2>, grid, dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL(norm_act_drop_kernel<3>, grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL(norm_act_drop_kernel<4>, grid, dim3(256), 0, s, p); break;
+    }
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
