@@ -1077,7 +1077,12 @@ int launch_mse_loss(const float* out, const float* x_start, const float* noise, 
 __global__ void sumsq_partial_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ part) {
     __shared__ double red[256];
     double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += (double)x[i] * x[i];
+    const int64_t n4 = n >> 2;  // 16-byte loads (the flat gradient buffer is 256-byte aligned), then the tail
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        s += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) s += (double)x[4 * n4 + threadIdx.x] * x[4 * n4 + threadIdx.x];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int m = 128; m > 0; m >>= 1) {
@@ -1087,19 +1092,31 @@ __global__ void sumsq_partial_kernel(const float* __restrict__ x, int64_t n, dou
     if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 // total_norm = sqrt(sum); clip coefficient = min(1, max_norm / (total_norm + 1e-6))  (torch.nn.utils.clip_grad_norm_)
-__global__ void clip_coef_kernel(const double* __restrict__ part, int nparts, float max_norm, float* __restrict__ out2) {
+// One wave: lane l adds the partial sums l, l + 64, ... in order, the 64 lane sums meet in a fixed tree (a single thread
+// walking 1024 dependent loads took 53 us).
+__global__ __launch_bounds__(64) void clip_coef_kernel(const double* __restrict__ part, int nparts, float max_norm,
+                                                       float* __restrict__ out2) {
+    __shared__ double red[64];
     double s = 0.0;
-    for (int i = 0; i < nparts; ++i) s += part[i];
-    const float norm = (float)sqrt(s);
-    out2[0] = norm;
-    out2[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (norm + 1e-6f)) : 1.0f;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 32; m > 0; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(red[0]);
+        out2[0] = norm;
+        out2[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (norm + 1e-6f)) : 1.0f;
+    }
 }
 int launch_grad_norm(const float* grads, int64_t n, double* part_ws /* 1024 doubles */, float max_norm, float* out2,
                      hipStream_t s) {
     const int nb = (int)std::min<int64_t>(1024, (n + 255) / 256);
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, grads, n, part_ws);
     DM_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, s, part_ws, nb, max_norm, out2);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, s, part_ws, nb, max_norm, out2);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
