@@ -276,6 +276,33 @@ def test_checkpoint_round_trip_and_torch_adam_reads_the_optimiser_state(tmp_path
     assert not torch.equal(trained[names[0]].cpu(), initial[names[0]])
 
 
+def test_training_calls_on_different_streams_are_ordered():
+    """loss + backward on one stream, the optimiser step (asynchronous: no host read-back requested by ema / re-pack) on
+    another, three iterations: the handle orders the calls through its event, the parameters equal the single-stream run's
+    bit for bit."""
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3)
+    g = torch.Generator().manual_seed(21)
+    batches = [torch.rand((4, 3, 16, 16), generator=g) for _ in range(3)]
+    ts = [torch.randint(0, 1000, (4,), generator=g) for _ in range(3)]
+    noises = [torch.randn((4, 3, 16, 16), generator=g) for _ in range(3)]
+
+    def run(streams):
+        d = _model(cfg, 41, "pred_noise", 1000)
+        for i in range(3):
+            with torch.cuda.stream(streams[0]):
+                d.p_losses(d.normalize(batches[i].to(DEV)), ts[i], noise=noises[i])
+            with torch.cuda.stream(streams[1]):
+                d.model.optimizer_step(lr=1e-3)
+                d.model.ema_update(0.9, copy=i == 0)
+        torch.cuda.synchronize()
+        return d.model.state_dict(), d.model.state_dict(ema=True)
+
+    s0 = torch.cuda.current_stream(DEV)
+    want, want_ema = run((s0, s0))
+    got, got_ema = run((torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)))
+    assert all(torch.equal(want[k], got[k]) for k in want) and all(torch.equal(want_ema[k], got_ema[k]) for k in want_ema)
+
+
 def _block_shapes(cfg, side):
     """(C, H, W) of every Block output in the order Unet.forward runs them (two per ResnetBlock)."""
     dims = cfg.dims
