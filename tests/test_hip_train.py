@@ -399,6 +399,34 @@ def test_image_conditional_training_step_vs_oracle():
     assert worst[0] < GRAD_TOL
 
 
+@pytest.mark.parametrize("shape", [(24, 24), (20, 12), (8, 8)])
+def test_training_step_at_other_image_sizes_vs_oracle(shape):
+    """Loss and every gradient against the oracle's autograd on images that are not powers of two: 24x24 (stages 24, 12, 6),
+    20x12 (non-square; a 5x3 bottleneck: odd maps take the direct weight-gradient kernel, even ones the Winograd-domain one)
+    and 8x8 (a 2x2 bottleneck: several whole images per pixel block), B = 3."""
+    from oracle import train_oracle as to
+
+    H, W = shape
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2, 4), channels=3)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=11)
+    u = dm.Unet(dim=32, dim_mults=(1, 2, 4), channels=3, device=DEV)
+    u.load_state_dict(sd)
+    d = dm.DenoisingDiffusion(u, image_size=(H, W), timesteps=1000).train()
+    g = torch.Generator().manual_seed(H * 100 + W)
+    B = 3
+    x_start = torch.rand((B, 3, H, W), generator=g) * 2 - 1
+    t = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.randn((B, 3, H, W), generator=g)
+    loss = float(d.p_losses(x_start, t, noise=noise))
+    torch.set_num_threads(8)
+    want_loss, want = to.loss_and_grads(sd, cfg, dm.make_schedule(1000, "linear"), x_start, t, noise)
+    assert abs(loss - want_loss) <= 1e-5 * abs(want_loss)
+    got = d.model.grads()
+    worst = max((rel_l2(got[k].cpu(), want[k]), k) for k in want)
+    print(shape, "worst gradient", worst)
+    assert worst[0] < GRAD_TOL
+
+
 @pytest.mark.parametrize("use_prediction", [False, True])
 def test_self_conditioned_training_step_vs_oracle(use_prediction):
     """Unet(self_condition=True): p_losses conditions on zeros or (half of the iterations, :846-855) on the x_start a
