@@ -16,8 +16,9 @@
 // instead of per 3x3 kernel: the chip is filled with a third of the splits, i.e. a third of the partial-sum traffic (which
 // was 38 MB per layer, written and read back), for three times the (cheap) staging.
 //
-// Modes: 3x3 / pad 1 (optionally on a nearest-x2 upsampled source: Upsample :48-52), 1x1, and the 2x2 / stride 2 form of
-// Downsample (:54-58; weight index c*4 + p1*2 + p2).  Inputs may be the channel concatenation of two tensors (the up
+// Modes: 0 3x3 / pad 1 (optionally on a nearest-x2 upsampled source: Upsample :48-52), 1 1x1, 2 the 2x2 / stride 2 form of
+// Downsample (:54-58; weight index c*4 + p1*2 + p2), 3 the 3x3 form in the Winograd domain (wgrad_wino_kernel below: what
+// the training step uses on even image sizes).  GROUPED instantiations run a table of layers in one launch.  Inputs may be the channel concatenation of two tensors (the up
 // path's torch.cat).  Channel counts must be multiples of 4; everything else (7x7 first conv over the NCHW image,
 // final_conv with 3 outputs) goes through wgrad_naive_kernel.
 #include "conv_device.h"
