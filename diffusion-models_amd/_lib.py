@@ -19,7 +19,7 @@ ABI_VERSION = 3
 # every symbol include/dm_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
     "dm_last_error", "dm_abi_version",
-    "dm_unet_create", "dm_unet_destroy", "dm_unet_set_param", "dm_unet_missing_params", "dm_unet_finalize",
+    "dm_unet_create", "dm_unet_destroy", "dm_unet_set_param", "dm_unet_missing_params", "dm_unet_get_param_host", "dm_unet_finalize",
     "dm_unet_update_param", "dm_unet_refresh", "dm_unet_graph_captures", "dm_unet_workspace_bytes",
     "dm_unet_forward", "dm_sample", "dm_sample_cond", "dm_sample_ex", "dm_randn",
     "dm_decoder_create", "dm_decoder_destroy", "dm_decoder_set_param", "dm_decoder_missing_params",
@@ -103,6 +103,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_unet_set_param.argtypes = [vp, C.c_char_p, fp, C.POINTER(i64), i32]
     lib.dm_unet_missing_params.argtypes = [vp]
     lib.dm_unet_finalize.argtypes = [vp]
+    lib.dm_unet_get_param_host.argtypes = [vp, C.c_char_p, vp, i64]
     lib.dm_unet_forward.argtypes = [vp, fp, vp, fp, i32, fp, i32, i32, i32, vp]
     lib.dm_unet_update_param.argtypes = [vp, C.c_char_p, fp, C.POINTER(i64), i32]
     lib.dm_unet_refresh.argtypes = [vp]

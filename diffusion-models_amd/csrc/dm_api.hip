@@ -1507,6 +1507,20 @@ int dm_unet_missing_params(dm_unet* u) {
     return missing;
 }
 
+/* read back the handle's host copy of one parameter (what dm_unet_set_param / dm_unet_update_param stored; after
+ * dm_unet_train_sync: the trained values) */
+int dm_unet_get_param_host(dm_unet* u, const char* name, float* out_host, int64_t n) {
+    DM_REQUIRE(u && name && out_host, "null argument");
+    auto it = u->params.find(name);
+    if (it == u->params.end() || !it->second.set) {
+        set_error(std::string("unknown or unset parameter: ") + name);
+        return 1;
+    }
+    DM_REQUIRE((int64_t)it->second.numel() == n, "dm_unet_get_param_host: element count mismatch");
+    std::memcpy(out_host, it->second.data.data(), (size_t)n * sizeof(float));
+    return 0;
+}
+
 int dm_unet_finalize(dm_unet* u) {
     DM_REQUIRE(u, "null handle");
     DM_REQUIRE(!u->finalized, "already finalized");

@@ -139,6 +139,13 @@ class DenoisingDiffusion:
     def cuda(self, device=None):
         return self.to("cuda" if device is None else f"cuda:{device}" if isinstance(device, int) else device)
 
+    def parameters(self):
+        """The U-Net's parameters (and the frozen VAE's, for the LDM classes, when it exposes them), as the scripts count them."""
+        yield from self.model.parameters()
+        vae = getattr(self, "vae", None)
+        if vae is not None and hasattr(vae, "parameters"):
+            yield from vae.parameters()
+
     def sample_shape(self):
         """(C, H, W) of one sample as ``sample()`` returns it (``dist.sample_global`` builds empty shards from it)."""
         (h, w), c = self.image_size, self.channels

@@ -230,8 +230,25 @@ class Unet:
     def state_dict(self, ema: bool = False) -> Dict[str, torch.Tensor]:
         """The trained parameters (reference names / shapes) from the device-resident state; ``ema=True``: the EMA copy."""
         if not getattr(self, "_training", False):
-            raise RuntimeError("state_dict() reads the device-resident training state: call train() first")
+            if ema:
+                raise RuntimeError("state_dict(ema=True) reads the device-resident training state: call train() first")
+            if not self._loaded:
+                raise RuntimeError("state_dict() before load_state_dict()")
+            out = {}
+            for name, shape in self.param_spec():  # the handle's host copies
+                t = torch.empty(tuple(shape), dtype=torch.float32)
+                _lib.check(self._lib.dm_unet_get_param_host(self._handle, name.encode(), t.data_ptr(), t.numel()))
+                out[name] = t.to(self.device)
+            return out
         return self._train_tensors(1 if ema else 0)
+
+    def named_parameters(self):
+        """(name, tensor) in the reference's ``parameters()`` order: copies of the current values (the scripts count them:
+        ``sum(p.numel() for p in model.parameters())``, latent-diffusion/train/train_ldm.py:104)."""
+        return iter(self.state_dict().items())
+
+    def parameters(self):
+        return iter(self.state_dict().values())
 
     def _train_tensors(self, which: int) -> Dict[str, torch.Tensor]:
         stream = torch.cuda.current_stream(self.device).cuda_stream

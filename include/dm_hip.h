@@ -71,6 +71,9 @@ void dm_unet_destroy(dm_unet* u);
 int dm_unet_set_param(dm_unet* u, const char* name, const float* data_host, const int64_t* shape, int ndim);
 /* number of parameters still missing (0 = complete) */
 int dm_unet_missing_params(dm_unet* u);
+/* read back the handle's host copy of one parameter (n = its element count): `Unet.state_dict()` / `.parameters()` of a
+ * handle that is not in training mode (a training handle reads its device-resident state: dm_unet_get_param) */
+int dm_unet_get_param_host(dm_unet* u, const char* name, float* out_host, int64_t n);
 /* repack weights into kernel layouts and upload; must follow the last set_param */
 int dm_unet_finalize(dm_unet* u);
 

@@ -365,6 +365,23 @@ def test_image_conditional_latent_diffusion():
     assert err < LOOP_TOL
 
 
+def test_state_dict_and_parameters_of_an_inference_handle():
+    """``state_dict()`` / ``parameters()`` / ``named_parameters()`` without training mode: the values that were loaded, in the
+    reference's parameter order; ``sum(p.numel() ...)`` as the training scripts print it."""
+    cfg = UnetConfig(dim=64, dim_mults=(1, 2), channels=3)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=3)
+    u = dm.Unet(dim=64, dim_mults=(1, 2), channels=3, device=DEV)
+    with pytest.raises(RuntimeError):
+        u.state_dict()
+    u.load_state_dict(sd)
+    got = u.state_dict()
+    assert list(got) == [n for n, _ in dm.unet_param_spec(cfg)] and all(torch.equal(got[k].cpu(), sd[k]) for k in sd)
+    n = sum(p.numel() for p in u.parameters())
+    assert n == sum(v.numel() for v in sd.values()) and [k for k, _ in u.named_parameters()] == list(got)
+    d = dm.DenoisingDiffusion(u, image_size=16, timesteps=10)
+    assert sum(p.numel() for p in d.parameters()) == n
+
+
 def test_module_like_to_and_cuda():
     """``.to(device)`` / ``.cuda()`` / ``.eval()`` as the reference's scripts chain them: accepted on the object's own device,
     refused elsewhere (no CPU fallback, no silent move)."""
