@@ -153,7 +153,12 @@ class DenoisingDiffusion:
         return tuple(vae.decoded_shape((c, h, w))) if vae is not None else (c, h, w)
 
     def state_dict(self):
-        return {k: getattr(self, k) for k in SCHEDULE_BUFFERS}
+        """``DenoisingDiffusion.state_dict()`` of the reference module: the 13 schedule buffers, then ``model.*`` (the U-Net's
+        current parameters: the device-resident training state in training mode, else the values that were loaded)."""
+        out = {k: getattr(self, k) for k in SCHEDULE_BUFFERS}
+        if getattr(self.model, "_loaded", False):
+            out.update({"model." + k: v for k, v in self.model.state_dict().items()})
+        return out
 
     def load_state_dict(self, state_dict, strict=True):
         """Accepts ``DenoisingDiffusion.state_dict()``: 13 schedule buffers + ``model.*``."""

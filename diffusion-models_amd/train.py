@@ -118,8 +118,9 @@ class EMA:
 def diffusion_state_dict(diffusion, ema: bool = False):
     """``DenoisingDiffusion.state_dict()`` of the reference module: the 13 schedule buffers + ``model.*`` (the online
     parameters of the device-resident training state, or its EMA copy)."""
-    out = dict(diffusion.state_dict())
-    out.update({"model." + k: v.cpu() for k, v in diffusion.model.state_dict(ema=ema).items()})
+    out = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in diffusion.state_dict().items()}
+    if ema:
+        out.update({"model." + k: v.cpu() for k, v in diffusion.model.state_dict(ema=True).items()})
     return out
 
 

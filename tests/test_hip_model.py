@@ -380,6 +380,14 @@ def test_state_dict_and_parameters_of_an_inference_handle():
     assert n == sum(v.numel() for v in sd.values()) and [k for k, _ in u.named_parameters()] == list(got)
     d = dm.DenoisingDiffusion(u, image_size=16, timesteps=10)
     assert sum(p.numel() for p in d.parameters()) == n
+    # DenoisingDiffusion.state_dict(): 13 schedule buffers, then model.*; a second object loads it back
+    dsd = d.state_dict()
+    assert list(dsd)[:2] == ["betas", "alphas_cumprod"] and [k for k in dsd if k.startswith("model.")] == ["model." + k for k in got]
+    u2 = dm.Unet(dim=64, dim_mults=(1, 2), channels=3, device=DEV)
+    d2 = dm.DenoisingDiffusion(u2, image_size=16, timesteps=10).load_state_dict(dsd)
+    x = torch.randn((2, 3, 16, 16), generator=torch.Generator().manual_seed(1))
+    t = torch.tensor([3, 7])
+    assert torch.equal(d2.model(x, t), u(x, t))
 
 
 def test_module_like_to_and_cuda():
