@@ -152,6 +152,20 @@ ConvGeom conv_plan(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, 
         g.WM = 4 / best_wn;
         fill_tile(g, B, Ho, Wo, Cout, KH, KW, stride);
     }
+    // Tiny images with a wide kernel (3x3 on 1x1 / 2x2 maps) blow the staged window up to KH * KW times the pixel tile: when
+    // a 256-pixel tile's window does not fit LDS, narrower pixel tiles (more waves along the couts, even if that pads
+    // them) are taken instead of failing.
+    auto window_fits = [&](const ConvGeom& t) {
+        const size_t halo = g.CK == 16 ? (size_t)pad_to(t.NB * t.IH * t.IW, 64) * CKP : (size_t)pad_to(t.NB * t.IH * t.IW * CKP, 4);
+        const size_t slab = (size_t)(t.WN == 1 ? KW : 1) * 64 * t.WN * CKP;  // TPS as chosen below
+        return (halo + 2 * slab + 64 * t.WM + 256) * 4 <= 160 * 1024;
+    };
+    while (!window_fits(g) && g.WN < 4) {
+        g.WN *= 2;
+        g.WM = 4 / g.WN;
+        g.fused_norm = 0;  // (a fused RMSNorm needs all couts in one tile: the caller lands through the norm kernel then)
+        fill_tile(g, B, Ho, Wo, Cout, KH, KW, stride);
+    }
     // taps per weight slab: a whole kernel row when two buffers + the window leave room for 2 WGs/CU
     const int NT = 64 * g.WN;
     // CK == 16 stages the window in whole 256-thread passes of 64 pixel rows (unpredicated LDS stores)

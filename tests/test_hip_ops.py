@@ -71,6 +71,8 @@ CONV_CASES = [
     (2, 8, 0, 6, 2, 64, 3, 1, False, True, False),        # single K chunk, image narrower than a tile row
     (2, 1024, 0, 4, 4, 64, 3, 1, False, True, False),     # Winograd with K split 8 ways (partial sums + finalize)
     (1, 1024, 0, 2, 2, 64, 3, 1, False, True, False),     # 2x2 image: window too large for Winograd -> direct kernel
+    (300, 192, 0, 1, 1, 44, 3, 1, False, True, False),    # 3x3 on 1x1 maps off the Winograd grid: the direct kernel's window is 9x its pixel tile (narrower tiles)
+    (70, 40, 24, 2, 2, 100, 3, 1, False, True, True),     # ... 2x2 maps, concat, residual
     # nearest x2 + 3x3 on the source grid (upwino_mfma.hip; C % 8 == 0, Cout % 64 == 0, source 4x4 or multiples of 8).
     # Small shapes reach it only with DM_UPWINO_MIN_WGS=1 DM_UPWINO_MIN_K=1 (tests/test_hip_forced_dispatch.py),
     # otherwise they check the folded direct kernel
