@@ -195,9 +195,9 @@ __global__ __launch_bounds__(256) void group_sums_kernel(const float* __restrict
             s += vx;
             ss += vx * vx;
         }
-    const int cg = C / groups;  // channels per group (>= 1); a float4 spans 4 / cg groups when cg < 4
-    if (sub < rpp) {
-        if (cg >= 4) {
+    const int cg = C / groups;  // channels per group (>= 1); a float4 lies inside one group only when cg % 4 == 0
+    if (sub < rpp) {               // (cg = 6 / 12 of a 192- / 384-channel layer: a quad straddles two groups)
+        if (cg % 4 == 0) {
             const int grp = (4 * c4) / cg;
             atomicAdd(&red[2 * grp], (double)s.x + (double)s.y + (double)s.z + (double)s.w);
             atomicAdd(&red[2 * grp + 1], (double)ss.x + (double)ss.y + (double)ss.z + (double)ss.w);

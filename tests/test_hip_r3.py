@@ -255,3 +255,26 @@ def test_conditional_interpolate_and_vqmodel_ckpt_path(tmp_path):
     z = torch.randn((2, 3, 16, 16), generator=g)
     assert torch.equal(a.decode(z), b.decode(z))
 
+
+def test_vqmodel_with_groups_that_straddle_channel_quads():
+    """``ch = 96`` gives GroupNorm(32) groups of 3, 6 and 12 channels: a 16-byte quad of a pixel row then belongs to two
+    groups (a random-configuration sweep, tools/fuzz_vae.py, found the statistics kernel assuming otherwise).  Decode,
+    encode_to_prequant and the code indices against the oracle."""
+    from oracle import vae_oracle as vo
+
+    common = dict(ch=96, ch_mult=(1, 2, 4), num_res_blocks=1, resolution=32, z_channels=4, embed_dim=4, attn_resolutions=(8,))
+    ecfg, dcfg = EncoderConfig(n_embed=256, **common), DecoderConfig(**common)
+    sd = dm.synth_state_dict(encoder_param_spec(ecfg) + dm.decoder_param_spec(dcfg), salt=57)
+    vae = dm.VQModel(dict(out_ch=3, in_channels=3, double_z=False, **{k: v for k, v in common.items() if k != "embed_dim"}),
+                     n_embed=256, embed_dim=4, device=DEV)
+    vae.load_state_dict(sd)
+    g = torch.Generator().manual_seed(2)
+    z = torch.randn((2, 4, 8, 8), generator=g)
+    img = torch.rand((2, 3, 32, 32), generator=g) * 2 - 1
+    with torch.inference_mode():
+        assert rel_l2(vae.decode(z).cpu(), vo.vq_decode(sd, dcfg, z)) < FWD_TOL
+        assert rel_l2(vae.encode_to_prequant(img).cpu(), vo.vq_encode_to_prequant(sd, ecfg, img)) < FWD_TOL
+        _, widx = vo.vq_encode(sd, ecfg, img)
+    idx = vae.encode(img)[2][2].cpu().reshape(-1)
+    assert float((idx == widx.reshape(-1)).float().mean()) > 0.99
+
