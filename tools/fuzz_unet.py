@@ -33,8 +33,13 @@ for it in range(a.n):
     f = 2 ** (len(mults) - 1)
     H, W = f * rng.randint(1, 4), f * rng.randint(1, 4)
     B = rng.choice([1, 2, 3, 5])
-    variant = rng.choice(["plain", "plain", "selfcond", "text_concat", "text_cross"])
-    kw = dict(self_condition=variant == "selfcond", text_condition=variant.startswith("text"), use_cross_attn=variant == "text_cross")
+    variant = rng.choice(["plain", "plain", "selfcond", "text_concat", "text_cross", "imgcond"])
+    if rng.random() < 0.15:
+        dim = 128
+    kw = dict(self_condition=variant == "selfcond", text_condition=variant.startswith("text"), use_cross_attn=variant == "text_cross",
+              cond_channels=channels if variant == "imgcond" else 0)
+    if rng.random() < 0.4:  # any pattern of full / linear attention over the stages (the default: full at the last one only)
+        kw["full_attn"] = tuple(rng.random() < 0.5 for _ in mults)
     cfg = UnetConfig(dim=dim, dim_mults=mults, channels=channels, **kw)
     case = (dim, mults, channels, (H, W), B, variant)
     try:
@@ -49,20 +54,30 @@ for it in range(a.n):
             fw["x_self_cond"] = torch.randn((B, channels, H, W), generator=g)
         if variant.startswith("text"):
             fw["text_emb"] = torch.randn((B, 512), generator=g)
+        if variant == "imgcond":
+            fw["cond"] = torch.rand((B, channels, H, W), generator=g)
         with torch.inference_mode():
             want = uo.unet_forward(sd, cfg, x, t, **fw)
         err = rel_l2(u(x, t, **fw).cpu(), want)
         msg = f"forward {err:.2e}"
         ok = err < 1e-4
-        if a.train and variant in ("plain", "text_concat", "text_cross"):
-            cls = dm.TextConditionalDenoisingDiffusion if variant.startswith("text") else dm.DenoisingDiffusion
-            d = (cls(model=u, image_size=(H, W), timesteps=1000) if variant.startswith("text")
-                 else cls(u, image_size=(H, W), timesteps=1000)).train()
+        if a.train:
+            if variant.startswith("text"):
+                d = dm.TextConditionalDenoisingDiffusion(model=u, image_size=(H, W), timesteps=1000).train()
+            elif variant == "imgcond":
+                d = dm.ImageConditionalDenoisingDiffusion(u, image_size=(H, W), timesteps=1000).train()
+            else:
+                d = dm.DenoisingDiffusion(u, image_size=(H, W), timesteps=1000).train()
             noise = torch.randn((B, channels, H, W), generator=g)
             x0 = torch.rand((B, channels, H, W), generator=g) * 2 - 1
-            tk = {"text_emb": fw["text_emb"]} if variant.startswith("text") else {}
+            tk = {k: v for k, v in fw.items() if k in ("text_emb", "cond")}
+            okw = dict(tk)
+            if variant == "selfcond":
+                sc = rng.random() < 0.5
+                tk["self_cond"] = sc
+                okw["self_cond"] = sc
             loss = float(d.p_losses(x0, t, noise=noise, **tk))
-            wl, wg = to.loss_and_grads(sd, cfg, dm.make_schedule(1000, "linear"), x0, t, noise, **tk)
+            wl, wg = to.loss_and_grads(sd, cfg, dm.make_schedule(1000, "linear"), x0, t, noise, **okw)
             got = d.model.grads()
             worst = max((rel_l2(got[k].cpu(), wg[k]) if float(wg[k].norm()) > 0 else float(got[k].norm()), k) for k in wg)
             msg += f" loss {abs(loss - wl) / abs(wl):.1e} worst grad {worst[0]:.2e} ({worst[1]})"
