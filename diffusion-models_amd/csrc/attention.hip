@@ -342,13 +342,85 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const float* __rest
     }
 }
 
+// The same for sequences whose K and V do not fit LDS: one wave per 64 queries (lane = query, its q row and the 32
+// accumulators in registers), the keys stream through LDS in tiles of 64 twice (row maximum; then exp, row sum and P V) --
+// two passes instead of an online rescale keep the arithmetic that of softmax() followed by the product.
+// grid (ceil(nq / 64), heads, B), 64 threads.
+__global__ __launch_bounds__(64) void attention_core_tiled_kernel(const float* __restrict__ q, int ldq,
+                                                                  const float* __restrict__ k,
+                                                                  const float* __restrict__ v, int ldk,
+                                                                  const float* __restrict__ mem_k,
+                                                                  const float* __restrict__ mem_v, int n_mem,
+                                                                  float* __restrict__ out, int ldo, int nq, int nk,
+                                                                  float scale) {
+    __shared__ float Ks[64 * (DH + 1)], Vs[64 * (DH + 1)];
+    const int h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    const int i = blockIdx.x * 64 + lane, ntok = nk + n_mem;
+    const bool ok = i < nq;
+    float qr[DH], acc[DH];
+#pragma unroll
+    for (int c = 0; c < DH; ++c) {
+        qr[c] = ok ? q[((size_t)b * nq + i) * ldq + h * DH + c] * scale : 0.f;
+        acc[c] = 0.f;
+    }
+    float mx = -INFINITY, sum = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int j0 = 0; j0 < ntok; j0 += 64) {
+            __syncthreads();
+            for (int e = lane; e < 64 * DH; e += 64) {
+                const int t = j0 + (e >> 5), c = e & 31;
+                float kv = 0.f, vvv = 0.f;
+                if (t < ntok) {
+                    if (t < n_mem) {
+                        kv = mem_k[((size_t)h * n_mem + t) * DH + c];
+                        vvv = mem_v[((size_t)h * n_mem + t) * DH + c];
+                    } else {
+                        const size_t o = ((size_t)b * nk + (t - n_mem)) * ldk + h * DH + c;
+                        kv = k[o];
+                        vvv = v[o];
+                    }
+                }
+                Ks[(e >> 5) * (DH + 1) + c] = kv;
+                Vs[(e >> 5) * (DH + 1) + c] = vvv;
+            }
+            __syncthreads();
+            const int jn = min(64, ntok - j0);
+            for (int jj = 0; jj < jn; ++jj) {
+                float sc = 0.f;
+#pragma unroll
+                for (int c = 0; c < DH; ++c) sc += qr[c] * Ks[jj * (DH + 1) + c];
+                if (pass == 0) {
+                    mx = fmaxf(mx, sc);
+                } else {
+                    const float pe = __expf(sc - mx);
+                    sum += pe;
+#pragma unroll
+                    for (int c = 0; c < DH; ++c) acc[c] += pe * Vs[jj * (DH + 1) + c];
+                }
+            }
+        }
+    }
+    if (!ok) return;
+    const float inv = 1.0f / sum;
+    float* o = out + ((size_t)b * nq + i) * ldo + h * DH;
+#pragma unroll
+    for (int c = 0; c < DH; c += 4) *reinterpret_cast<float4*>(o + c) = make_float4(acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv);
+}
+
 int launch_attention_core(const float* q, int ldq, const float* k, const float* v, int ldk, const float* mem_k,
                           const float* mem_v, int n_mem, float* out, int ldo, int B, int nq, int nk, int heads,
                           int dh, float scale, hipStream_t s) {
     DM_REQUIRE(dh == DH, "attention kernel is specialised for dim_head == 32");
     int ntok = nk + n_mem;
     size_t lds = ((size_t)ntok * (DH + 1) + (size_t)ntok * DH + 4 * (size_t)ntok + 4 * DH) * sizeof(float);
-    DM_REQUIRE(lds <= 160 * 1024, "attention: sequence too long for the LDS-resident kernel");
+    static const bool force_tiled = std::getenv("DM_ATTN_TILED") != nullptr;  // tests: the tiled form on short sequences
+    if (lds > 160 * 1024 || force_tiled) {
+        DM_REQUIRE(B <= 65535 && heads <= 65535 && ldo % 4 == 0, "attention: batch / row stride");
+        hipLaunchKernelGGL(attention_core_tiled_kernel, dim3((nq + 63) / 64, heads, B), dim3(64), 0, s, q, ldq, k, v, ldk,
+                           mem_k, mem_v, n_mem, out, ldo, nq, nk, scale);
+        DM_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     static LdsOptIn lds_flag;
     if (lds_opt_in(lds_flag, reinterpret_cast<const void*>(attention_core_kernel), 1)) return 1;
     const int qblocks = std::max(1, std::min((nq + 3) / 4, (512 + heads * B - 1) / (heads * B)));

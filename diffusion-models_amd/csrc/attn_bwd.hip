@@ -12,6 +12,7 @@
 #include "dm_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace dm {
 
@@ -420,9 +421,170 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdParams p) {
     }
 }
 
-static int launch_attn_bwd(const AttnBwdParams& p, int B, hipStream_t s) {
-    const size_t lds = ((size_t)(2 * (p.nk + p.n_mem) + 2 * p.nq) * (BDH + 1) + 3 * p.nq) * sizeof(float);
-    DM_REQUIRE(lds <= 160 * 1024, "attention backward: sequence too long for the LDS-resident kernel");
+// ---- the same gradients for sequences that do not fit LDS: two tiled kernels, one wave per 64 queries / 64 keys.
+// attn_bwd_q_tiled_kernel   grid (ceil(nq / 64), heads, B): lane = query; the keys stream through LDS in tiles of 64 three
+//     times (row maximum; row sum and D_i; dq) -- the three loops of attn_bwd_kernel's first phase; writes dq and the row
+//     statistics (m_i, 1 / l_i, D_i) to stats[b][h][i][3].
+// attn_bwd_kv_tiled_kernel  grid (ceil((nk + n_mem) / 64), heads, B): lane = key; the queries (q, dO, statistics) stream
+//     through LDS in tiles of 64 in order: dk, dv, memory-row gradients.  Fixed summation order, no atomics.
+constexpr int ATS = BDH + 1;
+__device__ __forceinline__ void attn_load_key(const AttnBwdParams& p, int b, int h, int j, int d, float* kv, float* vv) {
+    if (j < p.n_mem) {
+        *kv = p.mem_k[((size_t)h * p.n_mem + j) * BDH + d];
+        *vv = p.mem_v[((size_t)h * p.n_mem + j) * BDH + d];
+    } else {
+        const size_t row = ((size_t)b * p.nk + (j - p.n_mem)) * p.ldk + h * BDH + d;
+        *kv = p.k[row];
+        *vv = p.v[row];
+    }
+}
+__global__ __launch_bounds__(64) void attn_bwd_q_tiled_kernel(const AttnBwdParams p, float* __restrict__ stats) {
+    __shared__ float Ks[64 * ATS], Vs[64 * ATS];
+    const int h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    const int i = blockIdx.x * 64 + lane, n = p.nq, nkt = p.nk + p.n_mem;
+    const bool ok = i < n;
+    const int hid = p.heads * BDH;
+    const float scale = p.scale;
+    float q[BDH], dov[BDH];
+#pragma unroll
+    for (int d = 0; d < BDH; ++d) {
+        q[d] = ok ? p.q[((size_t)b * n + i) * p.ldq + h * BDH + d] : 0.f;
+        dov[d] = ok ? p.dout[((size_t)b * n + i) * hid + h * BDH + d] : 0.f;
+    }
+    float m = -INFINITY, l = 0.f, D = 0.f, dq[BDH];
+#pragma unroll
+    for (int d = 0; d < BDH; ++d) dq[d] = 0.f;
+    for (int pass = 0; pass < 3; ++pass) {
+        float linv = 0.f;
+        if (pass == 2) {
+            linv = 1.0f / l;
+            D *= linv;
+        }
+        for (int j0 = 0; j0 < nkt; j0 += 64) {
+            __syncthreads();
+            for (int e = lane; e < 64 * BDH; e += 64) {
+                const int jj = e >> 5, d = e & 31;
+                float kv = 0.f, vv = 0.f;
+                if (j0 + jj < nkt) attn_load_key(p, b, h, j0 + jj, d, &kv, &vv);
+                Ks[jj * ATS + d] = kv;
+                Vs[jj * ATS + d] = vv;
+            }
+            __syncthreads();
+            const int jn = min(64, nkt - j0);
+            for (int jj = 0; jj < jn; ++jj) {
+                float sc = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < BDH; ++d) {
+                    sc += q[d] * Ks[jj * ATS + d];
+                    dp += dov[d] * Vs[jj * ATS + d];
+                }
+                if (pass == 0) {
+                    m = fmaxf(m, sc * scale);
+                } else if (pass == 1) {
+                    const float e = __expf(sc * scale - m);
+                    l += e;
+                    D += e * dp;
+                } else {
+                    const float dS = __expf(sc * scale - m) * linv * (dp - D);
+#pragma unroll
+                    for (int d = 0; d < BDH; ++d) dq[d] += dS * Ks[jj * ATS + d];
+                }
+            }
+        }
+    }
+    if (ok) {
+        float* st = stats + (((size_t)b * p.heads + h) * n + i) * 3;
+        st[0] = m;
+        st[1] = 1.0f / l;
+        st[2] = D;
+        float* o = p.dq + ((size_t)b * n + i) * p.ldq + h * BDH;
+#pragma unroll
+        for (int d = 0; d < BDH; ++d) o[d] = scale * dq[d];
+    }
+}
+__global__ __launch_bounds__(64) void attn_bwd_kv_tiled_kernel(const AttnBwdParams p, const float* __restrict__ stats) {
+    __shared__ float Qs[64 * ATS], Ds[64 * ATS], St[64 * 3];
+    const int h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    const int j = blockIdx.x * 64 + lane, n = p.nq, nkt = p.nk + p.n_mem;
+    const bool ok = j < nkt;
+    const int hid = p.heads * BDH;
+    const float scale = p.scale;
+    float kk[BDH], vv[BDH], dk[BDH], dv[BDH];
+#pragma unroll
+    for (int d = 0; d < BDH; ++d) {
+        kk[d] = vv[d] = 0.f;
+        if (ok) attn_load_key(p, b, h, j, d, &kk[d], &vv[d]);
+        dk[d] = dv[d] = 0.f;
+    }
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        __syncthreads();
+        for (int e = lane; e < 64 * BDH; e += 64) {
+            const int ii = e >> 5, d = e & 31;
+            const bool in = i0 + ii < n;
+            Qs[ii * ATS + d] = in ? p.q[((size_t)b * n + i0 + ii) * p.ldq + h * BDH + d] : 0.f;
+            Ds[ii * ATS + d] = in ? p.dout[((size_t)b * n + i0 + ii) * hid + h * BDH + d] : 0.f;
+        }
+        for (int e = lane; e < 64 * 3; e += 64)
+            St[e] = i0 + e / 3 < n ? stats[(((size_t)b * p.heads + h) * n + i0) * 3 + e] : 0.f;
+        __syncthreads();
+        const int in_ = min(64, n - i0);
+        for (int ii = 0; ii < in_; ++ii) {
+            float sc = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < BDH; ++d) {
+                sc += Qs[ii * ATS + d] * kk[d];
+                dp += Ds[ii * ATS + d] * vv[d];
+            }
+            const float P = __expf(sc * scale - St[3 * ii]) * St[3 * ii + 1];
+            const float dS = P * (dp - St[3 * ii + 2]);
+#pragma unroll
+            for (int d = 0; d < BDH; ++d) {
+                dk[d] += dS * Qs[ii * ATS + d];
+                dv[d] += P * Ds[ii * ATS + d];
+            }
+        }
+    }
+    if (!ok) return;
+    if (j < p.n_mem) {
+        float* o = p.dmem_part + (size_t)b * 2 * p.heads * p.n_mem * BDH;
+#pragma unroll
+        for (int d = 0; d < BDH; ++d) {
+            o[((size_t)h * p.n_mem + j) * BDH + d] = scale * dk[d];
+            o[((size_t)(p.heads + h) * p.n_mem + j) * BDH + d] = dv[d];
+        }
+    } else {
+        const size_t row = ((size_t)b * p.nk + (j - p.n_mem)) * p.ldk + h * BDH;
+#pragma unroll
+        for (int d = 0; d < BDH; ++d) {
+            p.dk[row + d] = scale * dk[d];
+            p.dv[row + d] = dv[d];
+        }
+    }
+}
+
+static size_t attn_bwd_lds_bytes(int nq, int nk, int n_mem) {
+    return ((size_t)(2 * (nk + n_mem) + 2 * nq) * (BDH + 1) + 3 * nq) * sizeof(float);
+}
+static bool attn_bwd_tiled(int nq, int nk, int n_mem) {
+    static const bool force = std::getenv("DM_ATTN_BWD_TILED") != nullptr;  // tests: the tiled form on small shapes too
+    return force || attn_bwd_lds_bytes(nq, nk, n_mem) > 160 * 1024;
+}
+// floats of statistics workspace the tiled form needs (0 when the LDS-resident kernel takes the shape)
+size_t attn_bwd_ws_floats(int B, int nq, int nk, int n_mem, int heads) {
+    return attn_bwd_tiled(nq, nk, n_mem) ? (size_t)B * heads * nq * 3 : 0;
+}
+
+static int launch_attn_bwd(const AttnBwdParams& p, int B, float* ws, hipStream_t s) {
+    const size_t lds = attn_bwd_lds_bytes(p.nq, p.nk, p.n_mem);
+    if (attn_bwd_tiled(p.nq, p.nk, p.n_mem)) {
+        DM_REQUIRE(ws != nullptr, "attention backward: the tiled form needs its statistics workspace (attn_bwd_ws_floats)");
+        DM_REQUIRE(B <= 65535 && p.heads <= 65535, "attention backward: batch");
+        hipLaunchKernelGGL(attn_bwd_q_tiled_kernel, dim3((p.nq + 63) / 64, p.heads, B), dim3(64), 0, s, p, ws);
+        DM_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(attn_bwd_kv_tiled_kernel, dim3((p.nk + p.n_mem + 63) / 64, p.heads, B), dim3(64), 0, s, p, ws);
+        DM_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     static LdsOptIn flag;
     if (lds_opt_in(flag, reinterpret_cast<const void*>(attn_bwd_kernel), 1)) return 1;
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(p.heads, B), dim3(256), lds, s, p);
@@ -431,8 +593,8 @@ static int launch_attn_bwd(const AttnBwdParams& p, int B, hipStream_t s) {
 }
 
 // qkv (B, n, 3*heads*32), dout (B, n, heads*32) -> dqkv, dmem_part (B, 2, heads, 4, 32)
-int launch_attention_core_bwd(const float* qkv, const float* mem_kv, const float* dout, float* dqkv, float* dmem_part, int B,
-                              int n, int heads, int dh, hipStream_t s) {
+int launch_attention_core_bwd(const float* qkv, const float* mem_kv, const float* dout, float* dqkv, float* dmem_part, float* ws,
+                              int B, int n, int heads, int dh, hipStream_t s) {
     DM_REQUIRE(dh == BDH, "attention backward: dim_head 32");
     const int hid = heads * BDH;
     AttnBwdParams p{};
@@ -443,12 +605,12 @@ int launch_attention_core_bwd(const float* qkv, const float* mem_kv, const float
     p.dmem_part = dmem_part;
     p.ldq = p.ldk = 3 * hid; p.nq = p.nk = n; p.n_mem = NMEM; p.heads = heads;
     p.scale = 1.0f / sqrtf((float)dh);
-    return launch_attn_bwd(p, B, s);
+    return launch_attn_bwd(p, B, ws, s);
 }
 
 // CrossAttention core: q (B, nq, heads*32), k / v (B, m, heads*32) projections of the context -> dq, dk, dv (same shapes)
 int launch_cross_attention_core_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
-                                    float* dv, int B, int nq, int m, int heads, int dh, hipStream_t s) {
+                                    float* dv, float* ws, int B, int nq, int m, int heads, int dh, hipStream_t s) {
     DM_REQUIRE(dh == BDH, "attention backward: dim_head 32");
     AttnBwdParams p{};
     p.q = q; p.k = k; p.v = v;
@@ -456,7 +618,7 @@ int launch_cross_attention_core_bwd(const float* q, const float* k, const float*
     p.dq = dq; p.dk = dk; p.dv = dv;
     p.ldq = p.ldk = heads * BDH; p.nq = nq; p.nk = m; p.n_mem = 0; p.heads = heads;
     p.scale = 1.0f / sqrtf((float)dh);
-    return launch_attn_bwd(p, B, s);
+    return launch_attn_bwd(p, B, ws, s);
 }
 
 }  // namespace dm

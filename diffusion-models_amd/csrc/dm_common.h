@@ -458,9 +458,11 @@ int launch_adam_ema(float* p, const float* g, float* m, float* v, float* ema, co
 size_t linattn_bwd_ws_floats(int B, int n, int heads);
 int launch_linear_attention_core_bwd(const float* qkv, const float* mem_kv, const float* ctx, const float* dout, float* ws,
                                      float* dqkv, float* dmem_part, int B, int n, int heads, int dh, hipStream_t s);
-int launch_attention_core_bwd(const float* qkv, const float* mem_kv, const float* dout, float* dqkv, float* dmem_part, int B,
-                              int n, int heads, int dh, hipStream_t s);
+// ws: attn_bwd_ws_floats() floats (row statistics of the tiled form; 0 floats when the sequence fits LDS)
+size_t attn_bwd_ws_floats(int B, int nq, int nk, int n_mem, int heads);
+int launch_attention_core_bwd(const float* qkv, const float* mem_kv, const float* dout, float* dqkv, float* dmem_part, float* ws,
+                              int B, int n, int heads, int dh, hipStream_t s);
 int launch_cross_attention_core_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
-                                    float* dv, int B, int nq, int m, int heads, int dh, hipStream_t s);
+                                    float* dv, float* ws, int B, int nq, int m, int heads, int dh, hipStream_t s);
 
 }  // namespace dm

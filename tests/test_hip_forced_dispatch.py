@@ -3,7 +3,8 @@ test_hip_ops.py reach the F(4x4,3x3) and the upsample kernels only at benchmark-
 This test re-runs the convolution and Block cases ONCE in a child process whose dispatch thresholds are lowered
 (the thresholds are read once per process), so that every small edge case also goes through those kernels.  The same
 child runs the LinearAttention / Attention cases with the fused kernels switched off: the unfused chains (pre-norm, 1x1
-GEMM with its fused RMSNorm epilogue at 64 channels, attention cores) stay covered although no default shape takes them."""
+GEMM with its fused RMSNorm epilogue at 64 channels, attention cores -- the softmax core in its tiled long-sequence form)
+stay covered although no default shape takes them."""
 import os
 import subprocess
 import sys
@@ -16,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_small_shapes_through_the_large_shape_kernels():
     env = dict(os.environ, DM_WINO4_MIN_WGS="1", DM_WINO4_MIN_K="1", DM_UPWINO_MIN_WGS="1", DM_UPWINO_MIN_K="1",
-               DM_NO_FUSED_LINATTN="1", DM_NO_ATTN16="1")
+               DM_NO_FUSED_LINATTN="1", DM_NO_ATTN16="1", DM_ATTN_TILED="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_ops.py"), "-q", "-x",
                         "-m", "gpu", "-k", "conv2d or block or attention", "-p", "no:cacheprovider"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
@@ -73,6 +74,17 @@ def test_training_goldens_with_one_launch_per_layer():
     layer (no grouped launch, no deferred reductions), the direct 3x3 weight gradient instead of the Winograd-domain one,
     lazy instead of grouped re-packing."""
     _run_training(dict(DM_WGRAD_NO_DEFER="1", DM_WGRAD_NO_WINO="1", DM_NO_BATCH_REPACK="1"))
+
+
+def test_attention_backward_tiled_form_on_every_shape():
+    """The operator-level attention backward cases and the text-conditional training step (mid_attn + CrossAttention) with the
+    tiled kernels forced on the short sequences the LDS-resident kernel normally takes."""
+    env = dict(os.environ, DM_ATTN_BWD_TILED="1", DM_ATTN_TILED="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_train_ops.py"),
+                        os.path.join(ROOT, "tests", "test_hip_train.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "test_attention_bwd or test_text_conditional_training_step", "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
 
 
 def test_training_goldens_grouped_without_winograd():

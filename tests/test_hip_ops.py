@@ -214,7 +214,8 @@ def test_linear_attention(shape):
 
 # 4x4 maps with C % 256 == 0 take the one-kernel path (attn16_fused.hip), the others the unfused chain
 @pytest.mark.parametrize("shape", [(2, 256, 4, 4), (3, 512, 4, 4), (70, 512, 4, 4), (1, 1024, 4, 4), (1, 512, 8, 8),
-                                   (2, 64, 2, 2), (2, 128, 4, 4), (1, 128, 16, 16)])
+                                   (2, 64, 2, 2), (2, 128, 4, 4), (1, 128, 16, 16),
+                                   (1, 64, 32, 32), (2, 32, 25, 27)])  # over ~590 tokens: the tiled attention core
 def test_attention(shape):
     B, Cc, H, W = shape
     x = seeded(shape, 1)

@@ -497,26 +497,29 @@ def test_latent_diffusion_training_loss():
     assert bool(torch.isfinite(g).all()) and float(g.abs().sum()) > 0
 
 
-@pytest.mark.parametrize("variant", ["concat", "cross_m1", "cross_m3"])
+@pytest.mark.parametrize("variant", ["concat", "cross_m1", "cross_m3", "cross_m3_px64"])
 def test_text_conditional_training_step_vs_oracle(variant):
     """TextConditionalDenoisingDiffusion.p_losses (denoising_diffusion_text_conditional.py:476-542): the concat variant
     (text_proj -> cat(t, .) -> text_concat_proj) and the three CrossAttention layers around the bottleneck, with one pooled
     context token (what the reference's trainer passes: to_q / to_k receive exactly zero gradient, the softmax over a
-    single key is constant) and with three tokens; loss and every gradient against the oracle."""
+    single key is constant) and with three tokens; loss and every gradient against the oracle.  ``px64``: a 32x32
+    bottleneck -- 1024 query tokens through the tiled attention backward (mid_attn and the CrossAttention layers; the
+    LDS-resident kernel holds about 300)."""
     from oracle import train_oracle as to
 
     cross = variant != "concat"
+    px = 64 if variant.endswith("px64") else 16
     cfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3, text_condition=True, use_cross_attn=cross)
     sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=2 if cross else 3)
     u = dm.Unet(dim=32, dim_mults=(1, 2), channels=3, text_condition=True, use_cross_attn=cross, device=DEV)
     u.load_state_dict(sd)
-    d = dm.TextConditionalDenoisingDiffusion(model=u, image_size=16, timesteps=1000).train()
+    d = dm.TextConditionalDenoisingDiffusion(model=u, image_size=px, timesteps=1000).train()
     g = torch.Generator().manual_seed(44)
-    B = 4
-    x_start = torch.rand((B, 3, 16, 16), generator=g) * 2 - 1
+    B = 4 if px == 16 else 2
+    x_start = torch.rand((B, 3, px, px), generator=g) * 2 - 1
     t = torch.randint(0, 1000, (B,), generator=g)
-    noise = torch.randn((B, 3, 16, 16), generator=g)
-    emb = torch.randn((B, 3, 512), generator=g) if variant == "cross_m3" else torch.randn((B, 512), generator=g)
+    noise = torch.randn((B, 3, px, px), generator=g)
+    emb = torch.randn((B, 3, 512), generator=g) if "m3" in variant else torch.randn((B, 512), generator=g)
     loss = float(d.p_losses(x_start, t, emb, noise))
     torch.set_num_threads(8)
     want_loss, want = to.loss_and_grads(sd, cfg, dm.make_schedule(1000, "linear"), x_start, t, noise, text_emb=emb)

@@ -190,7 +190,8 @@ def test_linear_attention_bwd(case):
     assert max(errs.values()) < TOL, errs
 
 
-@pytest.mark.parametrize("case", [(2, 256, 4, 4), (3, 512, 4, 4), (2, 512, 8, 8), (2, 64, 3, 5), (1, 128, 16, 16), (2, 64, 1, 1)])
+@pytest.mark.parametrize("case", [(2, 256, 4, 4), (3, 512, 4, 4), (2, 512, 8, 8), (2, 64, 3, 5), (1, 128, 16, 16), (2, 64, 1, 1),
+                                  (1, 64, 32, 16), (2, 32, 23, 25)])  # the last two: the tiled form (over ~300 tokens)
 def test_attention_bwd(case):
     B, C, H, W = case
     sd = _attn_params(C, True, 20)
