@@ -278,3 +278,23 @@ def test_vqmodel_with_groups_that_straddle_channel_quads():
     idx = vae.encode(img)[2][2].cpu().reshape(-1)
     assert float((idx == widx.reshape(-1)).float().mean()) > 0.99
 
+
+
+def test_vqmodel_mid_attention_over_4096_tokens_with_32_channels():
+    """A single-level VQModel (``ch_mult=(1,)``) at resolution 64 runs its mid-block attention over 64 x 64 = 4096 tokens of
+    32 channels: the row kernel (C outside {64, 128, 256}) with more than 64 KB of LDS (tools/fuzz_vae.py found the old
+    limit).  Decode and encode_to_prequant against the oracle."""
+    from oracle import vae_oracle as vo
+
+    common = dict(ch=32, ch_mult=(1,), num_res_blocks=1, resolution=64, z_channels=3, embed_dim=3, attn_resolutions=())
+    ecfg, dcfg = EncoderConfig(n_embed=256, **common), DecoderConfig(**common)
+    sd = dm.synth_state_dict(encoder_param_spec(ecfg) + dm.decoder_param_spec(dcfg), salt=58)
+    vae = dm.VQModel(dict(out_ch=3, in_channels=3, double_z=False, **{k: v for k, v in common.items() if k != "embed_dim"}),
+                     n_embed=256, embed_dim=3, device=DEV)
+    vae.load_state_dict(sd)
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn((1, 3, 64, 64), generator=g)
+    img = torch.rand((1, 3, 64, 64), generator=g) * 2 - 1
+    with torch.inference_mode():
+        assert rel_l2(vae.decode(z).cpu(), vo.vq_decode(sd, dcfg, z)) < FWD_TOL
+        assert rel_l2(vae.encode_to_prequant(img).cpu(), vo.vq_encode_to_prequant(sd, ecfg, img)) < FWD_TOL
