@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--n", type=int, default=12)
 ap.add_argument("--train", action="store_true")
+ap.add_argument("--big", action="store_true", help="maps of 4..12 times the down-sampling factor per side (several pixel tiles, long attention sequences)")
 a = ap.parse_args()
 rng = random.Random(a.seed)
 torch.set_num_threads(16)
@@ -33,6 +34,10 @@ for it in range(a.n):
     f = 2 ** (len(mults) - 1)
     H, W = f * rng.randint(1, 4), f * rng.randint(1, 4)
     B = rng.choice([1, 2, 3, 5])
+    if a.big:
+        H, W = f * rng.randint(4, 12), f * rng.randint(4, 12)
+        B = rng.choice([1, 2])
+        dim = min(dim, 48)
     variant = rng.choice(["plain", "plain", "selfcond", "text_concat", "text_cross", "imgcond"])
     if rng.random() < 0.15:
         dim = 128
