@@ -195,6 +195,8 @@ class DenoisingDiffusion:
         shape = tuple(int(v) for v in shape)
         B, Cc, H, W = shape
         assert Cc == self.channels, f"shape has {Cc} channels, the model {self.channels}"
+        f = self.model.downsample_factor
+        assert B > 0 and H % f == 0 and W % f == 0, f"shape {shape}: the sides must be divisible by {f}"
         n_steps = len(times)
         if seed is None:
             seed = _default_seed()
@@ -214,6 +216,8 @@ class DenoisingDiffusion:
             x_T = (self._randn(shape, seed, 0, sample_offset) if x_init is None
                    else x_init.to(self.device, torch.float32).contiguous())
             noise_dev = None
+        assert tuple(x_T.shape) == shape, f"initial state {tuple(x_T.shape)} does not match {shape}"
+        assert noise_dev is None or tuple(noise_dev.shape[1:]) == shape, "noise() must return tensors of the sampled shape"
         if max_steps is not None:  # bounded run (bench / smoke): first `max_steps` iterations only
             n_steps = min(n_steps, int(max_steps))
         ctx, m = (None, 0)
@@ -320,8 +324,13 @@ class DenoisingDiffusion:
             self.model.train()
         x_start = x_start.to(self.device, torch.float32).contiguous()
         b, c, h, w = x_start.shape
+        f = self.model.downsample_factor
+        if c != self.channels or h % f or w % f:
+            raise RuntimeError(f"x_start {tuple(x_start.shape)}: expected {self.channels} channels and sides divisible by {f}")
         noise = (noise.to(self.device, torch.float32).contiguous() if noise is not None
                  else self._randn(x_start.shape, _default_seed(), 0))
+        if noise.shape != x_start.shape or t.numel() != b:
+            raise RuntimeError(f"noise {tuple(noise.shape)} / t ({t.numel()} entries) do not match x_start {tuple(x_start.shape)}")
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if offset_noise_strength and offset_noise_strength > 0.0:
             offs = (offset_noise.to(self.device, torch.float32).contiguous() if offset_noise is not None

@@ -376,7 +376,12 @@ class Unet:
         B, Cin, H, W = x.shape
         if Cin != self.cfg.input_channels:
             raise RuntimeError(f"expected {self.cfg.input_channels} input channels, got {Cin}")
-        t = time.to(device=self.device, dtype=torch.int64).contiguous()
+        t = time.to(device=self.device, dtype=torch.int64).reshape(-1)
+        if t.numel() == 1 and B > 1:
+            t = t.expand(B)  # the reference broadcasts a single time embedding over the batch
+        if t.numel() != B:
+            raise RuntimeError(f"time has {t.numel()} entries for a batch of {B}")
+        t = t.contiguous()
         ctx, m = self._ctx(text_emb, B)
         out = torch.empty((B, self.out_dim, H, W), device=self.device, dtype=torch.float32)
         stream = torch.cuda.current_stream(self.device).cuda_stream

@@ -298,3 +298,34 @@ def test_vqmodel_mid_attention_over_4096_tokens_with_32_channels():
     with torch.inference_mode():
         assert rel_l2(vae.decode(z).cpu(), vo.vq_decode(sd, dcfg, z)) < FWD_TOL
         assert rel_l2(vae.encode_to_prequant(img).cpu(), vo.vq_encode_to_prequant(sd, ecfg, img)) < FWD_TOL
+
+
+def test_shape_mistakes_raise_before_any_launch():
+    """Arguments whose shapes do not fit the model are refused on the host (the kernels index by the model's own channel
+    count and the batch they are told): wrong channel count / noise shape / number of timesteps in ``p_losses``, a time
+    vector of the wrong length in ``Unet.forward`` (a single entry broadcasts over the batch, as in the reference), sampler
+    shapes the down-sampling factor does not divide."""
+    u = dm.Unet(dim=16, dim_mults=(1, 2), channels=3, device=DEV)
+    u.load_state_dict(dm.synth_state_dict(u.param_spec(), salt=3))
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((2, 3, 8, 8), generator=g)
+    t = torch.tensor([5, 900])
+    with pytest.raises(RuntimeError, match="time has 3 entries"):
+        u(x, torch.tensor([1, 2, 3]))
+    with pytest.raises(RuntimeError, match="input channels"):
+        u(torch.randn((2, 4, 8, 8), generator=g), t)
+    one = u(x, torch.tensor([7]))
+    assert torch.equal(one, u(x, torch.tensor([7, 7])))
+    d = dm.DenoisingDiffusion(u, image_size=8, timesteps=1000)
+    with pytest.raises(AssertionError, match="divisible"):
+        d.p_sample_loop((1, 3, 8, 7))
+    with pytest.raises(AssertionError, match="channels"):
+        d.ddim_sample((1, 4, 8, 8), sampling_timesteps=2)
+    d.train()
+    with pytest.raises(RuntimeError, match="expected 3 channels"):
+        d.p_losses(torch.randn((2, 4, 8, 8), generator=g), t)
+    with pytest.raises(RuntimeError, match="do not match"):
+        d.p_losses(x, t, noise=torch.randn((2, 3, 8, 4), generator=g))
+    with pytest.raises(RuntimeError, match="do not match"):
+        d.p_losses(x, torch.tensor([5]))
+    assert float(d.p_losses(x, t)) > 0
