@@ -154,6 +154,15 @@ bool wino_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1);
 int wino_launch(const ConvParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
+// EXPERIMENTAL (DM_WINOB=1): Winograd F(2x2, 3x3) with fp32 products as six bf16 MFMA products (winob_mfma.hip); same
+// contract as wino_launch, chunks of 16 input channels, 64 tiles per workgroup, no K split
+bool winob_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up);
+size_t winob_packed_floats(int Cout, int C0, int C1);
+void winob_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1);
+ConvGeom winob_plan(int B, int Ho, int Wo, int Cout, int C0, int C1);
+bool winob_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1);
+int winob_launch(const ConvParams& p, hipStream_t s);
+
 // Winograd F(4x4, 3x3) convolution (wino4_mfma.hip): same contract as wino_launch, 2.25 instead of 4 multiplies per
 // output; images of 4x4, 8x8, 16x16 or (16k x 32m) pixels.  ConvGeom TW/TH/NB count 4x4-pixel tiles (32 per workgroup).
 // ---------------------------------------------------------------------------------------
