@@ -156,6 +156,8 @@ __global__ __launch_bounds__(256, 1) void winob_mfma_kernel(const ConvParams p) 
     const int ix0 = 2 * tx0 - 1, iy0 = 2 * ty0 - 1;  // window origin in pixels
     const int cb = 0, ce = p.n_chunks;
     float* raw[2] = {smem, smem + BWIN};
+    DM_STAMP_DECL
+    DM_STAMP(0);
 
     // ---- window staging: item = (window pixel, channel quad); quad q of pixel column hx sits in slot q ^ ((hx >> 2) & 3)
     int hpix[BHR], hoff[BHR];
@@ -279,6 +281,7 @@ __global__ __launch_bounds__(256, 1) void winob_mfma_kernel(const ConvParams p) 
         for (int e = 0; e < 4; ++e) T[r][i >> 1][i & 1][e] = __builtin_fmaf(sgn, tq[i % LAT][e], T[r][i >> 1][i & 1][e]);
     };
 
+    DM_STAMP_ADD(4)
     // ---- prologue: windows of chunks cb and cb + 1 -> LDS, T / A / B of phase (cb, 0) -> registers
     {
         const bool two = cb + 1 < ce;
@@ -299,6 +302,7 @@ __global__ __launch_bounds__(256, 1) void winob_mfma_kernel(const ConvParams p) 
 #pragma unroll
         for (int i = 0; i < BHR; ++i) *reinterpret_cast<f32x4*>(raw[1] + hoff[i]) = h2[i];
     }
+    DM_STAMP_ADD(5)
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -315,6 +319,7 @@ __global__ __launch_bounds__(256, 1) void winob_mfma_kernel(const ConvParams p) 
 #pragma unroll
         for (int u = 0; u < 12; ++u) a_micro(0, 0, r, u);
     __syncthreads();  // raw[0] is overwritten with chunk cb + 2 during the first iteration
+    DM_STAMP_ADD(0)
 
     // ---- main loop: phase (c, j) = the 24 MFMAs of patch column j of chunk c; everything else sits in hooks between
     // them (one basic block per chunk, sched_barrier pins every hook).  Loads past the last chunk re-read valid memory.
@@ -372,6 +377,7 @@ __global__ __launch_bounds__(256, 1) void winob_mfma_kernel(const ConvParams p) 
         if (c < ce) chunk_body(c, P0{});
     }
 
+    DM_STAMP_ADD(1)
     // ---- epilogue (winograd_mfma.hip, R = 2): R_i[b] = sum_j M[i][j] A[j][b] per wave, Y[a][b] = sum_i A^T[a][i] R_i[b]
     // through LDS, then the shared Block epilogue.
     constexpr int NR = 16;
@@ -425,6 +431,7 @@ __global__ __launch_bounds__(256, 1) void winob_mfma_kernel(const ConvParams p) 
             }
         }
     __syncthreads();
+    DM_STAMP_ADD(2)
     const float ysgn = oa ? -1.0f : 1.0f;  // Y[0] = R0 + R1 + R2,  Y[1] = R1 - R2 - R3
     const float* Y0 = smem + (oa * 2 + ob) * (TILES * BWTS) + c4;
     f32x4 v[NR];
@@ -437,6 +444,8 @@ __global__ __launch_bounds__(256, 1) void winob_mfma_kernel(const ConvParams p) 
         v[jj] = a0 + ysgn * a1 + ysgn * a2;
     }
     rows_epilogue<1, NR, true>(p, re, v, pixv, cg, cvalid, pf);
+    DM_STAMP_ADD(3)
+    DM_STAMP_FLUSH
 }
 
 int winob_launch(const ConvParams& pin, hipStream_t s) {
@@ -473,6 +482,30 @@ int winob_launch(const ConvParams& pin, hipStream_t s) {
             snprintf(name, sizeof(name), "winob_mfma_kernel");
         if (prof::begin(name, flops, bytes, s)) return 1;
     }
+#ifdef DM_STAMPS
+    {  // diagnostic build: run the launch synchronously with a stamp buffer and print the phase averages
+        const size_t nblk = (size_t)blocks;
+        unsigned long long* dbuf = nullptr;
+        DM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), nblk * 8 * sizeof(unsigned long long)));
+        DM_CHECK_HIP(hipMemsetAsync(dbuf, 0, nblk * 8 * sizeof(unsigned long long), s));
+        ConvParams ps = p;
+        ps.stamps = dbuf;
+        hipLaunchKernelGGL(winob_mfma_kernel, dim3(blocks, 1, 1), dim3(256), p.geo.lds_bytes, s, ps);
+        DM_CHECK_HIP(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h(nblk * 8);
+        DM_CHECK_HIP(hipMemcpy(h.data(), dbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        (void)hipFree(dbuf);
+        double avg[8] = {0};
+        for (size_t b = 0; b < nblk; ++b)
+            for (int k = 0; k < 8; ++k) avg[k] += (double)h[b * 8 + k] / nblk;
+        fprintf(stderr, "STAMPS winob %d+%d->%d @%dx%d e%d chunks %d: wgs=%zu | setup %.0f load+store %.0f transform %.0f "
+                        "loop %.0f (%.0f/chunk) reduce %.0f epilogue %.0f\n",
+                p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.epi, p.n_chunks, nblk, avg[4], avg[5], avg[0], avg[1], avg[1] / p.n_chunks,
+                avg[2], avg[3]);
+        if (timed && prof::end(s)) return 1;
+        return 0;
+    }
+#endif
     hipLaunchKernelGGL(winob_mfma_kernel, dim3(blocks, 1, 1), dim3(256), p.geo.lds_bytes, s, p);
     DM_CHECK_HIP(hipGetLastError());
     if (timed && prof::end(s)) return 1;
