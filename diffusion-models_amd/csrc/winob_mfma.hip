@@ -42,6 +42,8 @@ static constexpr int BRS = BIW * BCK + 8;    // floats per window row (+8: tile 
 static constexpr int BWIN = BIW * BRS;       // floats per window buffer
 static constexpr int BHR = 6;                // 16-byte staging items per thread: 18 * 18 * 4 = 1296 <= 6 * 256
 static constexpr int BWTS = 68;              // row stride of the epilogue tiles (as winograd_mfma.hip)
+static constexpr int B1WIN = 10 * BRS;       // 32-tile form: 18 x 10 window
+static constexpr int B1HR = 3;               // 18 * 10 * 4 = 720 items <= 3 * 256
 
 bool winob_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up) {
     static const bool on = env_int("DM_WINOB", 0) != 0 && std::getenv("DM_NO_WINOGRAD") == nullptr;
@@ -92,31 +94,35 @@ void winob_pack_weights(const float* oihw, float* packed, int Cout, int C0, int 
 }
 
 ConvGeom winob_plan(int B, int Ho, int Wo, int Cout, int C0, int C1) {
+    // R = tile groups of 32 per workgroup: 1 -> 8 x 4 tiles, 128 accumulators, two workgroups per CU (default);
+    //                                      2 -> 8 x 8 tiles, 256 accumulators, one workgroup per CU
+    static const int R = env_int("DM_WINOB_R", 1) == 2 ? 2 : 1;
+    const int tiles = 32 * R, TH = 4 * R, win = (2 * TH + 2) * BRS;
     ConvGeom g{};
-    g.WM = 2;
+    g.WM = R;
     g.WN = 1;
     g.CK = BCK;
     g.TW = 8;
-    g.TH = 8;
+    g.TH = TH;
     g.NB = 1;
     g.lTW = 3;
-    g.lTH = 3;
+    g.lTH = R == 2 ? 3 : 2;
     g.tiles_x = (Wo / 2 + 7) / 8;
-    g.tiles_y = (Ho / 2 + 7) / 8;
+    g.tiles_y = (Ho / 2 + TH - 1) / TH;
     g.groups = B;
     g.n_tiles_n = Cout / 64;
-    g.IH = BIW;
+    g.IH = 2 * TH + 2;
     g.IW = BIW;
     g.row_stride = BRS;
-    g.halo_floats = BWIN;
+    g.halo_floats = win;
     g.TPS = 3;
     g.splits = 1;
     g.chunks_per_split = (C0 + C1) / BCK;
     g.fused_norm = g.n_tiles_n == 1;
     g.w_floats = 0;
     // two windows + a scratch slot; the epilogue reuses the space for 4 x 2 transposed tiles; behind both the pixel table
-    g.ptab_off = std::max(2 * BWIN + 8, 4 * 2 * BTILES * BWTS);
-    g.lds_bytes = (g.ptab_off + 4 * BTILES) * 4;
+    g.ptab_off = std::max(2 * win + 8, 4 * 2 * tiles * BWTS);
+    g.lds_bytes = (g.ptab_off + 4 * tiles) * 4;
     return g;
 }
 
@@ -448,6 +454,323 @@ __global__ __launch_bounds__(256, 1) void winob_mfma_kernel(const ConvParams p) 
     DM_STAMP_FLUSH
 }
 
+// The 32-tile form: 8 x 4 tiles per workgroup, 128 accumulator registers, TWO workgroups per CU -- one wave's vector
+// instructions issue while the other's MFMAs run, and a workgroup's prologue / epilogue overlap its neighbour's loop; a
+// weight plane serves 32 tiles (twice the B traffic per MFMA of the 64-tile form).  tools/winob_microbench.hip: 234 vs 212
+// TFLOP/s fp32-equivalent in the loop.
+__global__ __launch_bounds__(256, 2) void winob1_mfma_kernel(const ConvParams p) {
+    constexpr int TILES = 32;
+    constexpr int WINF = B1WIN, HRN = B1HR, IHN = 10;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const ConvGeom& g = p.geo;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    int n_tile, bid;
+    block_to_tile(g, blockIdx.x, gridDim.x, n_tile, bid);
+    const int tile_x = bid % g.tiles_x;
+    bid /= g.tiles_x;
+    const int tile_y = bid % g.tiles_y;
+    const int b0 = bid / g.tiles_y;
+    const int tx0 = tile_x * 8, ty0 = tile_y * 4;    // in Winograd tiles
+    const int ix0 = 2 * tx0 - 1, iy0 = 2 * ty0 - 1;  // window origin in pixels
+    const int cb = 0, ce = p.n_chunks;
+    float* raw[2] = {smem, smem + WINF};
+    DM_STAMP_DECL
+    DM_STAMP(0);
+
+    // ---- window staging: item = (window pixel, channel quad); quad q of pixel column hx sits in slot q ^ ((hx >> 2) & 3)
+    int hpix[HRN], hoff[HRN];
+#pragma unroll
+    for (int i = 0; i < HRN; ++i) {
+        const int it = tid + 256 * i;
+        hpix[i] = -1;
+        hoff[i] = 2 * WINF;  // items past the window go to a scratch slot
+        if (it < BIW * IHN * 4) {
+            const int hp = it >> 2, qd = it & 3;
+            const int hy = hp / BIW, hx = hp - hy * BIW;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const int off = hy * BRS + hx * BCK + 4 * (qd ^ ((hx >> 2) & 3));
+            if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) {
+                hpix[i] = (b0 * p.Hin + iy) * p.Win + ix;
+                hoff[i] = off;
+            } else {
+                *reinterpret_cast<f32x4*>(raw[0] + off) = make_f32x4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<f32x4*>(raw[1] + off) = make_f32x4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        hpix[i] = max(hpix[i], 0);
+    }
+    {
+        // output pixel of (tile, a, b), or -1: thread = tile * 4 + (2a + b)  (layout of winograd_mfma.hip, NRT = 16)
+        constexpr int NRT = 8;
+        int* ptab = reinterpret_cast<int*>(smem + g.ptab_off);
+        if (tid < 4 * TILES) {
+            const int t = tid >> 2, ab = tid & 3;
+            const int tx = t & 7, ty = (t >> 3) & 3;
+            const int y = 2 * (ty0 + ty) + (ab >> 1), x = 2 * (tx0 + tx) + (ab & 1);
+            ptab[(t / NRT) * (4 * NRT) + ab * NRT + (t % NRT)] = (y < p.Ho && x < p.Wo) ? (b0 * p.Ho + y) * p.Wo + x : -1;
+        }
+    }
+    f32x4 hreg[HRN];
+    const size_t in_px = (size_t)p.B * p.Hin * p.Win;
+    const __amdgpu_buffer_rsrc_t rs_in0 = make_rsrc(p.in0, in_px * p.C0 * 4);
+    const __amdgpu_buffer_rsrc_t rs_in1 = make_rsrc(p.C1 ? p.in1 : p.in0, in_px * (p.C1 ? p.C1 : p.C0) * 4);
+    const unsigned hq = 4 * (tid & 3);
+    unsigned hvo[HRN];
+    auto window_offsets = [&](unsigned Cs) {
+#pragma unroll
+        for (int i = 0; i < HRN; ++i) hvo[i] = (__umul24((unsigned)hpix[i], Cs) + hq) * 4;
+    };
+    auto window_value = [&](int chunk, int i) {
+        const bool s1 = chunk >= p.chunks0;
+        return bufload4(s1 ? rs_in1 : rs_in0, hvo[i], (unsigned)(s1 ? chunk - p.chunks0 : chunk) * (BCK * 4));
+    };
+
+    // ---- input transform of this lane: tile l31, channels 8 lh .. 8 lh + 7, row `wave` of B^T d
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sgn = wave == 1 ? 1.0f : -1.0f;
+    const int tx = l31 & 7, ty = l31 >> 3;
+    int colq[4][2];  // float offset of (column b, quad 2 lh + k) of this lane's tiles inside a window row
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int hx = 2 * tx + b;
+            colq[b][k] = hx * BCK + 4 * ((2 * lh + k) ^ ((hx >> 2) & 3));
+        }
+    const int rowa = ra * BRS, rowb = rb * BRS;
+    const int rbase0 = 2 * ty * BRS;
+
+    // ---- B planes: [chunk][xi][plane][cout][16] bf16; per-lane byte offset once, the rest is scalar
+    const size_t w_bytes = (size_t)p.n_chunks * 16 * 3 * p.Cout * 32;
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, w_bytes);
+    const unsigned bvo = (unsigned)((n_tile * 64 + l31) * 2 + lh) * 16;
+    const unsigned plane_b = (unsigned)p.Cout * 32;  // bytes per (xi, plane)
+    const unsigned chunk_b = 16 * 3 * plane_b;
+    const unsigned bwave = (unsigned)(4 * wave) * 3 * plane_b;
+    auto bload = [&](int chunk, int j, int pl, int q) {
+        const unsigned so = (unsigned)chunk * chunk_b + bwave + (unsigned)(j * 3 + pl) * plane_b + (unsigned)q * (32 * 32);
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)bvo, (int)so, 0));
+    };
+
+    f32x16 acc[4][1][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 1; ++r)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][r][q][e] = 0.f;
+    u32x4 Ah[2][1], Am[2][1], Al[2][1];  // [set][0]: the three planes of the A operand (8 bf16 each)
+    bf16x8 Bp[2][3][2];                  // [set][plane][q]
+    f32x4 T[1][4][2];                    // [0][window column b][channel quad k]
+    constexpr int LAT = 2;               // MFMA gaps between an LDS read and its use
+    f32x4 tq[LAT];
+    float rs0 = 0.f, rs1 = 0.f;
+
+    // one channel pair (quad k, half h2) of A[set][r] for patch column jn in three stages (one per MFMA gap):
+    // 0: combine + high plane, 1: middle plane, 2: low plane; the residuals wait in rs0 / rs1 in between
+    auto a_stage = [&](int set, int jn, int r, int k, int h2, int st) {
+        if (st == 0) {
+            const int e0 = 2 * h2, e1 = 2 * h2 + 1;
+            const int ca = jn == 0 ? 0 : (jn == 2 ? 2 : 1), cc = jn == 0 ? 2 : (jn == 1 ? 2 : (jn == 2 ? 1 : 3));
+            const float x0 = jn == 1 ? T[r][ca][k][e0] + T[r][cc][k][e0] : T[r][ca][k][e0] - T[r][cc][k][e0];
+            const float x1 = jn == 1 ? T[r][ca][k][e1] + T[r][cc][k][e1] : T[r][ca][k][e1] - T[r][cc][k][e1];
+            const unsigned h = b_pk_bf16(x0, x1);
+            Ah[set][r][2 * k + h2] = h;
+            rs0 = x0 - __builtin_bit_cast(float, h << 16);
+            rs1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+        } else if (st == 1) {
+            const unsigned mm = b_pk_bf16(rs0, rs1);
+            Am[set][r][2 * k + h2] = mm;
+            rs0 = rs0 - __builtin_bit_cast(float, mm << 16);
+            rs1 = rs1 - __builtin_bit_cast(float, mm & 0xffff0000u);
+        } else {
+            Al[set][r][2 * k + h2] = b_pk_bf16(rs0, rs1);
+        }
+    };
+    auto a_micro = [&](int set, int jn, int r, int u) { a_stage(set, jn, r, (u / 3) >> 1, (u / 3) & 1, u % 3); };
+    auto t_issue = [&](const float* win, int r, int i) {  // item i = 2 b + k: row a lands in T, row b in tq
+        const float* base = win + rbase0;
+        T[r][i >> 1][i & 1] = *reinterpret_cast<const f32x4*>(base + rowa + colq[i >> 1][i & 1]);
+        tq[i % LAT] = *reinterpret_cast<const f32x4*>(base + rowb + colq[i >> 1][i & 1]);
+    };
+    auto t_finish = [&](int r, int i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T[r][i >> 1][i & 1][e] = __builtin_fmaf(sgn, tq[i % LAT][e], T[r][i >> 1][i & 1][e]);
+    };
+
+    DM_STAMP_ADD(4)
+    // ---- prologue: windows of chunks cb and cb + 1 -> LDS, T / A / B of phase (cb, 0) -> registers
+    {
+        const bool two = cb + 1 < ce;
+        f32x4 h2[HRN];
+        window_offsets(cb >= p.chunks0 ? p.C1 : p.C0);
+#pragma unroll
+        for (int i = 0; i < HRN; ++i) hreg[i] = window_value(cb, i);
+        const int c1 = two ? cb + 1 : cb;
+        if (c1 == p.chunks0) window_offsets(p.C1);
+#pragma unroll
+        for (int i = 0; i < HRN; ++i) h2[i] = window_value(c1, i);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) Bp[0][pl][q] = bload(cb, 0, pl, q);
+#pragma unroll
+        for (int i = 0; i < HRN; ++i) *reinterpret_cast<f32x4*>(raw[0] + hoff[i]) = hreg[i];
+#pragma unroll
+        for (int i = 0; i < HRN; ++i) *reinterpret_cast<f32x4*>(raw[1] + hoff[i]) = h2[i];
+    }
+    DM_STAMP_ADD(5)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 1; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float* base = raw[0] + rbase0;
+            const f32x4 da = *reinterpret_cast<const f32x4*>(base + rowa + colq[i >> 1][i & 1]);
+            const f32x4 db = *reinterpret_cast<const f32x4*>(base + rowb + colq[i >> 1][i & 1]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) T[r][i >> 1][i & 1][e] = __builtin_fmaf(sgn, db[e], da[e]);
+        }
+#pragma unroll
+    for (int r = 0; r < 1; ++r)
+#pragma unroll
+        for (int u = 0; u < 12; ++u) a_micro(0, 0, r, u);
+    __syncthreads();  // raw[0] is overwritten with chunk cb + 2 during the first iteration
+    DM_STAMP_ADD(0)
+
+    // ---- main loop: phase (c, j) = the 24 MFMAs of patch column j of chunk c; everything else sits in hooks between
+    // them (one basic block per chunk, sched_barrier pins every hook).  Loads past the last chunk re-read valid memory.
+    auto chunk_body = [&](int c, auto par_tag) {
+        constexpr int PAR = decltype(par_tag)::value;  // (c - cb) & 1: the buffer chunk c was read from
+        const bool has1 = c + 1 < ce, has2 = c + 2 < ce;
+        const int cn = has1 ? c + 1 : c;   // chunk whose B planes / window are consumed next
+        const int cw = has2 ? c + 2 : c;   // chunk whose window is fetched now (c again at the end: never read)
+        if (cw == p.chunks0 && p.C1 != p.C0) {
+            window_offsets(p.C1);
+            asm volatile("" ::: "memory");
+        }
+        const float* wnext = raw[PAR ^ 1];  // window of chunk c + 1
+        float* wstore = raw[PAR];           // free: window of chunk c was consumed during chunk c - 1
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int set = j & 1, nset = set ^ 1, jn = (j + 1) & 3;
+#pragma unroll
+            for (int m = 0; m < 12; ++m) {
+                const int pr = m >> 1, q = m & 1;
+                // small terms first: ah*bl, al*bh, am*bm, ah*bm, am*bh, ah*bh
+                const u32x4 au = pr == 0 || pr == 3 || pr == 5 ? Ah[set][0] : (pr == 1 ? Al[set][0] : Am[set][0]);
+                const bf16x8 bb = pr == 0 ? Bp[set][2][q] : (pr == 1 || pr == 4 || pr == 5 ? Bp[set][0][q] : Bp[set][1][q]);
+                acc[j][0][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, au), bb, acc[j][0][q], 0, 0, 0);
+                // ---- hooks
+                if (m < 6) Bp[nset][m >> 1][m & 1] = bload(j == 3 ? cn : c, jn, m >> 1, m & 1);
+                a_micro(nset, jn, 0, m);  // A of the next column: 12 micro-ops, one per gap
+                if (j == 0 && m >= 6 && m < 6 + HRN) hreg[m - 6] = window_value(cw, m - 6);
+                if (j == 1 && m >= 6 && m < 6 + HRN) *reinterpret_cast<f32x4*>(wstore + hoff[m - 6]) = hreg[m - 6];
+                // T of the next chunk: columns 0 and 2 are dead once A[2] exists (after phase 1), columns 1 and 3 once A[3]
+                // does (after phase 2); item i = 2 b + k
+                if (j == 2) {
+                    if (m >= LAT && m < 4 + LAT) t_finish(0, 4 * ((m - LAT) >> 1) + ((m - LAT) & 1));
+                    if (m < 4) t_issue(wnext, 0, 4 * (m >> 1) + (m & 1));
+                }
+                if (j == 3) {
+                    if (m >= LAT && m < 4 + LAT) t_finish(0, 4 * ((m - LAT) >> 1) + 2 + ((m - LAT) & 1));
+                    if (m < 4) t_issue(wnext, 0, 4 * (m >> 1) + 2 + (m & 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    };
+    {
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        int c = cb;
+        for (; c + 1 < ce; c += 2) {
+            chunk_body(c, P0{});
+            chunk_body(c + 1, P1{});
+        }
+        if (c < ce) chunk_body(c, P0{});
+    }
+
+    DM_STAMP_ADD(1)
+    // ---- epilogue (winograd_mfma.hip, R = 2): R_i[b] = sum_j M[i][j] A[j][b] per wave, Y[a][b] = sum_i A^T[a][i] R_i[b]
+    // through LDS, then the shared Block epilogue.
+    constexpr int NR = 8;
+    const int rsub = lane >> 4;
+    const int oa = rsub >> 1, ob = rsub & 1;
+    const int c4 = (lane & 15) * 4;
+    const int cg = n_tile * 64 + c4;
+    const bool cvalid = cg < p.Cout;
+    int pixv[NR];
+    {
+        const int* pt = reinterpret_cast<const int*>(smem + g.ptab_off) + wave * (4 * NR) + rsub * NR;
+#pragma unroll
+        for (int jj = 0; jj < NR; jj += 4) {
+            const int4 t4 = *reinterpret_cast<const int4*>(pt + jj);
+            pixv[jj] = t4.x;
+            pixv[jj + 1] = t4.y;
+            pixv[jj + 2] = t4.z;
+            pixv[jj + 3] = t4.w;
+        }
+    }
+    RowsEpilogue re;
+    re.split = 0;
+    re.M = (size_t)p.B * p.Ho * p.Wo;
+    re.b0 = b0;
+    re.uni = true;
+    re.HoWo = p.Ho * p.Wo;
+    re.red = nullptr;
+    re.rows_per_wg = 4 * TILES;
+    re.row_in_wg0 = wave * 4 * NR;
+    re.wn = 0;
+    re.all_valid = true;
+    RowsPrefetch<NR, true> pf;
+    rows_prefetch<NR, true>(p, re, pixv, cg, cvalid, pf);
+
+    float* Tb = smem + wave * (2 * TILES * BWTS);  // [b][tile][WTS]
+#pragma unroll
+    for (int r = 0; r < 1; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 a0 = {acc[0][r][q][e], acc[0][r][q][e + 1]}, a1 = {acc[1][r][q][e], acc[1][r][q][e + 1]};
+                const f32x2 a2 = {acc[2][r][q][e], acc[2][r][q][e + 1]}, a3 = {acc[3][r][q][e], acc[3][r][q][e + 1]};
+                const f32x2 r0 = pk_add(pk_add(a0, a1), a2);
+                const f32x2 r1 = pk_sub(pk_sub(a1, a2), a3);
+                const int row = r * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                Tb[row * BWTS + q * 32 + l31] = r0.x;
+                Tb[(row + 1) * BWTS + q * 32 + l31] = r0.y;
+                Tb[(TILES + row) * BWTS + q * 32 + l31] = r1.x;
+                Tb[(TILES + row + 1) * BWTS + q * 32 + l31] = r1.y;
+            }
+        }
+    __syncthreads();
+    DM_STAMP_ADD(2)
+    const float ysgn = oa ? -1.0f : 1.0f;  // Y[0] = R0 + R1 + R2,  Y[1] = R1 - R2 - R3
+    const float* Y0 = smem + (oa * 2 + ob) * (TILES * BWTS) + c4;
+    f32x4 v[NR];
+#pragma unroll
+    for (int jj = 0; jj < NR; ++jj) {
+        const float* yp = Y0 + (NR * wave + jj) * BWTS;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(yp);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(yp + 2 * TILES * BWTS);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(yp + 4 * TILES * BWTS);
+        v[jj] = a0 + ysgn * a1 + ysgn * a2;
+    }
+    rows_epilogue<1, NR, true>(p, re, v, pixv, cg, cvalid, pf);
+    DM_STAMP_ADD(3)
+    DM_STAMP_FLUSH
+}
+
 int winob_launch(const ConvParams& pin, hipStream_t s) {
     ConvParams p = pin;
     p.stamps = nullptr;
@@ -457,7 +780,9 @@ int winob_launch(const ConvParams& pin, hipStream_t s) {
     DM_REQUIRE(p.C0 % BCK == 0 && p.C1 % BCK == 0 && p.Cout % 64 == 0, "winograd bf16x6: channel counts");
     DM_REQUIRE(p.Hin == p.Ho && p.Win == p.Wo && p.Ho % 2 == 0 && p.Wo % 2 == 0 && p.Ho >= 16 && p.Wo >= 16,
                "winograd bf16x6: even images of at least 16 x 16");
-    DM_REQUIRE(g.WM == 2 && g.TW == 8 && g.TH == 8 && g.NB == 1 && g.splits == 1 && g.groups == p.B, "winograd bf16x6: plan");
+    DM_REQUIRE((g.WM == 1 || g.WM == 2) && g.TW == 8 && g.TH == 4 * g.WM && g.NB == 1 && g.splits == 1 && g.groups == p.B,
+               "winograd bf16x6: plan");
+    const bool one = g.WM == 1;
     DM_REQUIRE((size_t)p.B * p.Ho * p.Wo < (1u << 24) && (size_t)p.B * p.Ho * p.Wo * std::max(p.C0, p.C1) < (1ull << 30),
                "winograd bf16x6: tensor too large for 24-bit pixel indices");
     DM_REQUIRE(!(p.epi & EPI_NORM) || g.n_tiles_n == 1, "winograd bf16x6: fused RMSNorm needs one N tile");
@@ -466,8 +791,10 @@ int winob_launch(const ConvParams& pin, hipStream_t s) {
     const int blocks = g.n_tiles_n * g.tiles_x * g.tiles_y * g.groups;
     static const bool xcd_order = env_int("DM_NO_XCD_ORDER", 0) == 0;
     p.geo.xcd_groups = (xcd_order && blocks % 8 == 0 && 8 % g.n_tiles_n == 0) ? 8 / g.n_tiles_n : 0;
-    static LdsOptIn lds_flag;
-    if (lds_opt_in(lds_flag, reinterpret_cast<const void*>(winob_mfma_kernel), 1)) return 1;
+    static LdsOptIn lds_flag, lds_flag1;
+    if (one ? lds_opt_in(lds_flag1, reinterpret_cast<const void*>(winob1_mfma_kernel), 1)
+            : lds_opt_in(lds_flag, reinterpret_cast<const void*>(winob_mfma_kernel), 1))
+        return 1;
     const bool timed = prof::enabled();
     if (timed) {
         const double pix = (double)p.B * p.Ho * p.Wo;
@@ -477,7 +804,7 @@ int winob_launch(const ConvParams& pin, hipStream_t s) {
         const double bytes = 4.0 * (cin * pix + (1.0 + res_rows) * p.Cout * pix + 9.0 * cin * p.Cout);
         char name[64];
         if (prof::detail())
-            snprintf(name, sizeof(name), "winob 3x3 s1 %d+%d->%d @%dx%d e%d", p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.epi);
+            snprintf(name, sizeof(name), "winob<%d> 3x3 s1 %d+%d->%d @%dx%d e%d", g.WM, p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.epi);
         else
             snprintf(name, sizeof(name), "winob_mfma_kernel");
         if (prof::begin(name, flops, bytes, s)) return 1;
@@ -490,7 +817,10 @@ int winob_launch(const ConvParams& pin, hipStream_t s) {
         DM_CHECK_HIP(hipMemsetAsync(dbuf, 0, nblk * 8 * sizeof(unsigned long long), s));
         ConvParams ps = p;
         ps.stamps = dbuf;
-        hipLaunchKernelGGL(winob_mfma_kernel, dim3(blocks, 1, 1), dim3(256), p.geo.lds_bytes, s, ps);
+        if (one)
+            hipLaunchKernelGGL(winob1_mfma_kernel, dim3(blocks, 1, 1), dim3(256), p.geo.lds_bytes, s, ps);
+        else
+            hipLaunchKernelGGL(winob_mfma_kernel, dim3(blocks, 1, 1), dim3(256), p.geo.lds_bytes, s, ps);
         DM_CHECK_HIP(hipStreamSynchronize(s));
         std::vector<unsigned long long> h(nblk * 8);
         DM_CHECK_HIP(hipMemcpy(h.data(), dbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -498,15 +828,18 @@ int winob_launch(const ConvParams& pin, hipStream_t s) {
         double avg[8] = {0};
         for (size_t b = 0; b < nblk; ++b)
             for (int k = 0; k < 8; ++k) avg[k] += (double)h[b * 8 + k] / nblk;
-        fprintf(stderr, "STAMPS winob %d+%d->%d @%dx%d e%d chunks %d: wgs=%zu | setup %.0f load+store %.0f transform %.0f "
+        fprintf(stderr, "STAMPS winob<%d> %d+%d->%d @%dx%d e%d chunks %d: wgs=%zu | setup %.0f load+store %.0f transform %.0f "
                         "loop %.0f (%.0f/chunk) reduce %.0f epilogue %.0f\n",
-                p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.epi, p.n_chunks, nblk, avg[4], avg[5], avg[0], avg[1], avg[1] / p.n_chunks,
+                g.WM, p.C0, p.C1, p.Cout, p.Ho, p.Wo, p.epi, p.n_chunks, nblk, avg[4], avg[5], avg[0], avg[1], avg[1] / p.n_chunks,
                 avg[2], avg[3]);
         if (timed && prof::end(s)) return 1;
         return 0;
     }
 #endif
-    hipLaunchKernelGGL(winob_mfma_kernel, dim3(blocks, 1, 1), dim3(256), p.geo.lds_bytes, s, p);
+    if (one)
+        hipLaunchKernelGGL(winob1_mfma_kernel, dim3(blocks, 1, 1), dim3(256), p.geo.lds_bytes, s, p);
+    else
+        hipLaunchKernelGGL(winob_mfma_kernel, dim3(blocks, 1, 1), dim3(256), p.geo.lds_bytes, s, p);
     DM_CHECK_HIP(hipGetLastError());
     if (timed && prof::end(s)) return 1;
     return 0;

@@ -368,6 +368,146 @@ __global__ __launch_bounds__(256, 1) void winob_pipe(const bf16x8* __restrict__ 
     out[blockIdx.x * 256 + tid] = s;
 }
 
+// The 32-tile form: two workgroups per CU (two waves per SIMD, 256 registers each), so one wave's vector instructions issue
+// while the other's MFMAs run and a workgroup's fixed phases overlap its neighbour's loop; the price is twice the B traffic
+// per MFMA (a weight plane serves 32 tiles).  One B register set (loads issued right after the MFMAs that used the
+// registers), T of the next chunk lands column by column as the current columns die.
+constexpr int WIN1 = 10 * RS;  // 18 x 10 window
+__global__ __launch_bounds__(256, 2) void winob_pipe1(const bf16x8* __restrict__ wplanes, const float* __restrict__ xin,
+                                                      float* __restrict__ out, int n_chunks, int reps) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    for (int i = tid; i < 2 * WIN1; i += 256) sm[i] = (float)((i * 29 + blockIdx.x) & 127) * 0.01f - 0.6f;
+    __syncthreads();
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sgn = wave == 1 ? 1.0f : -1.0f;
+    const int tx = l31 & 7, ty = l31 >> 3;
+    int colq[4][2];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int hx = 2 * tx + b;
+            colq[b][k] = hx * 16 + 4 * ((2 * lh + k) ^ ((hx >> 2) & 3));
+        }
+    constexpr int HR1 = 3;  // 18 x 10 x 4 = 720 items
+    int hoff[HR1];
+#pragma unroll
+    for (int i = 0; i < HR1; ++i) {
+        const int it = tid + 256 * i;
+        const int px = min(it >> 2, 18 * 10 - 1), qd = it & 3;
+        const int hy = px / 18, hx = px - hy * 18;
+        hoff[i] = hy * RS + hx * 16 + 4 * (qd ^ ((hx >> 2) & 3));
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][q][e] = 0.f;
+    u32x4 Ah[2], Am[2], Al[2];  // [set]
+    bf16x8 Bp[2][3][2];         // [set][plane][q]
+    f32x4 T[4][2];              // [column b][channel quad k]
+    f32x4 hreg[HR1];
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8*>(wplanes), 0, (int)((size_t)n_chunks * 16 * 3 * 64 * 32), 0x00020000);
+    const unsigned bvo = (unsigned)(l31 * 2 + lh) * 16;
+    const unsigned bwave = __builtin_amdgcn_readfirstlane(wave) * 4 * 3 * 64 * 32;
+    auto bload = [&](int chunk, int j, int pl, int q) {
+        const unsigned so = (unsigned)chunk * (16 * 3 * 64 * 32) + bwave + (unsigned)((j * 3 + pl) * 64 + q * 32) * 32;
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)bvo, (int)so, 0));
+    };
+    float rs0 = 0.f, rs1 = 0.f;
+    auto a_stage = [&](int set, int jn, int k, int h2, int st) {
+        if (st == 0) {
+            const int e0 = 2 * h2, e1 = 2 * h2 + 1;
+            const int ca = jn == 0 ? 0 : (jn == 2 ? 2 : 1), cb = jn == 0 ? 2 : (jn == 1 ? 2 : (jn == 2 ? 1 : 3));
+            const float x0 = jn == 1 ? T[ca][k][e0] + T[cb][k][e0] : T[ca][k][e0] - T[cb][k][e0];
+            const float x1 = jn == 1 ? T[ca][k][e1] + T[cb][k][e1] : T[ca][k][e1] - T[cb][k][e1];
+            const unsigned h = pk_bf16(x0, x1);
+            Ah[set][2 * k + h2] = h;
+            rs0 = x0 - __builtin_bit_cast(float, h << 16);
+            rs1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+        } else if (st == 1) {
+            const unsigned mm = pk_bf16(rs0, rs1);
+            Am[set][2 * k + h2] = mm;
+            rs0 = rs0 - __builtin_bit_cast(float, mm << 16);
+            rs1 = rs1 - __builtin_bit_cast(float, mm & 0xffff0000u);
+        } else {
+            Al[set][2 * k + h2] = pk_bf16(rs0, rs1);
+        }
+    };
+    auto a_micro = [&](int set, int jn, int u) { a_stage(set, jn, (u / 3) >> 1, (u / 3) & 1, u % 3); };
+    constexpr int LAT = 2;
+    f32x4 tq[LAT];
+    auto t_issue = [&](const float* win, int b, int k, int slot) {
+        const float* base = win + (2 * ty) * RS;
+        T[b][k] = *reinterpret_cast<const f32x4*>(base + ra * RS + colq[b][k]);
+        tq[slot] = *reinterpret_cast<const f32x4*>(base + rb * RS + colq[b][k]);
+    };
+    auto t_finish = [&](int b, int k, int slot) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T[b][k][e] = __builtin_fmaf(sgn, tq[slot][e], T[b][k][e]);
+    };
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            t_issue(sm, b, k, 0);
+            t_finish(b, k, 0);
+        }
+#pragma unroll
+    for (int u = 0; u < 12; ++u) a_micro(0, 0, u);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) Bp[0][pl][q] = bload(0, 0, pl, q);
+
+    for (int rep = 0; rep < reps; ++rep) {
+        for (int c = 0; c < n_chunks; ++c) {
+            const int cn = c + 1 < n_chunks ? c + 1 : 0;
+            const float* wnext = sm + ((c + 1) & 1) * WIN1;
+            float* wstore = sm + (c & 1) * WIN1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int set = j & 1, nset = set ^ 1, jn = (j + 1) & 3;
+#pragma unroll
+                for (int m = 0; m < 12; ++m) {
+                    const int pr = m >> 1, q = m & 1;
+                    const u32x4 au = pr == 0 || pr == 3 || pr == 5 ? Ah[set] : (pr == 1 ? Al[set] : Am[set]);
+                    const bf16x8 b = pr == 0 ? Bp[set][2][q] : (pr == 1 || pr == 4 || pr == 5 ? Bp[set][0][q] : Bp[set][1][q]);
+                    acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, au), b, acc[j][q], 0, 0, 0);
+                    if (m < 6) Bp[nset][m >> 1][m & 1] = bload(j == 3 ? cn : c, jn, m >> 1, m & 1);
+                    a_micro(nset, jn, m);  // A of the next column (12 micro-ops, one per gap)
+                    if (j == 0 && m >= 6 && m < 6 + HR1)
+                        hreg[m - 6] = *reinterpret_cast<const f32x4*>(xin + ((size_t)(blockIdx.x * 8 + (c & 7)) * HR1 * 256 + 256 * (m - 6) + tid) * 4);
+                    if (j == 1 && m >= 6 && m < 6 + HR1) *reinterpret_cast<f32x4*>(wstore + hoff[m - 6]) = hreg[m - 6];
+                    // T of the next chunk: columns 0 and 2 die after A[2] (phase 1), columns 1 and 3 after A[3] (phase 2)
+                    if (j == 2) {
+                        if (m >= LAT && m < 4 + LAT) t_finish(((m - LAT) >> 1) * 2, (m - LAT) & 1, (m - LAT) % LAT);
+                        if (m < 4) t_issue(wnext, (m >> 1) * 2, m & 1, m % LAT);
+                    }
+                    if (j == 3) {
+                        if (m >= LAT && m < 4 + LAT) t_finish(((m - LAT) >> 1) * 2 + 1, (m - LAT) & 1, (m - LAT) % LAT);
+                        if (m < 4) t_issue(wnext, (m >> 1) * 2 + 1, m & 1, m % LAT);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s += acc[j][q][e];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
 #define CK(x)                                                                  \
     do {                                                                       \
         hipError_t e_ = (x);                                                   \
@@ -422,6 +562,26 @@ int run_pipe(const char* name, const bf16x8* w, const float* x, float* out, int 
     return 0;
 }
 
+int run_pipe1(const char* name, const bf16x8* w, const float* x, float* out, int n_chunks) {
+    const int blocks = 512, reps = 40;
+    const size_t lds = 2 * WIN1 * sizeof(float);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(winob_pipe1, dim3(blocks), dim3(256), lds, 0, w, x, out, n_chunks, 1);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(winob_pipe1, dim3(blocks), dim3(256), lds, 0, w, x, out, n_chunks, reps);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = (double)blocks * reps * n_chunks * 16.0 * 32 * 64 * 16 * 2;
+    const double tf = flops / ms / 1e9;
+    printf("%-64s %8.3f ms  %7.1f TF/s fp32-equivalent = %.2f of the six-product peak (419), %.2fx the f32-MFMA peak\n", name, ms,
+           tf, tf / 419.4, tf / 157.3);
+    return 0;
+}
+
 int main() {
     const int n_chunks = 32;  // a 512-channel layer
     const size_t wn = (size_t)n_chunks * 16 * 3 * 64 * 2;  // bf16x8 units
@@ -429,10 +589,10 @@ int main() {
     float *x, *out;
     CK(hipMalloc(&w, wn * sizeof(bf16x8)));
     CK(hipMemset(w, 0x3c, wn * sizeof(bf16x8)));  // 0x3c3c = 0.0115 in bf16
-    const size_t xn = (size_t)256 * 8 * HR * 256 * 4;
+    const size_t xn = (size_t)512 * 8 * HR * 256 * 4;
     CK(hipMalloc(&x, xn * sizeof(float)));
     CK(hipMemset(x, 0, xn * sizeof(float)));
-    CK(hipMalloc(&out, 256 * 256 * sizeof(float)));
+    CK(hipMalloc(&out, 512 * 256 * sizeof(float)));
     if (run<0>("MFMAs only", w, x, out, n_chunks)) return 1;
     if (run<1>("+ B planes from global memory (24 KB per wave and chunk)", w, x, out, n_chunks)) return 1;
     if (run<2>("+ A planes from the LDS window (reads, transform, split)", w, x, out, n_chunks)) return 1;
@@ -443,5 +603,6 @@ int main() {
     if (run_pipe<4>("  pipelined, without the window staging", w, x, out, n_chunks)) return 1;
     if (run_pipe<12>("  pipelined, without staging and barrier", w, x, out, n_chunks)) return 1;
     if (run_pipe<15>("  pipelined, MFMAs only", w, x, out, n_chunks)) return 1;
+    if (run_pipe1("32-tile form, two workgroups per CU, everything", w, x, out, n_chunks)) return 1;
     return 0;
 }
