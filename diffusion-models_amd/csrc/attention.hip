@@ -414,7 +414,10 @@ int launch_attention_core(const float* q, int ldq, const float* k, const float* 
     int ntok = nk + n_mem;
     size_t lds = ((size_t)ntok * (DH + 1) + (size_t)ntok * DH + 4 * (size_t)ntok + 4 * DH) * sizeof(float);
     static const bool force_tiled = std::getenv("DM_ATTN_TILED") != nullptr;  // tests: the tiled form on short sequences
-    if (lds > 160 * 1024 || force_tiled) {
+    // beyond ~320 keys the tiled form is also the faster one (tools/attn_time.py: 512 tokens 1.29 vs 2.79 ms per layer at
+    // B=64, equal at 256): the LDS-resident kernel re-stages all K / V of an (image, head) in every query block
+    static const int tiled_min = env_int("DM_ATTN_TILED_MIN", 320);
+    if (lds > 160 * 1024 || ntok > tiled_min || force_tiled) {
         DM_REQUIRE(B <= 65535 && heads <= 65535 && ldo % 4 == 0, "attention: batch / row stride");
         hipLaunchKernelGGL(attention_core_tiled_kernel, dim3((nq + 63) / 64, heads, B), dim3(64), 0, s, q, ldq, k, v, ldk,
                            mem_k, mem_v, n_mem, out, ldo, nq, nk, scale);
