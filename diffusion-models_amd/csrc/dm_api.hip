@@ -5,6 +5,7 @@
 #include "../../include/dm_hip.h"
 #include "dm_common.h"
 
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>

@@ -396,9 +396,10 @@ struct ColsumJob {
 int launch_norm_act_bwd(const float* dy, const float* u, const float* g, const float* ss, int ss_stride, int pix_per_image,
                         float* du, float* ws, float* dg, float* dbias, float* dss, int dss_stride, int B, int C, int flags,
                         int accumulate, hipStream_t s, RowgradJob* defer = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0,
-                        uint64_t drop_stream = 0, const float* add = nullptr);
+                        uint64_t drop_stream = 0, const float* add = nullptr, int dy_nsplit = 1, int64_t dy_stride = 0);
 int launch_norm_act_drop(const float* u, const float* g, const float* ss, int ss_stride, int pix_per_image, const float* residual,
-                         float* y, int B, int C, int flags, float drop_p, uint64_t drop_seed, uint64_t drop_stream, hipStream_t s);
+                         float* y, int B, int C, int flags, float drop_p, uint64_t drop_seed, uint64_t drop_stream, hipStream_t s,
+                         int nsplit = 1, int64_t split_stride = 0, const float* bias = nullptr, float* u_out = nullptr);
 void rowgrad_jobs_prefix(std::vector<RowgradJob>& jobs, int* img_blocks, int* fin_blocks);
 int launch_rowgrad_jobs(const RowgradJob* jobs_dev, int n_jobs, int img_blocks, int fin_blocks, hipStream_t s);
 void colsum_jobs_prefix(std::vector<ColsumJob>& jobs, int* part_blocks, int* fin_blocks);

@@ -40,6 +40,10 @@ struct NormBwdParams {
     float* part;       // [B][chunks][4][C]: dg, dbias, dscale, dshift
     int C, C4, LPR, NV, ss_stride, flags;
     int pix_per_image, rows_per_chunk, chunks;
+    // dy given as the K-split partial sums of the convolution that produced it (dy_nsplit tensors, dy_stride floats apart):
+    // summed on load, so no landing pass runs between that convolution and this kernel
+    int dy_nsplit;
+    long long dy_stride;
     // nn.Dropout between the activation and this kernel's input gradient: dy is multiplied by the mask of the forward pass
     // (dropout_kernel below: Philox keyed by (seed, stream, flat float4 index)), recomputed here instead of a separate pass
     float drop_p, drop_inv_keep;
@@ -83,6 +87,9 @@ __global__ __launch_bounds__(256) void norm_act_bwd_kernel(const NormBwdParams p
             const int c4 = sub + LPR * v;
             uv[v] = (cv[v] && rv) ? *reinterpret_cast<const f32x4*>(p.u + base + 4 * c4) : z;
             dv[v] = (cv[v] && rv) ? *reinterpret_cast<const f32x4*>(p.dy + base + 4 * c4) : z;
+            if (cv[v] && rv)
+                for (int sp = 1; sp < p.dy_nsplit; ++sp)
+                    dv[v] += *reinterpret_cast<const f32x4*>(p.dy + (size_t)sp * p.dy_stride + base + 4 * c4);
             if (p.drop_p > 0.f) {
                 const uint64_t i4 = (uint64_t)(base >> 2) + c4;
                 uint32_t c[4] = {(uint32_t)i4, (uint32_t)(i4 >> 32), (uint32_t)p.drop_stream, (uint32_t)(p.drop_stream >> 32)};
@@ -177,6 +184,13 @@ __global__ __launch_bounds__(256) void norm_act_bwd_kernel(const NormBwdParams p
 // (seed, stream, flat float4 index).  grid (chunks, B).
 struct NormFwdParams {
     const float* u;
+    // u given as the K-split partial sums of the convolution (nsplit tensors, split_stride floats apart) [+ bias]: the sum is
+    // what the backward pass needs, so it is stored to u_out in the same pass (tape forward: one launch instead of a landing
+    // pass followed by the norm pass)
+    int nsplit;
+    long long split_stride;
+    const float* bias;
+    float* u_out;
     const float* g;
     const float* ss;
     const float* residual;
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(256) void norm_act_drop_kernel(const NormFwdParams 
     const int row_lo = chunk * p.rows_per_chunk, row_hi = min(row_lo + p.rows_per_chunk, p.pix_per_image);
     const float sqrtC = sqrtf((float)p.C);
     const bool has_ss = p.ss != nullptr && (p.flags & EPI_SCALE_SHIFT);
-    f32x4 gq[NV], sc[NV], sh[NV];
+    f32x4 gq[NV], sc[NV], sh[NV], bq[NV];
     bool cv[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -202,6 +216,7 @@ __global__ __launch_bounds__(256) void norm_act_drop_kernel(const NormFwdParams 
         cv[v] = c4 < p.C4;
         const f32x4 z = make_f32x4(0.f, 0.f, 0.f, 0.f), one = make_f32x4(1.f, 1.f, 1.f, 1.f);
         gq[v] = (cv[v] && p.g) ? *reinterpret_cast<const f32x4*>(p.g + 4 * c4) : one;
+        bq[v] = (cv[v] && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + 4 * c4) : z;
         sc[v] = (cv[v] && has_ss) ? *reinterpret_cast<const f32x4*>(p.ss + (size_t)b * p.ss_stride + 4 * c4) : z;
         sh[v] = (cv[v] && has_ss) ? *reinterpret_cast<const f32x4*>(p.ss + (size_t)b * p.ss_stride + p.C + 4 * c4) : z;
     }
@@ -213,7 +228,14 @@ __global__ __launch_bounds__(256) void norm_act_drop_kernel(const NormFwdParams 
         float ssq = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            uv[v] = (cv[v] && rv) ? *reinterpret_cast<const f32x4*>(p.u + base + 4 * (sub + LPR * v)) : make_f32x4(0.f, 0.f, 0.f, 0.f);
+            uv[v] = make_f32x4(0.f, 0.f, 0.f, 0.f);
+            if (cv[v] && rv) {
+                const float* up = p.u + base + 4 * (sub + LPR * v);
+                uv[v] = *reinterpret_cast<const f32x4*>(up);
+                for (int sp = 1; sp < p.nsplit; ++sp) uv[v] += *reinterpret_cast<const f32x4*>(up + (size_t)sp * p.split_stride);
+                uv[v] += bq[v];
+                if (p.u_out) *reinterpret_cast<f32x4*>(p.u_out + base + 4 * (sub + LPR * v)) = uv[v];
+            }
             ssq += uv[v].x * uv[v].x + uv[v].y * uv[v].y + uv[v].z * uv[v].z + uv[v].w * uv[v].w;
         }
         for (int m = 1; m < LPR; m <<= 1) ssq += __shfl_xor(ssq, m);
@@ -374,8 +396,16 @@ static int pow2ceil(int v) {
     return p;
 }
 
+// Row chunks per image of the norm kernels below: about 1024 workgroups in total, and no chunk smaller than the rows one
+// workgroup covers per loop iteration (4 waves x 64 / LPR rows: 16 rows at C = 64, 4 at C >= 256 -- a 4x4 map of 512 channels
+// at batch 64 is 256 workgroups, not 64)
+static int norm_chunks(int B, int pix_per_image, int C) {
+    const int lpr = std::min(64, pow2ceil(C / 4));
+    const int rows_min = 4 * (64 / lpr);
+    return std::max(1, std::min(pix_per_image / rows_min, (1024 + B - 1) / B));
+}
 size_t norm_act_bwd_ws_floats(int B, int pix_per_image, int C) {
-    const int chunks = std::max(1, std::min(pix_per_image / 16, (1024 + B - 1) / B));
+    const int chunks = norm_chunks(B, pix_per_image, C);
     return (size_t)B * chunks * 4 * C + (size_t)B * 2 * C;  // chunk partials + per-image dg / dbias
 }
 
@@ -384,17 +414,19 @@ size_t norm_act_bwd_ws_floats(int B, int pix_per_image, int C) {
 int launch_norm_act_bwd(const float* dy, const float* u, const float* g, const float* ss, int ss_stride, int pix_per_image,
                         float* du, float* ws, float* dg, float* dbias, float* dss, int dss_stride, int B, int C, int flags,
                         int accumulate, hipStream_t s, RowgradJob* defer, float drop_p, uint64_t drop_seed,
-                        uint64_t drop_stream, const float* add) {
+                        uint64_t drop_stream, const float* add, int dy_nsplit, int64_t dy_stride) {
     DM_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "norm_act_bwd: C must be a multiple of 4, at most 1024");
     DM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "norm_act_bwd: dropout probability");
     NormBwdParams p{};
     p.drop_p = drop_p; p.drop_inv_keep = 1.0f / (1.0f - drop_p); p.drop_seed = drop_seed; p.drop_stream = drop_stream;
     p.dy = dy; p.u = u; p.g = g; p.ss = ss; p.du = du; p.part = ws; p.add = add;
+    DM_REQUIRE(dy_nsplit >= 1 && dy_stride % 4 == 0, "norm_act_bwd: partial sums of dy");
+    p.dy_nsplit = dy_nsplit; p.dy_stride = dy_stride;
     p.C = C; p.C4 = C / 4;
     p.LPR = std::min(64, pow2ceil(p.C4));
     p.NV = (p.C4 + p.LPR - 1) / p.LPR;
     p.ss_stride = ss_stride; p.flags = flags; p.pix_per_image = pix_per_image;
-    p.chunks = std::max(1, std::min(pix_per_image / 16, (1024 + B - 1) / B));
+    p.chunks = norm_chunks(B, pix_per_image, C);
     p.rows_per_chunk = (pix_per_image + p.chunks - 1) / p.chunks;
     p.chunks = (pix_per_image + p.rows_per_chunk - 1) / p.rows_per_chunk;
     const int groups = 4 * (64 / p.LPR);
@@ -423,16 +455,19 @@ int launch_norm_act_bwd(const float* dy, const float* u, const float* g, const f
 
 // RMSNorm -> (scale + 1, shift) -> SiLU -> dropout [+ residual] of a training-mode Block: u, y, residual [B * pix][C]
 int launch_norm_act_drop(const float* u, const float* g, const float* ss, int ss_stride, int pix_per_image, const float* residual,
-                         float* y, int B, int C, int flags, float drop_p, uint64_t drop_seed, uint64_t drop_stream, hipStream_t s) {
+                         float* y, int B, int C, int flags, float drop_p, uint64_t drop_seed, uint64_t drop_stream, hipStream_t s,
+                         int nsplit, int64_t split_stride, const float* bias, float* u_out) {
     DM_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "norm_act_drop: C must be a multiple of 4, at most 1024");
+    DM_REQUIRE(nsplit >= 1 && split_stride % 4 == 0, "norm_act_drop: partial sums of u");
     DM_REQUIRE((flags & EPI_NORM) && (flags & EPI_SILU) && drop_p >= 0.f && drop_p < 1.f, "norm_act_drop: a Block's epilogue");
     NormFwdParams p{};
     p.u = u; p.g = g; p.ss = ss; p.residual = residual; p.y = y;
+    p.nsplit = nsplit; p.split_stride = split_stride; p.bias = bias; p.u_out = u_out;
     p.C = C; p.C4 = C / 4;
     p.LPR = std::min(64, pow2ceil(p.C4));
     const int NV = (p.C4 + p.LPR - 1) / p.LPR;
     p.ss_stride = ss_stride; p.flags = flags; p.pix_per_image = pix_per_image;
-    int chunks = std::max(1, std::min(pix_per_image / 16, (1024 + B - 1) / B));
+    int chunks = norm_chunks(B, pix_per_image, C);
     p.rows_per_chunk = (pix_per_image + chunks - 1) / chunks;
     chunks = (pix_per_image + p.rows_per_chunk - 1) / p.rows_per_chunk;
     p.drop_p = drop_p; p.drop_inv_keep = 1.0f / (1.0f - drop_p); p.drop_seed = drop_seed; p.drop_stream = drop_stream;

@@ -304,7 +304,7 @@ class DenoisingDiffusion:
         return out
 
     def p_losses(self, x_start, t, noise=None, offset_noise_strength=None, cond=None, *, return_model_out=False,
-                 loss_scale=1.0, accumulate=False, self_cond=None, text_emb=None, offset_noise=None):
+                 loss_scale=1.0, accumulate=False, self_cond=None, text_emb=None, offset_noise=None, sync=True):
         """:823-889: returns the loss (0-dim CPU tensor); the parameter gradients stay on the model
         (``self.model.grad(name)`` / ``.grads()``) -- loss and backward are one call of the library, there is no autograd
         graph to keep.  ``loss_scale`` / ``accumulate`` are the micro-batch loop of ``Trainer.train`` (:1164-1176):
@@ -312,7 +312,8 @@ class DenoisingDiffusion:
         calls condition on a gradient-free prediction of x_start (:846-855; ``self_cond=True / False`` forces the branch).
         Offset noise (:830-834; ``offset_noise``: the (B, C) draw, for tests) and the immiscible noise assignment
         (:815-817: q_sample mixes in ``noise[assign]`` while the target stays the unpermuted ``noise``, as in the
-        reference) are on this path; the hybrid (KL) loss is not."""
+        reference) are on this path; the hybrid (KL) loss is not.  ``sync=False`` returns the loss as a 0-dim DEVICE tensor
+        without waiting for the GPU -- what the reference's loss is until ``Trainer`` calls ``.item()`` on it (:1173)."""
         if offset_noise_strength is None:
             offset_noise_strength = self.offset_noise_strength
         sc_mode = 0
@@ -349,6 +350,7 @@ class DenoisingDiffusion:
             cc = int(cond.shape[1])
         ctx, m = self.model._ctx(text_emb, b) if text_emb is not None else (None, 0)
         loss = C.c_float(0.0)
+        loss_ref = C.byref(loss) if sync else None
         out = torch.empty_like(x_start) if return_model_out else None
         t_arr = (C.c_int64 * b)(*[int(v) for v in t_cpu.tolist()])
         _lib.check(self._lib.dm_unet_loss_backward(
@@ -356,8 +358,12 @@ class DenoisingDiffusion:
             C.cast(coef.data_ptr(), C.POINTER(C.c_float)), _lib.ptr(noise), _lib.ptr(noise_q), _lib.ptr(cond), cc,
             _lib.ptr(ctx), m, sc_mode,
             self._objective_id,
-            float(loss_scale), int(bool(accumulate)), C.byref(loss), _lib.ptr(out), b, h, w, stream))
-        val = torch.tensor(loss.value, dtype=torch.float32)
+            float(loss_scale), int(bool(accumulate)), loss_ref, _lib.ptr(out), b, h, w, stream))
+        if sync:
+            val = torch.tensor(loss.value, dtype=torch.float32)
+        else:
+            val = torch.empty((), device=self.device, dtype=torch.float32)
+            _lib.check(self._lib.dm_unet_train_scalar(self.model._handle, 0, _lib.ptr(val), stream))
         return (val, out) if return_model_out else val
 
     def forward(self, img, *args, **kwargs):

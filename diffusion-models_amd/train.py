@@ -153,13 +153,15 @@ def load_checkpoint(path, diffusion, *, ema: Optional[EMA] = None):
 
 
 def train_step(diffusion, micro_batches: Iterable[torch.Tensor], *, lr=1e-4, betas=(0.9, 0.99), eps=1e-8,
-               max_grad_norm=1.0, ema: Optional[EMA] = None, t=None, noise=None, group=None):
+               max_grad_norm=1.0, ema: Optional[EMA] = None, t=None, noise=None, group=None, sync=True):
     """One iteration of ``Trainer.train`` (:1164-1190).  ``micro_batches``: the ``gradient_accumulate_every`` image batches
     (in [0, 1]) of the iteration.  ``t`` / ``noise`` (lists, one per micro-batch) inject the random draws for tests.
     Under ``torch.distributed`` (one process per GPU, as ``accelerate`` runs the reference's Trainer) every rank computes the
     gradients of ITS micro-batches and ONE in-place all-reduce of the flat gradient buffer (RCCL over xGMI) averages them
     before the optimiser step -- all 245 gradients in a single collective; every rank then takes the same step.
-    Returns (total_loss of this rank, grad_norm)."""
+    Returns (total_loss of this rank, grad_norm): floats, or with ``sync=False`` 0-dim device tensors -- the iteration is
+    then only ENQUEUED when the call returns (no host round trip: the reference's loop runs ahead of the GPU the same way
+    until ``loss.item()``), so back-to-back iterations leave no idle gaps on the GPU."""
     batches = list(micro_batches)
     k = len(batches)
     total = 0.0
@@ -167,7 +169,8 @@ def train_step(diffusion, micro_batches: Iterable[torch.Tensor], *, lr=1e-4, bet
         x = diffusion.normalize(data.to(diffusion.device, torch.float32))
         ti = t[i] if t is not None else torch.randint(0, diffusion.num_timesteps, (x.shape[0],)).long()
         ni = noise[i] if noise is not None else None
-        total += float(diffusion.p_losses(x, ti, noise=ni, loss_scale=1.0 / k, accumulate=i > 0))
+        loss = diffusion.p_losses(x, ti, noise=ni, loss_scale=1.0 / k, accumulate=i > 0, sync=sync)
+        total = (total + float(loss)) if sync else (loss if i == 0 else total + loss)
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized():  # also at world size 1: the collective is the same code path
@@ -175,7 +178,7 @@ def train_step(diffusion, micro_batches: Iterable[torch.Tensor], *, lr=1e-4, bet
         torch.cuda.current_stream(diffusion.device).synchronize()
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         flat.div_(dist.get_world_size(group))  # DDP averages; the buffer is the library's own (zero-copy view)
-    norm = diffusion.model.optimizer_step(lr=lr, betas=betas, eps=eps, max_grad_norm=max_grad_norm)
+    norm = diffusion.model.optimizer_step(lr=lr, betas=betas, eps=eps, max_grad_norm=max_grad_norm, sync=sync)
     if ema is not None:
         ema.update()
     return total, norm

@@ -212,15 +212,21 @@ class Unet:
 
         return torch.as_tensor(_View(), device=self.device)
 
-    def optimizer_step(self, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=1.0) -> float:
+    def optimizer_step(self, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=1.0, sync=True):
         """``clip_grad_norm_(max_grad_norm)`` + ``Adam(lr, betas).step()`` of ``Trainer.train``
         (denoising_diffusion.py:1006, :1178-1183) on the device-resident parameters; every packed weight buffer is then
-        rebuilt on the device.  Returns the total gradient norm (before clipping)."""
+        rebuilt on the device.  Returns the total gradient norm (before clipping): a float, or with ``sync=False`` a
+        0-dim device tensor (``clip_grad_norm_`` returns one too) without waiting for the GPU."""
         norm = C.c_float(0.0)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self._lib.dm_unet_optimizer_step(self._handle, lr, betas[0], betas[1], eps,
-                                                    max_grad_norm if max_grad_norm else 0.0, C.byref(norm), stream))
-        return float(norm.value)
+                                                    max_grad_norm if max_grad_norm else 0.0, C.byref(norm) if sync else None,
+                                                    stream))
+        if sync:
+            return float(norm.value)
+        out = torch.empty((), device=self.device, dtype=torch.float32)
+        _lib.check(self._lib.dm_unet_train_scalar(self._handle, 1, _lib.ptr(out), stream))
+        return out
 
     def ema_update(self, decay: float, copy: bool = False):
         """``ema = ema * decay + online * (1 - decay)`` (or a copy) on the device-resident EMA parameters."""

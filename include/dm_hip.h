@@ -327,7 +327,7 @@ int dm_unet_get_grad(dm_unet* u, const char* name, float* out_dev, void* stream)
  * (DD/denoising_diffusion_text_conditional.py:131-214, p_losses :476-542), concat or cross-attention per the handle's
  * text_mode.  noise_q (optional): the noise q_sample mixes in when it is not `noise` itself -- with immiscible=True the
  * reference's q_sample re-assigns the noise rows inside (:815-817) while p_losses keeps the unpermuted tensor as the
- * target (:865).  The call synchronises the stream. */
+ * target (:865).  The call synchronises the stream unless loss_out_host is NULL (then see dm_unet_train_scalar). */
 int dm_unet_loss_backward(dm_unet* u, const float* x_start, const int64_t* t_host, const float* coef_host,
                           const float* noise, const float* noise_q, const float* cond, int cond_channels, const float* ctx,
                           int ctx_tokens,
@@ -350,6 +350,11 @@ int dm_unet_loss_backward(dm_unet* u, const float* x_start, const int64_t* t_hos
  *   dm_unet_check_device_pack: self-check, number of packed buffers whose device packer differs from the host packer */
 int dm_unet_optimizer_step(dm_unet* u, float lr, float beta1, float beta2, float eps, float max_grad_norm,
                            float* grad_norm_out_host, void* stream);
+/* The loop's scalars without a host round trip (the reference's loss is a device tensor until Trainer calls loss.item(),
+ * DD/denoising_diffusion.py:1173): with loss_out_host == NULL dm_unet_loss_backward, and with grad_norm_out_host == NULL
+ * dm_unet_optimizer_step, return as soon as their kernels are enqueued; dm_unet_train_scalar copies the loss of the last
+ * loss / backward call (which = 0) or the total gradient norm of the last optimiser step (which = 1) to a DEVICE float. */
+int dm_unet_train_scalar(dm_unet* u, int which, float* out_dev, void* stream);
 int dm_unet_ema_update(dm_unet* u, float decay, int copy, void* stream);
 int dm_unet_get_param(dm_unet* u, const char* name, int which, float* out_dev, void* stream);
 int dm_unet_set_train_tensor(dm_unet* u, const char* name, int which, const float* src_dev, void* stream);

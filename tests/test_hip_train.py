@@ -533,3 +533,35 @@ def test_text_conditional_training_step_vs_oracle(variant):
             assert float(got[k].norm()) < 1e-6 * scale, k
         else:
             assert rel_l2(got[k].cpu(), w) < GRAD_TOL, (k, rel_l2(got[k].cpu(), w))
+
+
+@pytest.mark.parametrize("cross", [False, True])
+def test_caption_dropout_leaves_no_stale_text_gradients(cross):
+    """p_losses with captions, then p_losses with text_emb=None on the same text-conditional U-Net (how caption dropout is
+    trained; the reference's forward defaults text_emb to None): the second call visits no text parameter -- torch leaves
+    their .grad None -- so their gradients must read zero, not the first call's values, and an optimiser step must leave
+    those parameters where they were."""
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3, text_condition=True, use_cross_attn=cross)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=2 if cross else 3)
+    u = dm.Unet(dim=32, dim_mults=(1, 2), channels=3, text_condition=True, use_cross_attn=cross, device=DEV)
+    u.load_state_dict(sd)
+    d = dm.TextConditionalDenoisingDiffusion(model=u, image_size=16, timesteps=1000).train()
+    g = torch.Generator().manual_seed(45)
+    x_start = torch.rand((4, 3, 16, 16), generator=g) * 2 - 1
+    t = torch.randint(0, 1000, (4,), generator=g)
+    noise = torch.randn((4, 3, 16, 16), generator=g)
+    emb = torch.randn((4, 3, 512), generator=g) if cross else torch.randn((4, 512), generator=g)
+    text_names = [k for k in sd if k.startswith(("text_", "cross_attn"))]
+    assert text_names
+    d.p_losses(x_start, t, emb, noise)
+    assert any(float(u.grad(k).abs().sum()) > 0 for k in text_names)
+    d.p_losses(x_start, t, None, noise)
+    for k in text_names:
+        assert float(u.grad(k).abs().sum()) == 0.0, k
+    assert float(u.grad("init_conv.weight").abs().sum()) > 0
+    before = {k: u.state_dict()[k].clone() for k in text_names}
+    u.optimizer_step(lr=1e-3)
+    after = u.state_dict()
+    for k in text_names:
+        assert torch.equal(before[k], after[k]), k
+    assert not torch.equal(sd["init_conv.weight"], after["init_conv.weight"].cpu())
