@@ -173,6 +173,76 @@ def step_breakdown(ms_per_denoise_step: float, pmc_steps: int = 50):
     return out, src
 
 
+TRAIN_FAMILIES = (("wgrad", "wgrad_"), ("wino4", "wino4_mfma_kernel"), ("wino", "wino_mfma_kernel"),
+                  ("upwino", "upwino_mfma_kernel"), ("pw", "pw_mfma_kernel"), ("norm_bwd", "norm_act_bwd"),
+                  ("norm_fwd", "norm_act"), ("linattn_bwd", "linattn_bwd"), ("linattn", "linattn_"), ("attn", "att"),
+                  ("optimiser", ("adam_ema", "pack_", "scatter_copy", "sumsq", "clip_coef", "lerp", "rot_transpose")),
+                  ("linear", ("linear_", "mlp_rows", "colsum", "rowgrad", "act_")), ("init7", "init7_mfma_kernel"))
+
+
+def train_family_of(kernel: str) -> str:
+    for fam, prefix in TRAIN_FAMILIES:
+        if kernel.startswith(prefix):
+            return fam
+    return "other"
+
+
+def train_roofline(ms_per_iteration: float):
+    """The training iteration against the f32-MFMA peak by EXECUTED FLOPs, as the sampling step is priced: the committed
+    PMC pass of `tools/train_time.py --batch 64 --dropout 0.1 --full-only` (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 FLOPs per
+    launch x launches / iterations, HBM bytes from FETCH_SIZE x2 + WRITE_SIZE) over THIS run's measured iteration time; a
+    family's share is its kernel time in the committed rocprofv3 --kernel-trace --stats summary of the same command.
+    Accepted only when the file's hash of csrc/ equals the sources'."""
+    import csv
+    import re
+
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*_train_pmc.json"))
+    if not files:
+        return {"executed_frac": None, "source": "no profiles/r*_train_pmc.json"}
+    newest = max(files, key=lambda p: tuple(int(v) for v in re.findall(r"\d+", os.path.basename(p))))
+    with open(newest) as f:
+        doc = json.load(f)
+    src = os.path.basename(newest)
+    if doc.get("_csrc_sha") != csrc_sha():
+        return {"executed_frac": None, "source": f"{src} was collected on other kernel sources"}
+    iters = doc.get("_iterations")
+    if not iters:
+        return {"executed_frac": None, "source": f"{src} does not record its iteration count"}
+    flops, launches, hbm = {}, 0.0, 0.0
+    for k, row in doc.items():
+        if not isinstance(row, dict) or "launches" not in row:
+            continue
+        fam = train_family_of(k.replace("dm::", ""))
+        launches += row["launches"] / iters
+        hbm += (row["fetch_bytes_per_launch_corrected"] + row["write_bytes_per_launch"]) * row["launches"] / iters
+        if "mfma_mops_f32_per_launch" in row:
+            flops[fam] = flops.get(fam, 0.0) + row["mfma_mops_f32_per_launch"] * 512.0 * row["launches"] / iters
+    total = sum(flops.values())
+    sec = ms_per_iteration * 1e-3
+    out = {"bound": "mfma", "executed_gflop_per_iteration": total / 1e9, "executed_tflops": total / sec / 1e12,
+           "executed_frac": total / sec / 1e12 / PEAK_F32_TFLOPS, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+           "launches_per_iteration": round(launches, 1), "hbm_bytes_per_iteration": hbm, "hbm_TBps": hbm / sec / 1e12,
+           "source": src}
+    stats = os.path.join(ROOT, "profiles", src.replace("_train_pmc.json", "_train_kernel_stats.csv"))
+    fam_ns, all_ns = {}, 0.0
+    if os.path.exists(stats):
+        for r in csv.DictReader(open(stats)):
+            name = re.sub(r"^void\s+", "", r["Name"]).replace("dm::", "")
+            ns = float(r["TotalDurationNs"])
+            all_ns += ns
+            fam_ns[train_family_of(name)] = fam_ns.get(train_family_of(name), 0.0) + ns
+    fams = {}
+    for fam in sorted(set(flops) | set(fam_ns), key=lambda f: -fam_ns.get(f, 0.0)):
+        share = fam_ns.get(fam, 0.0) / all_ns if all_ns else None
+        row = {"share_of_iteration": share}
+        if share and flops.get(fam):
+            row["executed_tflops"] = flops[fam] / (share * sec) / 1e12
+            row["executed_frac"] = row["executed_tflops"] / PEAK_F32_TFLOPS
+        fams[fam] = row
+    out["families"] = fams
+    return out
+
+
 def other_configs(dev, replays: int = 100):
     """BASELINE configs 3, 4 and 5 on this GPU, timed in this process after the headline region: graph-replayed sampler,
     synthetic weights, `replays` denoise steps per timing (the per-step cost does not depend on the schedule length)."""
@@ -197,10 +267,11 @@ def other_configs(dev, replays: int = 100):
     S = replays
     out = {}
     u = unet(dim=64, dim_mults=(1, 2, 4, 8), channels=3)
-    d = dm.DenoisingDiffusion(u, image_size=64, timesteps=1000, sampling_timesteps=S)
+    d = dm.DenoisingDiffusion(u, image_size=64, timesteps=1000)  # config 3 is DDPM: the p_sample step with its Philox draw
     for B in (32, 8):
-        dt = timed(lambda: d.sample(batch_size=B, seed=1))
+        dt = timed(lambda: d.p_sample_loop((B, 3, 64, 64), seed=1, max_steps=S))
         out[f"config3_64x64_ddpm1000_b{B}_per_gpu"] = {"ms_per_denoise_step": 1e3 * dt / S, "replays": S,
+                                                      "sampler": "p_sample_loop, first %d of 1000 steps" % S,
                                                       "images_per_s_per_gpu": B / (1000 * dt / S)}
     del d, u
     u4 = unet(dim=64, dim_mults=(1, 2, 4, 8), channels=4)
@@ -257,6 +328,7 @@ def train_leg(dev, with_cpu: bool, batch: int = 64, iters: int = 10):
     assert math.isfinite(loss) and math.isfinite(norm) and loss > 0 and norm > 0, (loss, norm)
     out = {"workload": f"Trainer.train iteration, 32x32 U-Net dim 64, batch {batch}, dropout 0.1, Adam + clip + EMA",
            "ms_per_iteration": 1e3 * dt, "images_per_s": batch / dt, "iterations_timed": iters, "loss": loss, "grad_norm": norm}
+    out["roofline"] = train_roofline(1e3 * dt)
     del d, u, ema
     if with_cpu:
         from oracle import train_oracle as to

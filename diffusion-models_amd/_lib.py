@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DM_LIB") or os.path.join(_HERE, "libdm_hip.so")
 DM_MAX_STAGES = 8
 DM_COEFS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/dm_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
@@ -30,7 +30,7 @@ EXPORTS = (
     "dm_op_attention", "dm_op_sampler_update",
     "dm_conv_create", "dm_conv_destroy", "dm_conv_forward", "dm_op_pool2d", "dm_op_resize_bilinear",
     "dm_op_copy_channels_nhwc", "dm_op_global_avgpool", "dm_op_linear",
-    "dm_unet_train_enable", "dm_unet_grad_floats", "dm_unet_grads_flat", "dm_unet_get_grad", "dm_unet_loss_backward", "dm_op_q_sample",
+    "dm_unet_train_enable", "dm_unet_grad_floats", "dm_unet_grads_flat", "dm_unet_get_grad", "dm_unet_loss_backward", "dm_unet_loss_backward_ex", "dm_op_q_sample",
     "dm_op_offset_noise", "dm_op_cdist", "dm_op_gather_rows", "dm_op_lincomb", "dm_op_mask_mix",
     "dm_unet_optimizer_step", "dm_unet_train_scalar", "dm_unet_ema_update", "dm_unet_get_param", "dm_unet_set_train_tensor", "dm_unet_adam_step",
     "dm_unet_train_sync", "dm_unet_check_device_pack",
@@ -153,6 +153,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_unet_grads_flat.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     lib.dm_unet_loss_backward.argtypes = [vp, fp, C.POINTER(i64), C.POINTER(C.c_float), fp, fp, fp, i32, fp, i32, i32, i32,
                                           C.c_float, i32, C.POINTER(C.c_float), fp, i32, i32, i32, vp]
+    lib.dm_unet_loss_backward_ex.argtypes = [vp, C.POINTER(TrainArgs)]
     lib.dm_unet_optimizer_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), vp]
     lib.dm_unet_train_scalar.argtypes = [vp, i32, fp, vp]
     lib.dm_unet_ema_update.argtypes = [vp, C.c_float, i32, vp]
@@ -178,6 +179,16 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_op_attention_bwd.argtypes = [fp] * 13 + [i32] * 6 + [vp]
     lib.dm_profile_enable.argtypes = [i32]
     lib.dm_profile_read.argtypes = [C.POINTER(ProfileRow), i32, C.POINTER(i32)]
+
+
+class TrainArgs(C.Structure):
+    """``dm_train_args`` of include/dm_hip.h (dm_unet_loss_backward_ex)."""
+    _fields_ = [("x_start", C.c_void_p), ("t_host", C.POINTER(C.c_int64)), ("coef_host", C.POINTER(C.c_float)),
+                ("coef_stride", C.c_int), ("noise", C.c_void_p), ("noise_q", C.c_void_p), ("cond", C.c_void_p),
+                ("cond_channels", C.c_int), ("ctx", C.c_void_p), ("ctx_tokens", C.c_int), ("self_cond", C.c_int),
+                ("objective", C.c_int), ("loss_scale", C.c_float), ("accumulate", C.c_int),
+                ("loss_out_host", C.POINTER(C.c_float)), ("model_out", C.c_void_p), ("B", C.c_int), ("H", C.c_int),
+                ("W", C.c_int), ("stream", C.c_void_p), ("loss_terms", C.c_int), ("kl_scale", C.c_float)]
 
 
 def load() -> C.CDLL:

@@ -1395,7 +1395,7 @@ static int check_hw(dm_unet* u, int H, int W) {
 extern "C" {
 
 const char* dm_last_error(void) { return g_err.c_str(); }
-int dm_abi_version(void) { return 3; }
+int dm_abi_version(void) { return 4; }
 
 int dm_unet_create(const dm_unet_cfg* cfg, int device, dm_unet** out) {
     DM_REQUIRE(cfg && out, "null argument");

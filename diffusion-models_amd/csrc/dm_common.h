@@ -431,14 +431,17 @@ size_t linear_dgrad_ws_floats(int R, int I, int O);
 int launch_linear_dgrad(const float* dy, int ldy, const float* W, float* dx, int ldx, int R, int I, int O, float* ws,
                         hipStream_t s);
 // per-sample scalars of the training step, gathered on the host as `extract` does: [0] sqrt_alphas_cumprod[t],
-// [1] sqrt_one_minus_alphas_cumprod[t], [2] loss_weight[t], [3] 0, [4] sqrt_recip_alphas_cumprod[t], [5] sqrt_recipm1_alphas_cumprod[t], [6..7] 0
-#define DM_TRAIN_COEFS 8
+// [1] sqrt_one_minus_alphas_cumprod[t], [2] loss_weight[t], [3] (t > 0), [4] sqrt_recip_alphas_cumprod[t],
+// [5] sqrt_recipm1_alphas_cumprod[t], [6..7] 0, and for the hybrid KL term [8] posterior_mean_coef1[t], [9] posterior_mean_coef2[t],
+// [10] posterior_variance[t], [11] posterior_log_variance_clipped[t]
+#define DM_TRAIN_COEFS 12
 int launch_pred_x_start(const float* x, const float* out, const float* coef_dev, float* xs, int B, int per_sample, int objective,
                         hipStream_t s);
 int launch_q_sample(const float* x_start, const float* noise, const float* coef_dev, float* x, int B, int per_sample,
                     hipStream_t s);
 int launch_mse_loss(const float* out, const float* x_start, const float* noise, const float* coef_dev, float* dout,
-                    float* part, float* loss, int B, int per_sample, int objective, float loss_scale, hipStream_t s);
+                    float* part, float* loss, int B, int per_sample, int objective, float loss_scale, hipStream_t s,
+                    int terms = 1, const float* xq = nullptr, float* klpart = nullptr, float kl_scale = 0.f);
 int launch_lerp(float* ema, const float* p, int64_t n, float decay, hipStream_t s);
 // device mirrors of the host weight packers (pack_kernels.hip)
 int launch_pack_direct(const float* oihw, float* packed, int Cout, int C0, int C1, int KH, int KW, hipStream_t s);

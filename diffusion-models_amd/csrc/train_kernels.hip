@@ -1060,45 +1060,96 @@ int launch_pred_x_start(const float* x, const float* out, const float* coef_dev,
     return 0;
 }
 
-// one workgroup per sample: part[b] = loss_weight * mean((out - target)^2); dout = 2 (out - target) * w / (per_sample * B)
+// one workgroup per sample: part[b] = loss_weight * mean((out - target)^2); dout = 2 (out - target) * w / (per_sample * B).
+// terms: bit 0 the weighted MSE, bit 1 the hybrid KL term of p_losses (:880-897), written as the reference writes it --
+//   x0 = pred_x_start(out) clamped to [-1, 1] (p_mean_variance, clip_denoised = True: clamp_ passes the gradient inside the
+//   closed interval);  model_mean = coef1 x0 + coef2 x;  posterior_mean = coef1 x_start + coef2 x (q_posterior, :594-601);
+//   kl = 0.5 (plv - mlv + (exp(mlv) + (model_mean - posterior_mean)^2) / posterior_variance - 1), mlv = plv =
+//   posterior_log_variance_clipped[t];  klpart[b] = mean(kl) * [t_b > 0];  loss += kl_weight * sum_b klpart[b] / (n_pos + 1e-8)
+// -- including the division by posterior_variance[t] = 0 at t = 0 that the mask multiplies afterwards (inf * 0): a batch that
+// holds a t = 0 sample has a NaN loss and NaN gradients in the reference, and here.
+// coef[b]: [8] posterior_mean_coef1, [9] posterior_mean_coef2, [10] posterior_variance, [11] posterior_log_variance_clipped,
+// [3] 1 if t_b > 0 else 0.  xq: the q_sample output the U-Net saw (its first C channels).
 __global__ void mse_loss_kernel(const float* __restrict__ out, const float* __restrict__ x_start, const float* __restrict__ noise,
-                                const float* __restrict__ coef, float* __restrict__ dout, float* __restrict__ part,
-                                int per_sample, int B, int objective, float loss_scale) {
+                                const float* __restrict__ xq, const float* __restrict__ coef, float* __restrict__ dout,
+                                float* __restrict__ part, float* __restrict__ klpart, int per_sample, int B, int objective,
+                                float loss_scale, int terms, float kl_scale) {
+#pragma clang fp contract(off)  // the KL expression keeps the roundings of the reference's tensor expression
     __shared__ double red[256];
+    __shared__ double red2[256];
     const int b = blockIdx.x;
     const float* c = coef + DM_TRAIN_COEFS * b;
-    const float gscale = loss_scale * 2.0f * c[2] / ((float)per_sample * (float)B);
-    double s = 0.0;
+    const float gscale = (terms & 1) ? loss_scale * 2.0f * c[2] / ((float)per_sample * (float)B) : 0.f;
+    // d(loss) / d(kl element) = loss_scale * kl_weight * mask_b / (n_pos + 1e-8) / per_sample  (kl_scale = kl_weight / (n_pos + 1e-8))
+    const float kscale = loss_scale * kl_scale * c[3] / (float)per_sample;
+    const float emlv = (terms & 2) ? expf(c[11]) : 0.f;
+    double s = 0.0, sk = 0.0;
     for (int i = threadIdx.x; i < per_sample; i += 256) {
         const size_t k = (size_t)b * per_sample + i;
         float tgt;
         if (objective == 0) tgt = noise[k];
         else if (objective == 1) tgt = x_start[k];
         else tgt = c[0] * noise[k] - c[1] * x_start[k];
-        const float d = out[k] - tgt;
+        const float o = out[k];
+        const float d = o - tgt;
         s += (double)d * d;
-        dout[k] = d * gscale;
+        float g = d * gscale;
+        if (terms & 2) {
+            const float x = xq[k];
+            float x0, dx0;  // pred_x_start and its derivative w.r.t. the model output
+            if (objective == 0) { x0 = c[4] * x - c[5] * o; dx0 = -c[5]; }
+            else if (objective == 1) { x0 = o; dx0 = 1.0f; }
+            else { x0 = c[0] * x - c[1] * o; dx0 = -c[1]; }
+            const bool inside = x0 >= -1.0f && x0 <= 1.0f;
+            const float x0c = fminf(fmaxf(x0, -1.0f), 1.0f);
+            const float mm = c[8] * x0c + c[9] * x;
+            const float pm = c[8] * x_start[k] + c[9] * x;
+            const float diff = mm - pm;
+            const float kl = 0.5f * ((c[11] - c[11]) + (emlv + diff * diff) / c[10] - 1.0f);
+            sk += (double)kl;
+            // 0.5 * 2 diff / pv * coef1 * [inside] * dx0, then the chain of means; formed in the reference's order so that
+            // t = 0 (pv = 0, mask 0) yields 0 * inf = NaN as autograd does
+            const float gk = kscale * (diff / c[10]) * (inside ? c[8] * dx0 : 0.0f);
+            g = (terms & 1) ? g + gk : gk;
+        }
+        dout[k] = g;
     }
     red[threadIdx.x] = s;
+    red2[threadIdx.x] = sk;
     __syncthreads();
     for (int m = 128; m > 0; m >>= 1) {
-        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        if ((int)threadIdx.x < m) {
+            red[threadIdx.x] += red[threadIdx.x + m];
+            red2[threadIdx.x] += red2[threadIdx.x + m];
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) part[b] = (float)(red[0] / per_sample) * c[2];
+    if (threadIdx.x == 0) {
+        part[b] = (terms & 1) ? (float)(red[0] / per_sample) * c[2] : 0.f;
+        if (terms & 2) klpart[b] = (float)(red2[0] / per_sample) * c[3];  // kl * mask, as the reference multiplies
+    }
 }
-__global__ void mean_kernel(const float* __restrict__ part, int B, float* __restrict__ loss, float loss_scale) {
+__global__ void mean_kernel(const float* __restrict__ part, const float* __restrict__ klpart, int B, float* __restrict__ loss,
+                            float loss_scale, float kl_scale) {
     double s = 0.0;
     for (int b = 0; b < B; ++b) s += part[b];
-    *loss = (float)(s / B) * loss_scale;
+    float v = (float)(s / B);
+    if (klpart) {
+        float k = 0.f;
+        for (int b = 0; b < B; ++b) k += klpart[b];
+        v += kl_scale * k;  // loss.mean() of (loss_b + 0.001 * kl): the scalar joins every row
+    }
+    *loss = v * loss_scale;
 }
 // loss_scale: 1 / gradient_accumulate_every of Trainer.train (:1171) -- scales the reported loss and every gradient
 int launch_mse_loss(const float* out, const float* x_start, const float* noise, const float* coef_dev, float* dout,
-                    float* part, float* loss, int B, int per_sample, int objective, float loss_scale, hipStream_t s) {
-    hipLaunchKernelGGL(mse_loss_kernel, dim3(B), dim3(256), 0, s, out, x_start, noise, coef_dev, dout, part, per_sample, B,
-                       objective, loss_scale);
+                    float* part, float* loss, int B, int per_sample, int objective, float loss_scale, hipStream_t s,
+                    int terms, const float* xq, float* klpart, float kl_scale) {
+    DM_REQUIRE(terms >= 1 && terms <= 3 && (!(terms & 2) || (xq && klpart)), "mse_loss: terms");
+    hipLaunchKernelGGL(mse_loss_kernel, dim3(B), dim3(256), 0, s, out, x_start, noise, xq, coef_dev, dout, part, klpart,
+                       per_sample, B, objective, loss_scale, terms, kl_scale);
     DM_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1), 0, s, part, B, loss, loss_scale);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1), 0, s, part, (terms & 2) ? klpart : nullptr, B, loss, loss_scale, kl_scale);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }

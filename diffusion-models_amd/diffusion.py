@@ -87,24 +87,14 @@ class DenoisingDiffusion:
         assert objective in {"pred_noise", "pred_x0", "pred_v"}, "objective must be pred_noise, pred_x0 or pred_v"
         self.objective = objective
         self._objective_id = _lib.OBJECTIVES[objective]
-        sched = make_schedule(timesteps, beta_schedule, **schedule_fn_kwargs)  # raises ValueError on unknown name
+        # raises ValueError on an unknown schedule name; loss_weight (ones, or from the float64 SNR, :532-549) comes with it
+        sched = make_schedule(timesteps, beta_schedule, ddpm=ddpm, objective=objective, min_snr_loss_weight=min_snr_loss_weight,
+                              min_snr_gamma=min_snr_gamma, **schedule_fn_kwargs)
         self.num_timesteps = int(sched["betas"].shape[0])
         self.sampling_timesteps = sampling_timesteps if sampling_timesteps is not None else self.num_timesteps
         assert self.sampling_timesteps <= self.num_timesteps
         self.is_ddim_sampling = self.sampling_timesteps < self.num_timesteps
         self.ddim_sampling_eta = ddim_sampling_eta
-        if not ddpm:  # loss weight from the signal-to-noise ratio (:535-549); ddpm=True keeps ones (:532-533)
-            ac = sched["alphas_cumprod"].double()
-            snr = ac / (1 - ac)
-            clipped = snr.clone()
-            if min_snr_loss_weight:
-                clipped.clamp_(max=min_snr_gamma)
-            lw = {"pred_noise": clipped / snr, "pred_x0": clipped, "pred_v": clipped / (snr + 1)}[objective]
-            sched["loss_weight"] = lw.to(torch.float32)
-        # training options the HIP training step does not implement are refused where they would change the result
-        # hybrid_loss (:880-897) is not built: the reference's KL term divides by posterior_variance[t], which is 0 at
-        # t = 0, and masks the result afterwards (inf * 0): its loss is NaN for every batch that holds a t = 0 sample
-        assert not hybrid_loss, "hybrid (KL) loss is not on the HIP path"
         self.offset_noise_strength = offset_noise_strength
         self.immiscible, self.hybrid_loss = immiscible, hybrid_loss
         self._sched = sched  # fp32 CPU tensors; the per-step scalars are derived from them on the host
@@ -255,14 +245,15 @@ class DenoisingDiffusion:
         return self
 
     def _tcoef(self, t: torch.Tensor) -> torch.Tensor:
-        """(B, 8): what `extract` gathers for q_sample / predict_v / the loss weight / predict_start_from_noise at each
-        sample's timestep (DM_TRAIN_COEFS of include/dm_hip.h)."""
+        """(B, 12): what `extract` gathers for q_sample / predict_v / the loss weight / predict_start_from_noise and, for the
+        hybrid KL term, q_posterior at each sample's timestep (DM_TRAIN_COEFS rows of include/dm_hip.h)."""
         t = t.detach().to("cpu", torch.long)
         s = self._sched
         z = torch.zeros(t.shape[0])
-        return torch.stack([s["sqrt_alphas_cumprod"][t], s["sqrt_one_minus_alphas_cumprod"][t], s["loss_weight"][t], z,
-                            s["sqrt_recip_alphas_cumprod"][t], s["sqrt_recipm1_alphas_cumprod"][t], z, z],
-                           dim=1).to(torch.float32).contiguous()
+        return torch.stack([s["sqrt_alphas_cumprod"][t], s["sqrt_one_minus_alphas_cumprod"][t], s["loss_weight"][t],
+                            (t > 0).float(), s["sqrt_recip_alphas_cumprod"][t], s["sqrt_recipm1_alphas_cumprod"][t], z, z,
+                            s["posterior_mean_coef1"][t], s["posterior_mean_coef2"][t], s["posterior_variance"][t],
+                            s["posterior_log_variance_clipped"][t]], dim=1).to(torch.float32).contiguous()
 
     def noise_assignment(self, x_start, noise):
         """:805-809 (immiscible diffusion): the assignment of noise rows to images that minimises the total L2 distance.
@@ -312,7 +303,11 @@ class DenoisingDiffusion:
         calls condition on a gradient-free prediction of x_start (:846-855; ``self_cond=True / False`` forces the branch).
         Offset noise (:830-834; ``offset_noise``: the (B, C) draw, for tests) and the immiscible noise assignment
         (:815-817: q_sample mixes in ``noise[assign]`` while the target stays the unpermuted ``noise``, as in the
-        reference) are on this path; the hybrid (KL) loss is not.  ``sync=False`` returns the loss as a 0-dim DEVICE tensor
+        reference) are on this path, and so is the hybrid (KL) term (:880-897, ``hybrid_loss=True``): the reference evaluates it
+        through ``p_mean_variance``, a second forward pass with gradients -- without dropout that pass repeats the first bit
+        for bit and both terms share one pass here; with dropout it draws new masks, so the KL term runs as a second,
+        accumulating call.  As in the reference, a batch that holds a ``t = 0`` sample has a NaN loss (the KL expression
+        divides by ``posterior_variance[0] = 0`` before the mask multiplies).  ``sync=False`` returns the loss as a 0-dim DEVICE tensor
         without waiting for the GPU -- what the reference's loss is until ``Trainer`` calls ``.item()`` on it (:1173)."""
         if offset_noise_strength is None:
             offset_noise_strength = self.offset_noise_strength
@@ -350,20 +345,44 @@ class DenoisingDiffusion:
             cc = int(cond.shape[1])
         ctx, m = self.model._ctx(text_emb, b) if text_emb is not None else (None, 0)
         loss = C.c_float(0.0)
-        loss_ref = C.byref(loss) if sync else None
         out = torch.empty_like(x_start) if return_model_out else None
         t_arr = (C.c_int64 * b)(*[int(v) for v in t_cpu.tolist()])
-        _lib.check(self._lib.dm_unet_loss_backward(
-            self.model._handle, _lib.ptr(x_start), C.cast(t_arr, C.POINTER(C.c_int64)),
-            C.cast(coef.data_ptr(), C.POINTER(C.c_float)), _lib.ptr(noise), _lib.ptr(noise_q), _lib.ptr(cond), cc,
-            _lib.ptr(ctx), m, sc_mode,
-            self._objective_id,
-            float(loss_scale), int(bool(accumulate)), loss_ref, _lib.ptr(out), b, h, w, stream))
+        a = _lib.TrainArgs()
+        a.x_start, a.noise, a.noise_q, a.cond, a.ctx = (_lib.ptr(v) for v in (x_start, noise, noise_q, cond, ctx))
+        a.t_host = C.cast(t_arr, C.POINTER(C.c_int64))
+        a.coef_host, a.coef_stride = C.cast(coef.data_ptr(), C.POINTER(C.c_float)), int(coef.shape[1])
+        a.cond_channels, a.ctx_tokens, a.self_cond, a.objective = cc, m, sc_mode, self._objective_id
+        a.loss_scale, a.accumulate = float(loss_scale), int(bool(accumulate))
+        a.loss_out_host = C.pointer(loss) if sync else None
+        a.model_out, a.B, a.H, a.W, a.stream = _lib.ptr(out), b, h, w, stream
+        a.loss_terms = 1
+        if self.hybrid_loss:
+            if cond is not None:
+                # the reference's image-conditional p_losses calls p_mean_variance WITHOUT cond (denoising_diffusion_image_
+                # conditional.py:295): its 6-channel U-Net then receives 3 channels and raises
+                raise NotImplementedError("hybrid_loss with an image condition fails in the reference (p_mean_variance is "
+                                          "called without cond); not reproduced")
+            mask_sum = (t_cpu > 0).float().sum()  # fp32, as the reference forms kl / (mask.sum() + 1e-8), :893-895
+            a.kl_scale = float(torch.tensor(0.001, dtype=torch.float32) / (mask_sum + 1e-8))
+            a.loss_terms = 3 if float(getattr(self.model, "dropout", 0.0) or 0.0) == 0.0 else 1
+        _lib.check(self._lib.dm_unet_loss_backward_ex(self.model._handle, C.byref(a)))
+        if self.hybrid_loss and a.loss_terms == 1:
+            # dropout: p_mean_variance's forward pass draws its own masks -- a second, accumulating call for the KL term
+            mse = C.c_float(loss.value)
+            if not sync:
+                mse_dev = torch.empty((), device=self.device, dtype=torch.float32)
+                _lib.check(self._lib.dm_unet_train_scalar(self.model._handle, 0, _lib.ptr(mse_dev), stream))
+            a.loss_terms, a.accumulate, a.model_out = 2, 1, None
+            _lib.check(self._lib.dm_unet_loss_backward_ex(self.model._handle, C.byref(a)))
+            if sync:
+                loss = C.c_float(mse.value + loss.value)
         if sync:
             val = torch.tensor(loss.value, dtype=torch.float32)
         else:
             val = torch.empty((), device=self.device, dtype=torch.float32)
             _lib.check(self._lib.dm_unet_train_scalar(self.model._handle, 0, _lib.ptr(val), stream))
+            if self.hybrid_loss and a.loss_terms == 2:
+                val = val + mse_dev
         return (val, out) if return_model_out else val
 
     def forward(self, img, *args, **kwargs):
@@ -669,21 +688,23 @@ class TextConditionalDenoisingDiffusion(DenoisingDiffusion):
     __call__ = forward
 
     @torch.inference_mode()
-    @torch.inference_mode()
     def interpolate(self, x1, x2, t=None, text_emb=None, lam=0.5, *, noise=None, seed=None):
         """denoising_diffusion_text_conditional.py:456-473 (positional order: x1, x2, t, text_emb, lam)."""
         return self._interpolate(x1, x2, t, lam, noise, seed, text_emb=text_emb)
 
+    @torch.inference_mode()
     def model_predictions(self, x, t, text_emb=None, x_self_cond=None, clip_x_start=False, rederive_pred_noise=False):
         """denoising_diffusion_text_conditional.py:274-297 (positional order: x, t, text_emb, x_self_cond)."""
         kw = {"text_emb": text_emb} if text_emb is not None else {}
         return super().model_predictions(x, t, x_self_cond, clip_x_start, rederive_pred_noise, **kw)
 
+    @torch.inference_mode()
     def p_mean_variance(self, x, t, text_emb=None, x_self_cond=None, clip_denoised=True):
         """:299-307."""
         kw = {"text_emb": text_emb} if text_emb is not None else {}
         return super().p_mean_variance(x, t, x_self_cond, clip_denoised, **kw)
 
+    @torch.inference_mode()
     def p_sample(self, x, t: int, text_emb=None, x_self_cond=None, *, noise=None):
         """denoising_diffusion_text_conditional.py:310-317 (the reference's positional order: x, t, text_emb)."""
         return self._p_sample(x, t, noise, {"text_emb": text_emb} if text_emb is not None else {}, x_self_cond)

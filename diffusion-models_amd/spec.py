@@ -256,8 +256,11 @@ def _betas(name: str, timesteps: int, **kw) -> torch.Tensor:
     return torch.clip(1 - (ac[1:] / ac[:-1]), 0, 0.999)
 
 
-def make_schedule(timesteps: int = 1000, beta_schedule: str = "linear", **schedule_fn_kwargs) -> Dict[str, torch.Tensor]:
-    """The 13 fp32 buffers of ``DenoisingDiffusion`` (ddpm=True loss weight)."""
+def make_schedule(timesteps: int = 1000, beta_schedule: str = "linear", *, ddpm: bool = True, objective: str = "pred_noise",
+                  min_snr_loss_weight: bool = False, min_snr_gamma=5, **schedule_fn_kwargs) -> Dict[str, torch.Tensor]:
+    """The 13 fp32 buffers of ``DenoisingDiffusion`` (denoising_diffusion.py:482-549).  ``loss_weight``: ones with
+    ``ddpm=True`` (:532-533), else derived from the float64 signal-to-noise ratio and rounded to fp32 ONCE, as the
+    reference's ``register_buffer`` does (:535-549)."""
     betas = _betas(beta_schedule, timesteps, **schedule_fn_kwargs)
     alphas = 1.0 - betas
     ac = torch.cumprod(alphas, dim=0)
@@ -278,6 +281,14 @@ def make_schedule(timesteps: int = 1000, beta_schedule: str = "linear", **schedu
         "posterior_mean_coef2": (1.0 - ac_prev) * torch.sqrt(alphas) / (1.0 - ac),
         "loss_weight": torch.ones(timesteps, dtype=torch.float64),
     }
+    if not ddpm:
+        snr = ac / (1 - ac)
+        clipped = snr.clone()
+        if min_snr_loss_weight:
+            clipped.clamp_(max=min_snr_gamma)
+        if objective not in ("pred_noise", "pred_x0", "pred_v"):
+            raise ValueError(f"unknown objective {objective}")
+        f64["loss_weight"] = {"pred_noise": clipped / snr, "pred_x0": clipped, "pred_v": clipped / (snr + 1)}[objective]
     return {k: v.to(torch.float32) for k, v in f64.items()}
 
 

@@ -165,11 +165,12 @@ def train_step(diffusion, micro_batches: Iterable[torch.Tensor], *, lr=1e-4, bet
     batches = list(micro_batches)
     k = len(batches)
     total = 0.0
+    lazy = {} if sync else {"sync": False}  # only the asynchronous form asks the diffusion object for anything new
     for i, data in enumerate(batches):
         x = diffusion.normalize(data.to(diffusion.device, torch.float32))
         ti = t[i] if t is not None else torch.randint(0, diffusion.num_timesteps, (x.shape[0],)).long()
         ni = noise[i] if noise is not None else None
-        loss = diffusion.p_losses(x, ti, noise=ni, loss_scale=1.0 / k, accumulate=i > 0, sync=sync)
+        loss = diffusion.p_losses(x, ti, noise=ni, loss_scale=1.0 / k, accumulate=i > 0, **lazy)
         total = (total + float(loss)) if sync else (loss if i == 0 else total + loss)
     import torch.distributed as dist
 
@@ -178,7 +179,7 @@ def train_step(diffusion, micro_batches: Iterable[torch.Tensor], *, lr=1e-4, bet
         torch.cuda.current_stream(diffusion.device).synchronize()
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         flat.div_(dist.get_world_size(group))  # DDP averages; the buffer is the library's own (zero-copy view)
-    norm = diffusion.model.optimizer_step(lr=lr, betas=betas, eps=eps, max_grad_norm=max_grad_norm, sync=sync)
+    norm = diffusion.model.optimizer_step(lr=lr, betas=betas, eps=eps, max_grad_norm=max_grad_norm, **lazy)
     if ema is not None:
         ema.update()
     return total, norm

@@ -333,6 +333,40 @@ int dm_unet_loss_backward(dm_unet* u, const float* x_start, const int64_t* t_hos
                           int ctx_tokens,
                           int self_cond, int objective, float loss_scale, int accumulate, float* loss_out_host,
                           float* model_out, int B, int H, int W, void* stream);
+/* The same call with its arguments in one struct, plus the hybrid (KL) term of p_losses (:880-897):
+ *   loss_terms: 1 the weighted MSE (what dm_unet_loss_backward computes), 2 the KL term alone, 3 both in one pass.  The
+ *     reference evaluates the KL term through p_mean_variance, i.e. a SECOND forward pass of the U-Net with gradients: without
+ *     dropout that pass repeats the first one bit for bit and loss_terms = 3 is the same loss and gradient; with dropout the
+ *     second pass draws new masks -- the caller then runs loss_terms = 1 followed by loss_terms = 2 with accumulate = 1.
+ *   coef_stride: floats per row of coef_host, 8 (rows as above) or 12: [3] = 1 if t_b > 0 else 0 (the reference's mask),
+ *     [8] posterior_mean_coef1[t_b], [9] posterior_mean_coef2[t_b], [10] posterior_variance[t_b],
+ *     [11] posterior_log_variance_clipped[t_b] -- required by the KL term.
+ *   kl_scale = 0.001 / (mask.sum() + 1e-8), formed by the caller in fp32 as the reference does (:893-895).
+ * The KL term divides by posterior_variance[t], which is 0 at t = 0, before the mask multiplies (inf * 0): a batch holding a
+ * t = 0 sample has a NaN loss and NaN gradients in the reference and here. */
+typedef struct dm_train_args {
+    const float* x_start;
+    const int64_t* t_host;
+    const float* coef_host;
+    int coef_stride;
+    const float* noise;
+    const float* noise_q;
+    const float* cond;
+    int cond_channels;
+    const float* ctx;
+    int ctx_tokens;
+    int self_cond;
+    int objective;
+    float loss_scale;
+    int accumulate;
+    float* loss_out_host;
+    float* model_out;
+    int B, H, W;
+    void* stream;
+    int loss_terms;
+    float kl_scale;
+} dm_train_args;
+int dm_unet_loss_backward_ex(dm_unet* u, const dm_train_args* a);
 /* The rest of one Trainer.train iteration (:1178-1190) on device-resident state: the master parameters, the Adam moments and
  * the EMA copy live in flat device buffers in the reference layouts; after the update every packed weight buffer the
  * kernels read is rebuilt on the device (pack_kernels.hip, bit-identical to the host packers).
@@ -369,7 +403,7 @@ int dm_unet_check_device_pack(dm_unet* u);
  * applies, n elements in (B, H, W, C) order -- parity tests hand these masks to the oracle. */
 int dm_unet_train_dropout(dm_unet* u, float p, uint64_t seed);
 int dm_op_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t call, int block_index, void* stream);
-/* q_sample (:813-821) on its own: out = coef[b][0] * x_start + coef[b][1] * noise, coef_host (B, 8) as above */
+/* q_sample (:813-821) on its own: out = coef[b][0] * x_start + coef[b][1] * noise, coef_host (B, 12): rows as in dm_train_args */
 int dm_op_q_sample(const float* x_start, const float* noise, const float* coef_host, float* out, int B, int per_sample,
                    void* stream);
 /* The elementwise helpers of DenoisingDiffusion as callable methods -- predict_start_from_noise, predict_noise_from_start,

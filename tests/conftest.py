@@ -89,6 +89,13 @@ def golden_train():
 
 
 @pytest.fixture(scope="session")
+def golden_hybrid():
+    """The hybrid (KL) loss branch of p_losses and the ddpm=False loss weights, from the reference
+    (tests/golden/make_golden_hybrid.py)."""
+    return load_golden("hybrid.pt")
+
+
+@pytest.fixture(scope="session")
 def golden_train_noise():
     """The reference's p_losses(...).backward() with offset noise / with the immiscible noise assignment
     (tests/golden/make_golden_train_noise.py)."""

@@ -565,3 +565,105 @@ def test_caption_dropout_leaves_no_stale_text_gradients(cross):
     for k in text_names:
         assert torch.equal(before[k], after[k]), k
     assert not torch.equal(sd["init_conv.weight"], after["init_conv.weight"].cpu())
+
+
+@pytest.mark.parametrize("objective", ["pred_noise", "pred_x0", "pred_v"])
+def test_hybrid_loss_vs_reference_autograd(golden_hybrid, objective):
+    """``DenoisingDiffusion(hybrid_loss=True)`` (:880-897) against the REFERENCE's loss.backward(): the loss and every
+    gradient for a batch without t = 0; for a batch that holds t = 0 the reference's own answer is NaN (it divides by
+    posterior_variance[0] = 0 before the mask multiplies) and so is ours."""
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3)
+    b = golden_hybrid["hybrid_" + objective]
+    u = dm.Unet(dim=32, dim_mults=(1, 2), channels=3, device=DEV)
+    u.load_state_dict(dm.synth_state_dict(dm.unet_param_spec(cfg), salt=41))
+    d = dm.DenoisingDiffusion(u, image_size=16, timesteps=b["T"], objective=objective, hybrid_loss=True).train()
+    x_start = b["img"] * 2 - 1
+    loss = float(d.p_losses(x_start, b["t"], noise=b["noise"]))
+    print(objective, "hybrid loss", loss, b["loss"], "without the KL term", b["loss_without_kl"])
+    assert abs(loss - b["loss"]) <= 1e-5 * abs(b["loss"])
+    grads = d.model.grads()
+    for name, dg in b["grads"].items():
+        check_grad_digest(name, grads[name].cpu(), dg, GRAD_TOL)
+    z = golden_hybrid["hybrid_" + objective + "_t0"]
+    loss0 = float(d.p_losses(x_start, z["t"], noise=b["noise"]))
+    assert loss0 != loss0, loss0
+    assert all(bool(torch.isnan(g).all()) for g in d.model.grads().values())
+    # the asynchronous form returns the same number
+    again = d.p_losses(x_start, b["t"], noise=b["noise"], sync=False)
+    assert again.is_cuda and float(again) == loss
+
+
+def test_hybrid_loss_text_conditional_and_with_dropout(golden_hybrid):
+    """The text-conditional class's hybrid branch against the reference; and with dropout the KL term runs as a second,
+    accumulating pass with its own masks (the reference's p_mean_variance call is a second forward pass): checked against the
+    oracle with both passes' masks exported."""
+    import ctypes as C
+
+    from diffusion_models_amd import _lib
+    from oracle import train_oracle as to
+
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3, text_condition=True, use_cross_attn=True)
+    b = golden_hybrid["hybrid_text_cross"]
+    u = dm.Unet(dim=32, dim_mults=(1, 2), channels=3, text_condition=True, use_cross_attn=True, device=DEV)
+    u.load_state_dict(dm.synth_state_dict(dm.unet_param_spec(cfg), salt=2))
+    d = dm.TextConditionalDenoisingDiffusion(model=u, image_size=16, timesteps=b["T"], hybrid_loss=True).train()
+    loss = float(d.p_losses(b["img"] * 2 - 1, b["t"], b["emb"], b["noise"]))
+    assert abs(loss - b["loss"]) <= 1e-5 * abs(b["loss"]), (loss, b["loss"])
+    grads = d.model.grads()
+    scale = max(dg["norm"] for dg in b["grads"].values())
+    for name, dg in b["grads"].items():
+        if dg["norm"] < 1e-9 * scale:
+            assert float(grads[name].norm()) < 1e-6 * scale, name
+        else:
+            check_grad_digest(name, grads[name].cpu(), dg, GRAD_TOL)
+    # dropout: two passes, two sets of masks
+    cfg2 = UnetConfig(dim=64, dim_mults=(1, 2), channels=3)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg2), salt=42)
+    u2 = dm.Unet(dim=64, dim_mults=(1, 2), channels=3, dropout=0.1, device=DEV)
+    u2.load_state_dict(sd)
+    d2 = dm.DenoisingDiffusion(u2, image_size=16, timesteps=1000, hybrid_loss=True).train()
+    p, seed, B = 0.1, 424242, 4
+    u2.set_dropout_seed(seed)
+    g = torch.Generator().manual_seed(10)
+    x_start = torch.rand((B, 3, 16, 16), generator=g) * 2 - 1
+    t = torch.tensor([3, 400, 777, 999])
+    noise = torch.randn((B, 3, 16, 16), generator=g)
+    loss2 = float(d2.p_losses(x_start, t, noise=noise))
+    got = d2.model.grads()
+    lib = _lib.load()
+    masks = [[], []]
+    for call in (0, 1):
+        for k, (c, h, w) in enumerate(_block_shapes(cfg2, 16)):
+            m = torch.empty((B, h, w, c), device=DEV)
+            _lib.check(lib.dm_op_dropout_mask(_lib.ptr(m), m.numel(), p, C.c_uint64(seed), C.c_uint64(call), k, None))
+            masks[call].append(m.permute(0, 3, 1, 2).contiguous().cpu())
+    torch.set_num_threads(8)
+    want_loss, want = to.loss_and_grads(sd, cfg2, dm.make_schedule(1000, "linear"), x_start, t, noise, hybrid=True,
+                                        dropout_masks=masks[0], kl_fwd_kw=dict(dropout_masks=masks[1]))
+    print("hybrid + dropout: loss", loss2, want_loss)
+    assert abs(loss2 - want_loss) <= 1e-5 * abs(want_loss)
+    worst = max((rel_l2(got[k].cpu(), want[k]), k) for k in want)
+    print("worst gradient", worst)
+    assert worst[0] < GRAD_TOL
+
+
+def test_non_ddpm_loss_weight_training_step_vs_oracle():
+    """ddpm=False with the min-SNR clip (:535-549): the loss weight multiplies each sample's loss; against the oracle."""
+    from oracle import train_oracle as to
+
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=41)
+    u = dm.Unet(dim=32, dim_mults=(1, 2), channels=3, device=DEV)
+    u.load_state_dict(sd)
+    d = dm.DenoisingDiffusion(u, image_size=16, timesteps=1000, objective="pred_v", ddpm=False, min_snr_loss_weight=True).train()
+    g = torch.Generator().manual_seed(12)
+    x_start = torch.rand((4, 3, 16, 16), generator=g) * 2 - 1
+    t = torch.tensor([0, 5, 500, 990])
+    noise = torch.randn((4, 3, 16, 16), generator=g)
+    loss = float(d.p_losses(x_start, t, noise=noise))
+    sched = dm.make_schedule(1000, "linear", ddpm=False, objective="pred_v", min_snr_loss_weight=True)
+    want_loss, want = to.loss_and_grads(sd, cfg, sched, x_start, t, noise, "pred_v")
+    assert abs(loss - want_loss) <= 1e-5 * abs(want_loss), (loss, want_loss)
+    got = d.model.grads()
+    worst = max((rel_l2(got[k].cpu(), want[k]), k) for k in want)
+    assert worst[0] < GRAD_TOL, worst

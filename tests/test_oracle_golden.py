@@ -427,6 +427,59 @@ def test_train_noise_options(golden_train_noise, case):
         check_grad_digest(name, grads[name], dg, 2e-5)
 
 
+@pytest.mark.parametrize("objective", ["pred_noise", "pred_x0", "pred_v"])
+def test_hybrid_loss_and_gradients(golden_hybrid, objective):
+    """The hybrid (KL) branch of p_losses (:880-897) in the oracle against the reference's own loss.backward(): the loss and
+    every gradient for a batch without t = 0, and the NaN the reference returns for a batch that holds one."""
+    from conftest import check_grad_digest
+    from oracle import train_oracle as to
+
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3)
+    b = golden_hybrid["hybrid_" + objective]
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=41)
+    sched = dm.make_schedule(b["T"], "linear")
+    x_start = b["img"] * 2 - 1
+    torch.set_num_threads(8)
+    loss, grads = to.loss_and_grads(sd, cfg, sched, x_start, b["t"], b["noise"], objective, hybrid=True)
+    assert abs(loss - b["loss"]) <= 1e-5 * abs(b["loss"]), (loss, b["loss"])
+    assert abs(b["loss"] - b["loss_without_kl"]) > 1e-5 * abs(b["loss"])  # the KL term is there
+    for name, dg in b["grads"].items():
+        check_grad_digest(name, grads[name], dg, 2e-5)
+    z = golden_hybrid["hybrid_" + objective + "_t0"]
+    assert z["loss"] != z["loss"] and z["all_grads_nan"]  # the reference itself: NaN
+    loss0, grads0 = to.loss_and_grads(sd, cfg, sched, x_start, z["t"], b["noise"], objective, hybrid=True)
+    assert loss0 != loss0 and all(bool(torch.isnan(g).all()) for g in grads0.values())
+
+
+def test_hybrid_loss_text_conditional(golden_hybrid):
+    """denoising_diffusion_text_conditional.py:522-542: the same branch with the text embedding in both forward passes."""
+    from conftest import check_grad_digest
+    from oracle import train_oracle as to
+
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3, text_condition=True, use_cross_attn=True)
+    b = golden_hybrid["hybrid_text_cross"]
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=2)
+    torch.set_num_threads(8)
+    loss, grads = to.loss_and_grads(sd, cfg, dm.make_schedule(b["T"], "linear"), b["img"] * 2 - 1, b["t"], b["noise"],
+                                    "pred_noise", hybrid=True, text_emb=b["emb"])
+    assert abs(loss - b["loss"]) <= 1e-5 * abs(b["loss"]), (loss, b["loss"])
+    scale = max(dg["norm"] for dg in b["grads"].values())
+    for name, dg in b["grads"].items():
+        if dg["norm"] < 1e-9 * scale:  # exact zeros in the reference (single context token)
+            assert float(grads[name].norm()) < 1e-6 * scale, name
+        else:
+            check_grad_digest(name, grads[name], dg, 2e-5)
+
+
+def test_loss_weight_buffers(golden_hybrid):
+    """make_schedule's ``loss_weight`` for ddpm=False (:535-549: float64 SNR, one rounding to fp32) against the reference's
+    registered buffer, bit for bit, for every schedule x objective x min-SNR combination."""
+    for key, want in golden_hybrid["loss_weight"].items():
+        schedule, objective, min_snr = key.split("/")
+        got = dm.make_schedule(1000, schedule, ddpm=False, objective=objective, min_snr_loss_weight=bool(int(min_snr)))
+        assert torch.equal(got["loss_weight"], want), key
+
+
 def test_prediction_helpers_and_guided_ddim(golden_guided):
     """oracle/sampler_oracle.py: model_predictions / p_mean_variance / q_posterior with a batch of different timesteps for the
     three objectives, and ddim_sample_guided (with and without a guide), against the reference's own outputs."""

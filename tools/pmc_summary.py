@@ -27,6 +27,9 @@ def main():
     tag = sys.argv[1]
     from bench import csrc_sha
     out = {"_csrc_sha": csrc_sha(), "_tag": os.path.basename(tag)}
+    if os.environ.get("PMC_ITERS"):  # iterations of the profiled loop (training step: tools/final_profiles.sh)
+        out["_iterations"] = int(os.environ["PMC_ITERS"])
+        out["_command"] = os.environ.get("PMC_CMD", "")
     ft, fc = load(tag + "_fetch")
     wt, wc = load(tag + "_write")
     mt, mc = load(tag + "_mfma")

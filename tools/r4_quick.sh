@@ -1,7 +1,5 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python -m pytest tests/test_hip_train.py tests/test_hip_train_ops.py -x -q 2>&1 | tail -5
-python3 tools/train_time.py --batch 64 --steps 20
+python -m pytest tests/test_hip_train.py tests/test_hip_train_bench_shape.py tests/test_hip_train_ops.py tests/test_hip_r3.py -x -q -s 2>&1 | grep -v "amdgpu.ids" | tail -40
 python3 tools/train_time.py --batch 64 --steps 20 --dropout 0.1
 python3 tools/train_time.py --batch 16 --steps 20
-DM_TRAIN_NO_LANDING_FUSE=1 python3 tools/train_time.py --batch 64 --steps 20

@@ -16,6 +16,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--size", type=int, default=32)
 ap.add_argument("--dropout", type=float, default=0.0)
+ap.add_argument("--full-only", action="store_true", help="only full Trainer.train iterations: 1 warm-up + --steps (profiling)")
 ap.add_argument("--host", action="store_true", help="also print the host time to ENQUEUE an iteration")
 args = ap.parse_args()
 u = dm.Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=3, dropout=args.dropout, device="cuda:0")
@@ -23,14 +24,15 @@ u.load_state_dict(dm.synth_state_dict(u.param_spec(), salt=0))
 d = dm.DenoisingDiffusion(u, image_size=args.size, timesteps=1000).train()
 img = torch.rand(args.batch, 3, args.size, args.size, device="cuda:0")
 torch.manual_seed(0)
-d(img)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(args.steps):
-    loss = d(img, sync=False)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / args.steps
-print(f"loss+backward B={args.batch} {args.size}x{args.size}: {1e3 * dt:.2f} ms/step  {args.batch / dt:.1f} images/s  (loss {float(loss):.4f})")
+if not args.full_only:
+    d(img)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = d(img, sync=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    print(f"loss+backward B={args.batch} {args.size}x{args.size}: {1e3 * dt:.2f} ms/step  {args.batch / dt:.1f} images/s  (loss {float(loss):.4f})")
 ema = dm.EMA(d, beta=0.995, update_every=10)
 dm.train_step(d, [img], lr=2e-4, ema=ema)
 torch.cuda.synchronize()
