@@ -299,12 +299,16 @@ def other_configs(dev, replays: int = 100):
     return out
 
 
-def train_leg(dev, with_cpu: bool, batch: int = 64, iters: int = 10):
+def train_leg(dev, with_cpu: bool, batch: int = 64, iters: int = 10, world: int = 1, rank: int = 0, rehearse: bool = False):
     """The training half of the caller of record, measured beside the headline: one iteration of
     Trainer.train (DD/denoising_diffusion.py:1164-1190: p_losses + backward, clip_grad_norm_, Adam, ema.update) at the shipped
     ddpm_cifar.yaml shape (32x32 U-Net dim 64, train_batch_size 64, dropout 0.1), all on the GPU with device-resident
-    parameters; and the same iteration through torch autograd on this box's host cores (the oracle, one iteration)."""
+    parameters; and the same iteration through torch autograd on this box's host cores (the oracle, one iteration).
+    world > 1 (bench.py --gpus N): data-parallel as accelerate runs the reference's Trainer -- `batch` images per rank (weak
+    scaling), ONE all-reduce of the flat gradient buffer over RCCL inside every timed iteration, every rank steps its own
+    replica; the time is the maximum over ranks and the all-reduce's share comes from HIP events around it."""
     import torch
+    import torch.distributed as dist
 
     import diffusion_models_amd as dm
     from diffusion_models_amd.spec import UnetConfig
@@ -315,20 +319,38 @@ def train_leg(dev, with_cpu: bool, batch: int = 64, iters: int = 10):
     u.load_state_dict(sd)
     d = dm.DenoisingDiffusion(u, image_size=IMAGE, timesteps=T).train()
     ema = dm.EMA(d, beta=0.995, update_every=10)
-    img = torch.rand(batch, CHANNELS, IMAGE, IMAGE, device=dev)
+    img = torch.rand(batch, CHANNELS, IMAGE, IMAGE, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + rank))
     for _ in range(3):  # warm-up: workspace sizing, then the first lazily re-packed iteration, then the steady state
         dm.train_step(d, [img], lr=2e-4, ema=ema)
-    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    timing = {} if world > 1 else None
+    barrier()
     t0 = time.perf_counter()
     for _ in range(iters):  # enqueued back to back; loss / norm stay device tensors (the reference's loss.item() is the caller's)
-        loss, norm = dm.train_step(d, [img], lr=2e-4, ema=ema, sync=False)
-    torch.cuda.synchronize()
+        loss, norm = dm.train_step(d, [img], lr=2e-4, ema=ema, sync=False, timing=timing)
+    barrier()
     dt = (time.perf_counter() - t0) / iters
+    if world > 1:
+        tmax = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
     loss, norm = float(loss), float(norm)
     assert math.isfinite(loss) and math.isfinite(norm) and loss > 0 and norm > 0, (loss, norm)
-    out = {"workload": f"Trainer.train iteration, 32x32 U-Net dim 64, batch {batch}, dropout 0.1, Adam + clip + EMA",
-           "ms_per_iteration": 1e3 * dt, "images_per_s": batch / dt, "iterations_timed": iters, "loss": loss, "grad_norm": norm}
-    out["roofline"] = train_roofline(1e3 * dt)
+    out = {"workload": f"Trainer.train iteration, 32x32 U-Net dim 64, batch {batch} per GPU, dropout 0.1, Adam + clip + EMA",
+           "ms_per_iteration": 1e3 * dt, "images_per_s": world * batch / dt, "iterations_timed": iters, "loss": loss,
+           "grad_norm": norm, "n_gpus": world, "global_batch": world * batch}
+    if world > 1:
+        ar = [a.elapsed_time(b) for a, b in timing["allreduce_events"]]
+        out["allreduce_ms"] = sum(ar) / len(ar)
+        out["allreduce_share"] = out["allreduce_ms"] / (1e3 * dt)
+        out["allreduce_bytes"] = int(d.model.grads_flat().numel()) * 4
+        out["allreduce"] = "one in-place all-reduce of the flat gradient buffer per iteration, not overlapped with the backward pass"
+    out["roofline"] = train_roofline(1e3 * dt) if world == 1 else None
     del d, u, ema
     if with_cpu:
         from oracle import train_oracle as to
@@ -582,8 +604,10 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_other_configs:
         result["other_configs"] = other_configs(dev)
-    if rank == 0 and world == 1 and not args.no_train:
-        result["train_step"] = train_leg(dev, with_cpu=not args.no_cpu_baseline)
+    if not args.no_train:  # every rank: under world > 1 the iteration holds a collective
+        tr = train_leg(dev, with_cpu=world == 1 and not args.no_cpu_baseline, world=world, rank=rank, rehearse=rehearse)
+        if rank == 0:
+            result["train_step"] = tr
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.cpu_steps)

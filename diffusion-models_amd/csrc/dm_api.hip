@@ -219,7 +219,6 @@ struct ConvLayer {
     float* w = nullptr;
     float* ww = nullptr;  // Winograd-transformed weights (winograd_mfma.hip) when the layer is eligible
     float* ww4 = nullptr;  // F(4x4,3x3) transformed weights (wino4_mfma.hip)
-    float* wwb = nullptr;  // experimental (DM_WINOB=1): F(2x2,3x3) weights as three bf16 planes (winob_mfma.hip)
     float* wwu = nullptr;  // transformed weights of the upsample + 3x3 algorithm (upwino_mfma.hip)
     float* wpw = nullptr;  // lane-ordered weights of the 1x1 GEMM kernel (pw_mfma.hip)
     float* wi7 = nullptr;  // weights of the 7x7 first-conv kernel (init7_mfma.hip)
@@ -467,13 +466,6 @@ static int make_conv(DeviceOwner& own, ConvLayer& L, const float* oihw, const fl
         if (own.upload(wp.data(), wp.size(), &L.ww4)) return 1;
         own.record(PK_WINO4, L.ww4, wp.size(), Cout, C0, C1, KH, KW);
     }
-    L.wwb = nullptr;
-    if (winob_eligible(Cout, C0, C1, KH, KW, stride, pad, up)) {
-        // not recorded as a packing recipe: the training step never takes this kernel (plan_conv), so nothing re-packs it
-        std::vector<float> wp(winob_packed_floats(Cout, C0, C1));
-        winob_pack_weights(oihw, wp.data(), Cout, C0, C1);
-        if (own.upload(wp.data(), wp.size(), &L.wwb)) return 1;
-    }
     L.wwu = nullptr;
     if (upwino_eligible(Cout, C0, C1, KH, KW, stride, pad, up)) {
         std::vector<float> wp(upwino_packed_floats(Cout, C0, C1));
@@ -654,22 +646,8 @@ static int build_attn_body(dm_unet* u, AttnLayer& A, const std::string& p, int d
                     u->own.upload(wv.data(), wv.size(), &dv) || u->own.upload(wor.data.data(), wor.data.size(), &dwo) ||
                     u->own.upload(kb.data(), kb.size(), &dkb) || u->own.upload(ogs.data(), ogs.size(), &dog))
                     return 1;
-                A.fused = LinAttnFused{dim, dq, dk, dv, dwo, A.out.bias, dog, dkb, A.mem_kv, nullptr, nullptr, nullptr, 0};
+                A.fused = LinAttnFused{dim, dq, dk, dv, dwo, A.out.bias, dog, dkb, A.mem_kv};
                 A.has_fused = true;
-                static const bool bf16x6 = std::getenv("DM_LINATTN_BF16X6") != nullptr;
-                if (bf16x6 && dim == 64) {  // experimental: fp32 products on the bf16 matrix cores
-                    float* d3[3];
-                    for (int which = 0; which < 3; ++which) {
-                        std::vector<float> w3;
-                        linattn_bf16x6_pack_proj(P(u, p + ".to_qkv.weight").data.data(), P(u, p + ".norm.g").data.data(),
-                                                 dim, which, w3);
-                        if (u->own.upload(w3.data(), w3.size(), &d3[which])) return 1;
-                    }
-                    A.fused.wq3 = d3[0];
-                    A.fused.wk3 = d3[1];
-                    A.fused.wv3 = d3[2];
-                    A.fused.bf16x6 = 1;
-                }
             }
         }
     }
@@ -942,21 +920,13 @@ static int plan_conv(const Ctx& c, const ConvLayer& L, bool has_in1, int Hin, in
     }
     // 3x3 / stride 1 convolutions run as Winograd F(4x4,3x3) on power-of-two images, else as F(2x2,3x3), when the layer
     // has transformed weights
-    const bool winob = P.kind == 0 && L.wwb && !(c.u && c.u->train) && !L.fold && !in_nchw && !out_nchw && padw == L.pad &&
-                       winob_shape_ok(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
-    const bool wino4 = P.kind == 0 && !winob && L.ww4 && !L.fold && !in_nchw && !out_nchw && padw == L.pad &&
+    const bool wino4 = P.kind == 0 && L.ww4 && !L.fold && !in_nchw && !out_nchw && padw == L.pad &&
                        wino4_shape_ok(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
     const bool wino = P.kind == 0 && !wino4 && L.ww && !L.fold && !in_nchw && !out_nchw && padw == L.pad &&
                       wino_use(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
-    const bool pw = P.kind == 0 && !winob && L.wpw && !L.fold && !p.s2d && !in_nchw && !out_nchw && L.pad_hi == 0 && padw == 0 &&
+    const bool pw = P.kind == 0 && L.wpw && !L.fold && !p.s2d && !in_nchw && !out_nchw && L.pad_hi == 0 && padw == 0 &&
                     pw_shape_ok(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
-    if (winob) {
-        p.w = L.wwb;
-        p.chunks0 = L.C0 / 16;
-        p.n_chunks = (L.C0 + L.C1) / 16;
-        p.geo = winob_plan(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1);
-        P.kind = 8;
-    } else if (pw) {
+    if (pw) {
         p.w = L.wpw;
         p.chunks0 = L.C0 / 16;
         p.n_chunks = (L.C0 + L.C1) / 16;
@@ -982,7 +952,6 @@ static int plan_conv(const Ctx& c, const ConvLayer& L, bool has_in1, int Hin, in
 static int launch_planned(const PlannedConv& P, const ConvParams& q, hipStream_t s, dm_unet* u = nullptr) {
     if (u && u->train && ensure_packed(u, q.w, s)) return 1;  // training loop: weights re-packed on the device when stale
     switch (P.kind) {
-        case 8: return winob_launch(q, s);
         case 7: return init7_launch(q, s);
         case 5: return pw_launch(q, s);
         case 3: return upwino_launch(q, s);

@@ -153,16 +153,6 @@ ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_s
 bool wino_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1);
 int wino_launch(const ConvParams& p, hipStream_t s);
 
-// ---------------------------------------------------------------------------------------
-// EXPERIMENTAL (DM_WINOB=1): Winograd F(2x2, 3x3) with fp32 products as six bf16 MFMA products (winob_mfma.hip); same
-// contract as wino_launch, chunks of 16 input channels, 64 tiles per workgroup, no K split
-bool winob_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, bool up);
-size_t winob_packed_floats(int Cout, int C0, int C1);
-void winob_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1);
-ConvGeom winob_plan(int B, int Ho, int Wo, int Cout, int C0, int C1);
-bool winob_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1);
-int winob_launch(const ConvParams& p, hipStream_t s);
-
 // Winograd F(4x4, 3x3) convolution (wino4_mfma.hip): same contract as wino_launch, 2.25 instead of 4 multiplies per
 // output; images of 4x4, 8x8, 16x16 or (16k x 32m) pixels.  ConvGeom TW/TH/NB count 4x4-pixel tiles (32 per workgroup).
 // ---------------------------------------------------------------------------------------
@@ -260,6 +250,7 @@ int launch_sinusoid(const int64_t* t, const int64_t* step_times, const SamplerSt
 bool vae_attn_mfma_ok(int n, int C);
 int launch_vae_attn_mfma(const float* q, const float* k, const float* v, float* out, int B, int n, int C, hipStream_t s);
 bool group_sums_ok(int C, int groups);
+size_t group_stats_ws_floats(int B, int groups);
 int launch_group_stats_fast(const float* x, float* stats, double* acc, int B, int HW, int C, int groups, float eps,
                             hipStream_t s);
 // GroupNorm(32 groups) + optional swish, NHWC; stats_ws holds B*groups*2 floats + B*groups*2 doubles
@@ -316,18 +307,12 @@ struct LinAttnFused {
     const float* og;            // to_out RMSNorm gain * sqrt(C) [C]
     const float* kbound;        // softmax shift per (head, d) [128]
     const float* mem_kv;        // (2, heads, 32, 4)
-    // experimental, off by default (DM_LINATTN_BF16X6=1, C == 64): projection weights as bf16 triples (linattn_bf16x6.hip)
-    const void *wq3, *wk3, *wv3;
-    int bf16x6;
 };
 bool linattn_fused_eligible(int C, int heads, int dh);
 bool linattn_fused_pack(const float* w_qkv, const float* norm_g, const float* w_out, const float* mem_kv, int C,
                         std::vector<float>& wq, std::vector<float>& wk, std::vector<float>& wv, std::vector<float>& wo,
                         std::vector<float>& kbound);
 size_t linattn_fused_ws_floats(int B, int n);
-void linattn_bf16x6_pack_proj(const float* w_qkv, const float* norm_g, int C, int which, std::vector<float>& dst);
-int launch_linattn_bf16x6(const LinAttnFused& w, const float* x, float* ws, float* y, int B, int n, bool add_x,
-                          hipStream_t s);
 int launch_linattn_fused(const LinAttnFused& w, const float* x, float* ws, float* y, int B, int n, bool add_x,
                          hipStream_t s);
 

@@ -379,7 +379,7 @@ __global__ void group_apply_kernel(const float* __restrict__ x, const float* __r
 }
 int launch_group_norm(const float* x, const float* w, const float* b, float* y, float* stats_ws, int B, int HW,
                       int C, int groups, float eps, int swish, hipStream_t s) {
-    // stats_ws: B*groups*2 floats (mean, rstd) followed by B*groups*2 doubles of accumulator scratch
+    // stats_ws: group_stats_ws_floats(B, groups) = B*groups*2 floats (mean, rstd), then the per-block partial sums (doubles)
     if (group_sums_ok(C, groups)) {
         double* acc = reinterpret_cast<double*>(stats_ws + (size_t)B * groups * 2);
         if (launch_group_stats_fast(x, stats_ws, acc, B, HW, C, groups, eps, s)) return 1;

@@ -387,7 +387,6 @@ static int launch_c(const LinAttnFused& w, const float* x, float* ws, float* y, 
 int launch_linattn_fused(const LinAttnFused& w, const float* x, float* ws, float* y, int B, int n, bool add_x,
                          hipStream_t s) {
     DM_REQUIRE(w.C == 64 || w.C == 128, "fused LinearAttention: C must be 64 or 128");
-    if (w.bf16x6) return launch_linattn_bf16x6(w, x, ws, y, B, n, add_x, s);
     if (w.C == 64) return launch_c<64>(w, x, ws, y, B, n, add_x, s);
     return launch_c<128>(w, x, ws, y, B, n, add_x, s);
 }

@@ -3,6 +3,7 @@
 // statistics (:55-56).  gfx950 only.
 #include "conv_device.h"
 
+#include <algorithm>
 #include <cmath>
 
 namespace dm {
@@ -172,20 +173,22 @@ int launch_vae_attn_mfma(const float* q, const float* k, const float* v, float* 
 }
 
 // ---------------------------------------------------------------------------------------
-// GroupNorm statistics, NHWC: one block per (image, slab of pixels) reads whole pixel rows (16 bytes per lane,
-// coalesced), accumulates per-lane channel sums in fp32 over its <= 64 pixels, folds them per group in double and adds
-// them to acc[b][group][2] (sum, sum of squares; zeroed by the caller).  group_finish turns them into (mean, rstd).
+// GroupNorm statistics, NHWC, deterministic.  Stage 1: one block per (image, slab of pixel rows) reads whole pixel rows
+// (16 bytes per lane, coalesced), keeps per-lane channel sums in fp32 over its rows, folds a lane's quad in double, combines
+// the lanes of one group with wavefront shuffles (a group's channels are adjacent lanes of one pixel row: a fixed butterfly),
+// the row slots of the block through LDS in a fixed order, and writes its (sum, sum of squares) per group to
+// part[b][block][2 * groups].  Stage 2: one thread per (image, group) adds the blocks in order -> (mean, rstd).  No atomics:
+// the result does not depend on arrival order.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void group_sums_kernel(const float* __restrict__ x, double* __restrict__ acc, int HW, int C,
+constexpr int GS_MAX_BLOCKS = 64;  // slabs per image (the slab grows with the image instead)
+__global__ __launch_bounds__(256) void group_sums_kernel(const float* __restrict__ x, double* __restrict__ part, int HW, int C,
                                                          int groups, int rows_per_block) {
-    __shared__ double red[64];  // [group][2]
+    __shared__ double red[256][8];  // per thread: (sum, sum of squares) of its quad [0..1], or per element of it [2e, 2e + 1]
     const int b = blockIdx.y;
     const int c4n = C / 4;                 // float4 per pixel
     const int tpr = min(c4n, 256);         // threads per pixel row (C <= 1024)
     const int rpp = 256 / tpr;             // pixel rows in flight per pass
     const int c4 = threadIdx.x % tpr, sub = threadIdx.x / tpr;
-    if (threadIdx.x < 64) red[threadIdx.x] = 0.0;
-    __syncthreads();
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(r0 + rows_per_block, HW);
     f32x4 s = make_f32x4(0.f, 0.f, 0.f, 0.f), ss = make_f32x4(0.f, 0.f, 0.f, 0.f);
@@ -195,48 +198,88 @@ __global__ __launch_bounds__(256) void group_sums_kernel(const float* __restrict
             s += vx;
             ss += vx * vx;
         }
-    const int cg = C / groups;  // channels per group (>= 1); a float4 lies inside one group only when cg % 4 == 0
-    if (sub < rpp) {               // (cg = 6 / 12 of a 192- / 384-channel layer: a quad straddles two groups)
-        if (cg % 4 == 0) {
-            const int grp = (4 * c4) / cg;
-            atomicAdd(&red[2 * grp], (double)s.x + (double)s.y + (double)s.z + (double)s.w);
-            atomicAdd(&red[2 * grp + 1], (double)ss.x + (double)ss.y + (double)ss.z + (double)ss.w);
-        } else {
-            const float sv[4] = {s.x, s.y, s.z, s.w}, qv[4] = {ss.x, ss.y, ss.z, ss.w};
+    const int cg = C / groups;  // channels per group (>= 1)
+    if (cg % 4 != 0) {
+        // a quad straddles groups (2 channels per group at C = 64, 6 at C = 192): per-element sums through LDS, each group
+        // added up channel by channel and row slot by row slot, in order
+        const float sv[4] = {s.x, s.y, s.z, s.w}, qv[4] = {ss.x, ss.y, ss.z, ss.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int grp = (4 * c4 + e) / cg;
-                atomicAdd(&red[2 * grp], (double)sv[e]);
-                atomicAdd(&red[2 * grp + 1], (double)qv[e]);
-            }
+        for (int e = 0; e < 4; ++e) {
+            red[threadIdx.x][2 * e] = (double)sv[e];
+            red[threadIdx.x][2 * e + 1] = (double)qv[e];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * groups) {
+            const int grp = threadIdx.x >> 1, which = threadIdx.x & 1;
+            double t = 0.0;
+            for (int sb = 0; sb < rpp; ++sb)
+                for (int c = grp * cg; c < (grp + 1) * cg; ++c) t += red[sb * tpr + (c >> 2)][2 * (c & 3) + which];
+            part[((size_t)b * gridDim.x + blockIdx.x) * 2 * groups + threadIdx.x] = t;
+        }
+        return;
+    }
+    const int lpg = cg / 4;  // a group = lpg adjacent lanes of a pixel row
+    double ds = ((double)s.x + (double)s.y) + ((double)s.z + (double)s.w);
+    double dq = ((double)ss.x + (double)ss.y) + ((double)ss.z + (double)ss.w);
+    if ((lpg & (lpg - 1)) == 0 && lpg <= 64) {
+        // power-of-two group width: butterfly over the group's lanes (tpr is a multiple of lpg and divides 256, so a group
+        // never straddles a wavefront); idle row slots (sub >= rpp) hold zeros and take part harmlessly
+        for (int m = 1; m < lpg; m <<= 1) {
+            ds += __shfl_xor(ds, m);
+            dq += __shfl_xor(dq, m);
+        }
+        red[threadIdx.x][0] = ds;
+        red[threadIdx.x][1] = dq;
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * groups) {
+            const int grp = threadIdx.x >> 1, which = threadIdx.x & 1;
+            double t = 0.0;
+            for (int sb = 0; sb < rpp; ++sb) t += red[sb * tpr + grp * lpg][which];
+            part[((size_t)b * gridDim.x + blockIdx.x) * 2 * groups + threadIdx.x] = t;
+        }
+    } else {
+        red[threadIdx.x][0] = ds;
+        red[threadIdx.x][1] = dq;
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * groups) {  // e.g. 96 channels per group = 24 lanes: summed lane by lane, in order
+            const int grp = threadIdx.x >> 1, which = threadIdx.x & 1;
+            double t = 0.0;
+            for (int sb = 0; sb < rpp; ++sb)
+                for (int l = 0; l < lpg; ++l) t += red[sb * tpr + grp * lpg + l][which];
+            part[((size_t)b * gridDim.x + blockIdx.x) * 2 * groups + threadIdx.x] = t;
         }
     }
-    __syncthreads();
-    if (threadIdx.x < 2 * groups) atomicAdd(&acc[(size_t)b * 2 * groups + threadIdx.x], red[threadIdx.x]);
 }
 
-__global__ void group_finish_kernel(const double* __restrict__ acc, float* __restrict__ stats, int n_stats, double inv_n,
-                                    float eps) {
+__global__ void group_finish_kernel(const double* __restrict__ part, float* __restrict__ stats, int n_stats, int groups,
+                                    int n_blocks, double inv_n, float eps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (b, group)
     if (i >= n_stats) return;
-    const double mean = acc[2 * i] * inv_n;
-    const double var = fmax(acc[2 * i + 1] * inv_n - mean * mean, 0.0);
+    const int b = i / groups, g = i - b * groups;
+    double sum = 0.0, sq = 0.0;
+    for (int k = 0; k < n_blocks; ++k) {
+        const double* q = part + ((size_t)b * n_blocks + k) * 2 * groups + 2 * g;
+        sum += q[0];
+        sq += q[1];
+    }
+    const double mean = sum * inv_n;
+    const double var = fmax(sq * inv_n - mean * mean, 0.0);
     stats[2 * i] = (float)mean;
     stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 bool group_sums_ok(int C, int groups) { return groups == 32 && C % 32 == 0 && C % 4 == 0 && C <= 1024; }
+// floats of the statistics workspace: B * groups * 2 (mean, rstd), then the per-block partial sums as doubles
+size_t group_stats_ws_floats(int B, int groups) { return (size_t)B * groups * 2 + (size_t)B * GS_MAX_BLOCKS * 2 * groups * 2; }
 
-// stats_ws: B*groups*2 floats (mean, rstd) followed, 8-byte aligned, by B*groups*2 doubles of scratch
-int launch_group_stats_fast(const float* x, float* stats, double* acc, int B, int HW, int C, int groups, float eps,
+int launch_group_stats_fast(const float* x, float* stats, double* part, int B, int HW, int C, int groups, float eps,
                             hipStream_t s) {
     DM_REQUIRE(group_sums_ok(C, groups), "group_sums: 32 groups, C % 32 == 0, C <= 1024");
-    DM_CHECK_HIP(hipMemsetAsync(acc, 0, (size_t)B * groups * 2 * sizeof(double), s));
-    const int rows_per_block = 64;
-    hipLaunchKernelGGL(group_sums_kernel, dim3((HW + rows_per_block - 1) / rows_per_block, B), dim3(256), 0, s, x, acc, HW, C,
-                       groups, rows_per_block);
+    const int rows_per_block = std::max(64, (HW + GS_MAX_BLOCKS - 1) / GS_MAX_BLOCKS);
+    const int n_blocks = (HW + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(group_sums_kernel, dim3(n_blocks, B), dim3(256), 0, s, x, part, HW, C, groups, rows_per_block);
     const int ns = B * groups;
-    hipLaunchKernelGGL(group_finish_kernel, dim3((ns + 255) / 256), dim3(256), 0, s, acc, stats, ns,
+    hipLaunchKernelGGL(group_finish_kernel, dim3((ns + 255) / 256), dim3(256), 0, s, part, stats, ns, groups, n_blocks,
                        1.0 / ((double)HW * (C / groups)), eps);
     DM_CHECK_HIP(hipGetLastError());
     return 0;

@@ -307,46 +307,49 @@ class FIDEvaluation:
             features = features.mean(dim=(2, 3), keepdim=True)
         return features[:, :, 0, 0]
 
+    # -- statistics of a set of images: what FID compares ------------------------------------------------------------------
+    def _moments(self, batches):
+        """(mean vector, covariance matrix) of the pooled Inception features of an iterable of image batches."""
+        rows = [self.calculate_inception_features(b) for b in batches]
+        table = torch.cat(rows, dim=0).cpu().numpy()
+        return table.mean(axis=0), np.cov(table, rowvar=False)
+
+    def _real_batches(self):
+        """Up to ``ceil(n_samples / batch_size)`` batches of the real-data iterator, on the device; a short loader just ends."""
+        for _ in range(math.ceil(self.n_samples / self.batch_size)):
+            batch = next(self.dl, None)
+            if batch is None:
+                return
+            yield batch.to(self.device)
+
     def load_or_precalc_dataset_stats(self):
-        path = os.path.join(self.stats_dir, "dataset_stats")
-        synthetic = self.inception_v3.synthetic_weights  # random weights: never read or write the statistics cache
-        try:
-            if synthetic:
-                raise OSError("synthetic weights")
-            ckpt = np.load(path + ".npz")
-            self.m2, self.s2 = ckpt["m2"], ckpt["s2"]
+        """fid_evaluation.py:62-98: the real data's (m2, s2), from ``<stats_dir>/dataset_stats.npz`` (keys ``m2`` / ``s2``,
+        the reference's cache format) when that file exists, else computed from the loader and cached there.  With synthetic
+        Inception weights the cache is neither read nor written: its numbers would not mean anything to a later run."""
+        cache = os.path.join(self.stats_dir, "dataset_stats")
+        use_cache = not self.inception_v3.synthetic_weights
+        if use_cache and os.path.exists(cache + ".npz"):
+            with np.load(cache + ".npz") as stored:
+                self.m2, self.s2 = stored["m2"], stored["s2"]
             self.print_fn("Dataset stats loaded from disk.")
-            ckpt.close()
-        except OSError:
-            num_batches = int(math.ceil(self.n_samples / self.batch_size))
-            feats = []
+        else:
             self.print_fn(f"Stacking Inception features for {self.n_samples} samples from the real dataset.")
-            for _ in range(num_batches):
-                try:
-                    real_samples = next(self.dl)
-                except StopIteration:
-                    break
-                feats.append(self.calculate_inception_features(real_samples.to(self.device)))
-            feats = torch.cat(feats, dim=0).cpu().numpy()
-            m2, s2 = np.mean(feats, axis=0), np.cov(feats, rowvar=False)
-            if not synthetic:
+            self.m2, self.s2 = self._moments(self._real_batches())
+            if use_cache:
                 os.makedirs(self.stats_dir, exist_ok=True)
-                np.savez_compressed(path, m2=m2, s2=s2)
-                self.print_fn(f"Dataset stats cached to {path}.npz for future use.")
-            self.m2, self.s2 = m2, s2
+                np.savez_compressed(cache, m2=self.m2, s2=self.s2)
+                self.print_fn(f"Dataset stats cached to {cache}.npz for future use.")
         self.dataset_stats_loaded = True
 
     @torch.inference_mode()
     def fid_score(self, fake_samples):
+        """fid_evaluation.py:106-133: Frechet distance between the generated images' feature moments and the real data's."""
         if not self.dataset_stats_loaded:
             self.load_or_precalc_dataset_stats()
         self.sampler.eval()
-        feats = []
         self.print_fn(f"Stacking Inception features for {self.n_samples} generated samples.")
-        for i in range(0, len(fake_samples), self.batch_size):
-            feats.append(self.calculate_inception_features(fake_samples[i:i + self.batch_size]))
-        feats = torch.cat(feats, dim=0).cpu().numpy()
-        m1, s1 = np.mean(feats, axis=0), np.cov(feats, rowvar=False)
+        step = self.batch_size
+        m1, s1 = self._moments(fake_samples[k:k + step] for k in range(0, len(fake_samples), step))
         return calculate_frechet_distance(m1, s1, self.m2, self.s2)
 
 
@@ -363,28 +366,31 @@ class InceptionScoreEvaluation:
         os.makedirs(stats_dir, exist_ok=True)
         self.log_path = os.path.join(stats_dir, "inception_score_log.txt")
 
+    def _prepare(self, images):
+        """What torchvision's classifier expects: three channels in [0, 1] at 299x299, then the ImageNet statistics
+        (inception_score_evaluation.py:66-86)."""
+        x = images.to(self.device)
+        if self.channels == 1:
+            x = x.expand(-1, 3, -1, -1)
+        if x.min() < 0:  # [-1, 1] -> [0, 1]
+            x = (x + 1) / 2.0
+        if tuple(x.shape[-2:]) != (299, 299):
+            x = torch.nn.functional.interpolate(x, size=(299, 299), mode="bilinear", align_corners=False)
+        imagenet = torch.tensor([[0.485, 0.456, 0.406], [0.229, 0.224, 0.225]], device=self.device).view(2, 1, 3, 1, 1)
+        return (x - imagenet[0]) / imagenet[1]
+
     @torch.inference_mode()
     def calculate_inception_score(self, fake_samples):
+        """inception_score_evaluation.py:52-104: exp(mean_x KL(p(y|x) || p(y))) over the generated images."""
         self.sampler.eval()
-        preds_list = []
-        self.print_fn(f"Calculating Inception Score on {fake_samples.shape[0]} generated samples.")
-        mean = torch.tensor([0.485, 0.456, 0.406], device=self.device).view(1, 3, 1, 1)
-        std = torch.tensor([0.229, 0.224, 0.225], device=self.device).view(1, 3, 1, 1)
-        for i in range(0, fake_samples.shape[0], self.batch_size):
-            batch = fake_samples[i:i + self.batch_size].to(self.device)
-            if self.channels == 1:
-                batch = batch.expand(-1, 3, -1, -1)
-            if batch.min() < 0:  # [-1, 1] -> [0, 1]
-                batch = (batch + 1) / 2.0
-            if batch.shape[-2:] != (299, 299):
-                batch = torch.nn.functional.interpolate(batch, size=(299, 299), mode="bilinear", align_corners=False)
-            batch = (batch - mean) / std
-            preds_list.append(torch.softmax(self.inception_model.logits(batch), dim=1).cpu())
-        preds = torch.cat(preds_list, dim=0)
-        p_y = preds.mean(dim=0)
-        eps = 1e-10
-        kl_div = (preds * (torch.log(preds + eps) - torch.log(p_y + eps))).sum(dim=1)
-        inception_score = math.exp(kl_div.mean().item())
+        n = fake_samples.shape[0]
+        self.print_fn(f"Calculating Inception Score on {n} generated samples.")
+        probs = torch.cat([torch.softmax(self.inception_model.logits(self._prepare(fake_samples[k:k + self.batch_size])), dim=1).cpu()
+                           for k in range(0, n, self.batch_size)], dim=0)
+        marginal = probs.mean(dim=0)
+        tiny = 1e-10
+        kl_per_image = (probs * ((probs + tiny).log() - (marginal + tiny).log())).sum(dim=1)
+        inception_score = math.exp(kl_per_image.mean().item())
         try:
             with open(self.log_path, "a") as f:
                 f.write(f"{inception_score}\n")

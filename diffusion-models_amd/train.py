@@ -153,7 +153,8 @@ def load_checkpoint(path, diffusion, *, ema: Optional[EMA] = None):
 
 
 def train_step(diffusion, micro_batches: Iterable[torch.Tensor], *, lr=1e-4, betas=(0.9, 0.99), eps=1e-8,
-               max_grad_norm=1.0, ema: Optional[EMA] = None, t=None, noise=None, group=None, sync=True):
+               max_grad_norm=1.0, ema: Optional[EMA] = None, t=None, noise=None, group=None, sync=True,
+               timing: Optional[dict] = None):
     """One iteration of ``Trainer.train`` (:1164-1190).  ``micro_batches``: the ``gradient_accumulate_every`` image batches
     (in [0, 1]) of the iteration.  ``t`` / ``noise`` (lists, one per micro-batch) inject the random draws for tests.
     Under ``torch.distributed`` (one process per GPU, as ``accelerate`` runs the reference's Trainer) every rank computes the
@@ -161,7 +162,8 @@ def train_step(diffusion, micro_batches: Iterable[torch.Tensor], *, lr=1e-4, bet
     before the optimiser step -- all 245 gradients in a single collective; every rank then takes the same step.
     Returns (total_loss of this rank, grad_norm): floats, or with ``sync=False`` 0-dim device tensors -- the iteration is
     then only ENQUEUED when the call returns (no host round trip: the reference's loop runs ahead of the GPU the same way
-    until ``loss.item()``), so back-to-back iterations leave no idle gaps on the GPU."""
+    until ``loss.item()``), so back-to-back iterations leave no idle gaps on the GPU.  ``timing`` (a dict): HIP event pairs
+    around the gradient all-reduce are appended to ``timing["allreduce_events"]`` (bench.py reports its share)."""
     batches = list(micro_batches)
     k = len(batches)
     total = 0.0
@@ -176,9 +178,17 @@ def train_step(diffusion, micro_batches: Iterable[torch.Tensor], *, lr=1e-4, bet
 
     if dist.is_available() and dist.is_initialized():  # also at world size 1: the collective is the same code path
         flat = diffusion.model.grads_flat()
-        torch.cuda.current_stream(diffusion.device).synchronize()
+        # no host synchronisation: the collective is ordered behind the backward kernels on the current stream (torch's
+        # process group waits on it), and the division and the optimiser step are ordered behind the collective
+        ev = None
+        if timing is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         flat.div_(dist.get_world_size(group))  # DDP averages; the buffer is the library's own (zero-copy view)
+        if ev is not None:
+            ev[1].record()
+            timing.setdefault("allreduce_events", []).append(ev)
     norm = diffusion.model.optimizer_step(lr=lr, betas=betas, eps=eps, max_grad_norm=max_grad_norm, **lazy)
     if ema is not None:
         ema.update()

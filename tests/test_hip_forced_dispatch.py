@@ -24,18 +24,6 @@ def test_small_shapes_through_the_large_shape_kernels():
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
 
 
-def test_operator_cases_through_the_experimental_bf16x6_winograd_kernel():
-    """The convolution / Block cases with DM_WINOB=1 (winob_mfma.hip, off by default: F(2x2,3x3) with fp32 products as six
-    bf16 MFMA products): every eligible shape (even images >= 16x16, C % 16 == 0, Cout % 64 == 0) goes through it, at the
-    unchanged fp32 tolerance of the operator tests."""
-    for tiles in ("1", "2"):  # 32 tiles per workgroup and two workgroups per CU (default), or 64 and one
-        env = dict(os.environ, DM_WINOB="1", DM_WINOB_MIN_WGS="1", DM_WINOB_R=tiles)
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_ops.py"), "-q", "-x",
-                            "-m", "gpu", "-k", "conv2d or block", "-p", "no:cacheprovider"],
-                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
-
-
 MODEL_CASES = "test_unet_full_forward or test_unet_latent_and_text_full or test_full_samplers or test_unet_text_variants"
 
 

@@ -174,6 +174,25 @@ def test_vae_decode(golden_vae):
     assert err < FWD_TOL
 
 
+def test_vae_decode_is_bit_reproducible():
+    """VQModel.decode several times on the same latents: bit-identical.  The GroupNorm statistics
+    are a wave-shuffle + fixed-order two-stage reduction (csrc/vae_kernels.hip: group_sums_kernel), not atomics, so nothing
+    depends on the order in which workgroups arrive; every other kernel of the decoder is deterministic by construction.
+    Channel counts 64 (two groups per quad), 128 and 256 / 512 (butterfly over 2 / 4 lanes) are all on this path."""
+    for ch, mult, res, z in ((64, (1, 2), 64, 4), (64, (1, 2, 4, 8), 32, 3)):
+        cfg = DecoderConfig(ch=ch, ch_mult=mult, num_res_blocks=2, attn_resolutions=(), resolution=res, z_channels=z,
+                            embed_dim=z)
+        vae = dm.VQDecoder(dict(ch=ch, out_ch=3, ch_mult=mult, num_res_blocks=2, attn_resolutions=(), resolution=res,
+                                z_channels=z), embed_dim=z, device=DEV)
+        vae.load_state_dict(dm.synth_state_dict(dm.decoder_param_spec(cfg), salt=8))
+        side = res // 2 ** (len(mult) - 1)
+        lat = torch.randn((6, z, side, side), generator=torch.Generator().manual_seed(3)).to(DEV)
+        a = vae.decode(lat)
+        for _ in range(3):
+            assert torch.equal(vae.decode(lat), a)
+        assert bool(torch.isfinite(a).all())
+
+
 def test_latent_diffusion_vs_oracle():
     """LatentDiffusion.sample = latent loop (no (x+1)/2) + decode (latent_diffusion.py:59-66), against the oracle's loop
     with unnormalize=False followed by the oracle's VQModel.decode (the reference's own LatentDiffusion.sample output
@@ -282,22 +301,6 @@ def test_text_conditional_loop():
         err = rel_l2(got, want)
         print("text ddpm", cross, err)
         assert err < LOOP_TOL
-
-
-def test_bf16x6_linear_attention_in_child_process():
-    """The experimental LinearAttention with fp32 products on the bf16 matrix cores (linattn_bf16x6.hip; off by default,
-    the switch is read once per process): the same operator and full-model parity tests, same tolerances, in a child
-    process with DM_LINATTN_BF16X6=1."""
-    import os
-    import subprocess
-    import sys
-
-    env = dict(os.environ, DM_LINATTN_BF16X6="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "tests/test_hip_ops.py::test_linear_attention",
-                        "tests/test_hip_model.py::test_unet_full_forward", "tests/test_hip_model.py::test_full_samplers"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_vae_encode(golden_encoder):

@@ -89,8 +89,7 @@ CONV_CASES = [
     (1, 8, 0, 2, 2, 64, 1, 0, False, True, False),        # one chunk, four pixels
     (7, 72, 8, 16, 16, 128, 1, 0, False, True, False),    # chunk boundary of the concat inside the prefetch ring
     (2, 64, 0, 8, 8, 192, 1, 0, False, True, False),      # 192 couts: three 64-cout blocks (InceptionV3 branches)
-    # shapes for the experimental bf16x6 Winograd kernel (winob_mfma.hip; even images >= 16x16, C % 16 == 0, Cout % 64 == 0),
-    # which takes them only in the DM_WINOB=1 child of tests/test_hip_forced_dispatch.py; here they check the default kernels
+    # even images >= 16x16 with C % 16 == 0, Cout % 64 == 0: masked / ragged pixel blocks of the Winograd kernels
     (2, 32, 16, 24, 40, 128, 3, 1, False, True, True),    # masked 16x16 blocks, concat 32+16, two cout tiles, residual
     (1, 16, 0, 18, 34, 64, 3, 1, False, False, False),    # single chunk, no bias, ragged blocks in both directions
     # the direct 3x3 kernel behind it (odd sizes are not Winograd-eligible)
