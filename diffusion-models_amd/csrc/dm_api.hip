@@ -160,12 +160,15 @@ struct Arena {
         bool free;
     };
     std::vector<Blk> blks;  // sorted by offset, adjacent, covering [0, end of the last block)
+    int n_free = 0;         // free blocks in `blks`: the tape forward of the training step releases almost nothing, and a
+                            // best-fit scan over its ~1000 live blocks per allocation was a millisecond of host time per call
     char* origin() const { return dry ? reinterpret_cast<char*>(uintptr_t(1) << 44) : base; }
     float* alloc(size_t nfloats) {
         const size_t bytes = std::max<size_t>((nfloats * sizeof(float) + 255) & ~size_t(255), 256);
         int best = -1;
-        for (size_t i = 0; i < blks.size(); ++i)  // best fit
-            if (blks[i].free && blks[i].size >= bytes && (best < 0 || blks[i].size < blks[best].size)) best = (int)i;
+        if (n_free > 0)
+            for (size_t i = 0; i < blks.size(); ++i)  // best fit
+                if (blks[i].free && blks[i].size >= bytes && (best < 0 || blks[i].size < blks[best].size)) best = (int)i;
         size_t at;
         if (best >= 0) {
             Blk& b = blks[best];
@@ -174,14 +177,16 @@ struct Arena {
                 const Blk rest{b.off + bytes, b.size - bytes, true};
                 b.size = bytes;
                 b.free = false;
-                blks.insert(blks.begin() + best + 1, rest);
+                blks.insert(blks.begin() + best + 1, rest);  // one free block became a used one and a free rest
             } else {
                 b.free = false;
+                n_free -= 1;
             }
         } else if (!blks.empty() && blks.back().free) {  // grow the free tail
             at = blks.back().off;
             blks.back().size = bytes;
             blks.back().free = false;
+            n_free -= 1;
         } else {
             at = blks.empty() ? 0 : blks.back().off + blks.back().size;
             blks.push_back(Blk{at, bytes, false});
@@ -193,16 +198,26 @@ struct Arena {
         static const bool off = std::getenv("DM_NO_WS_REUSE") != nullptr;  // measurement switch: one fresh block per tensor
         if (!p || off) return;
         const size_t at = (size_t)(static_cast<const char*>(p) - origin());
-        for (size_t i = 0; i < blks.size(); ++i) {
-            if (blks[i].off != at || blks[i].free) continue;
+        // blocks are sorted by offset: binary search for the one that starts at `at`
+        size_t lo = 0, hi = blks.size();
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if (blks[mid].off < at) lo = mid + 1;
+            else hi = mid;
+        }
+        for (size_t i = lo; i < blks.size() && blks[i].off == at; ++i) {
+            if (blks[i].free) continue;
             blks[i].free = true;
+            n_free += 1;
             if (i + 1 < blks.size() && blks[i + 1].free) {
                 blks[i].size += blks[i + 1].size;
                 blks.erase(blks.begin() + i + 1);
+                n_free -= 1;
             }
             if (i > 0 && blks[i - 1].free) {
                 blks[i - 1].size += blks[i].size;
                 blks.erase(blks.begin() + i);
+                n_free -= 1;
             }
             return;
         }

@@ -1,7 +1,12 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python -m pytest tests/test_hip_model.py tests/test_inception.py tests/test_hip_ops.py tests/test_hip_forced_dispatch.py -x -q 2>&1 | grep -v "amdgpu.ids" | tail -5
-python3 tools/vae_time.py 2>&1 | tail -3
-DM_BENCH_REHEARSE=1 timeout -k 10 600 python3 bench.py --gpus 2 --steps 1 --warmup 1 --batch 32 --workload ddim50 --no-cpu-baseline --no-roofline --no-other-configs > gpurun_out/r4_rehearse2.json 2> gpurun_out/r4_rehearse2.err || (tail -20 gpurun_out/r4_rehearse2.err; false)
-python3 -c "
-import json; d=json.load(open('gpurun_out/r4_rehearse2.json')); print({k:d[k] for k in ('value','n_gpus')}); print(d['train_step'])"
+for k in 0 8; do
+echo "== DM_WINO4_ROUND_K=$k"
+DM_WINO4_ROUND_K=$k python3 tools/step_time.py --batch 256 --size 32
+DM_WINO4_ROUND_K=$k python3 tools/step_time.py --batch 64 --size 32
+DM_WINO4_ROUND_K=$k python3 tools/step_time.py --batch 32 --size 64
+DM_WINO4_ROUND_K=$k python3 tools/step_time.py --batch 8 --size 64
+done
+python3 tools/layer_report.py --batch 8 --size 64 > gpurun_out/r4_layer_report_b8_64.txt 2>&1
+python3 tools/layer_report.py --batch 256 --size 32 > gpurun_out/r4_layer_report_b256_32.txt 2>&1
+tail -5 gpurun_out/r4_layer_report_b8_64.txt
