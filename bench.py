@@ -331,9 +331,14 @@ def train_leg(dev, with_cpu: bool, batch: int = 64, iters: int = 10, world: int 
     timing = {} if world > 1 else None
     barrier()
     t0 = time.perf_counter()
+    host_ms = []
     for _ in range(iters):  # enqueued back to back; loss / norm stay device tensors (the reference's loss.item() is the caller's)
+        th = time.perf_counter()
         loss, norm = dm.train_step(d, [img], lr=2e-4, ema=ema, sync=False, timing=timing)
+        host_ms.append(round(1e3 * (time.perf_counter() - th), 2))
     barrier()
+    if os.environ.get("DM_BENCH_DEBUG"):
+        print(f"[rank {rank}] train_step host ms per iteration: {host_ms}", file=sys.stderr)
     dt = (time.perf_counter() - t0) / iters
     if world > 1:
         tmax = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
@@ -349,7 +354,10 @@ def train_leg(dev, with_cpu: bool, batch: int = 64, iters: int = 10, world: int 
         out["allreduce_ms"] = sum(ar) / len(ar)
         out["allreduce_share"] = out["allreduce_ms"] / (1e3 * dt)
         out["allreduce_bytes"] = int(d.model.grads_flat().numel()) * 4
-        out["allreduce"] = "one in-place all-reduce of the flat gradient buffer per iteration, not overlapped with the backward pass"
+        out["allreduce"] = ("bucket by bucket on a second stream, each bucket as soon as the backward pass has completed it "
+                            "(allreduce_ms = what is left exposed behind the pass)" if getattr(d.model, "_bucketed", False)
+                            else "one in-place all-reduce of the flat gradient buffer per iteration, behind the backward pass")
+        out["gradient_buckets_MB"] = [round(4 * n / 2 ** 20, 1) for _, n in d.model.grad_buckets()]
     out["roofline"] = train_roofline(1e3 * dt) if world == 1 else None
     del d, u, ema
     if with_cpu:

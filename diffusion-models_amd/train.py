@@ -154,38 +154,64 @@ def load_checkpoint(path, diffusion, *, ema: Optional[EMA] = None):
 
 def train_step(diffusion, micro_batches: Iterable[torch.Tensor], *, lr=1e-4, betas=(0.9, 0.99), eps=1e-8,
                max_grad_norm=1.0, ema: Optional[EMA] = None, t=None, noise=None, group=None, sync=True,
-               timing: Optional[dict] = None):
+               timing: Optional[dict] = None, bucketed: Optional[bool] = None):
     """One iteration of ``Trainer.train`` (:1164-1190).  ``micro_batches``: the ``gradient_accumulate_every`` image batches
     (in [0, 1]) of the iteration.  ``t`` / ``noise`` (lists, one per micro-batch) inject the random draws for tests.
-    Under ``torch.distributed`` (one process per GPU, as ``accelerate`` runs the reference's Trainer) every rank computes the
-    gradients of ITS micro-batches and ONE in-place all-reduce of the flat gradient buffer (RCCL over xGMI) averages them
-    before the optimiser step -- all 245 gradients in a single collective; every rank then takes the same step.
+    Under ``torch.distributed`` (one process per GPU, as ``accelerate`` runs the reference's Trainer under DDP) every rank
+    computes the gradients of ITS micro-batches and the flat gradient buffer is averaged over the ranks in place (RCCL over
+    xGMI) before the optimiser step; every rank then takes the same step.  With more than one rank (``bucketed=True`` forces
+    it, ``False`` forbids it) the buffer is all-reduced BUCKET BY BUCKET on a second stream, each bucket as soon as the
+    backward pass has completed it -- DDP's overlap of communication with the backward pass (``Unet.grad_buckets``);
+    otherwise as one collective.
     Returns (total_loss of this rank, grad_norm): floats, or with ``sync=False`` 0-dim device tensors -- the iteration is
     then only ENQUEUED when the call returns (no host round trip: the reference's loop runs ahead of the GPU the same way
     until ``loss.item()``), so back-to-back iterations leave no idle gaps on the GPU.  ``timing`` (a dict): HIP event pairs
     around the gradient all-reduce are appended to ``timing["allreduce_events"]`` (bench.py reports its share)."""
+    import torch.distributed as dist
+
     batches = list(micro_batches)
     k = len(batches)
     total = 0.0
     lazy = {} if sync else {"sync": False}  # only the asynchronous form asks the diffusion object for anything new
+    parallel = dist.is_available() and dist.is_initialized()  # also at world size 1: the collectives are the same code path
+    unet = diffusion.model
+    # by default on RCCL with more than one rank (gloo stages every collective through pinned host memory: nothing to overlap)
+    overlap = parallel and bucketed is not False and hasattr(unet, "grad_buckets") and (
+        bucketed or (dist.get_world_size(group) > 1 and dist.get_backend(group) == "nccl"))
+    if overlap != getattr(unet, "_bucketed", False) and hasattr(unet, "grad_buckets"):
+        unet.grad_buckets(enable=overlap)
     for i, data in enumerate(batches):
         x = diffusion.normalize(data.to(diffusion.device, torch.float32))
         ti = t[i] if t is not None else torch.randint(0, diffusion.num_timesteps, (x.shape[0],)).long()
         ni = noise[i] if noise is not None else None
         loss = diffusion.p_losses(x, ti, noise=ni, loss_scale=1.0 / k, accumulate=i > 0, **lazy)
         total = (total + float(loss)) if sync else (loss if i == 0 else total + loss)
-    import torch.distributed as dist
-
-    if dist.is_available() and dist.is_initialized():  # also at world size 1: the collective is the same code path
-        flat = diffusion.model.grads_flat()
-        # no host synchronisation: the collective is ordered behind the backward kernels on the current stream (torch's
-        # process group waits on it), and the division and the optimiser step are ordered behind the collective
+    if parallel:
+        # DDP averages the gradients over the ranks.  The buffer is the library's own (a zero-copy view); no host
+        # synchronisation anywhere: each collective is ordered behind the kernels that complete its span, and the optimiser
+        # step behind the collectives.
+        flat, world = unet.grads_flat(), dist.get_world_size(group)
         ev = None
         if timing is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        flat.div_(dist.get_world_size(group))  # DDP averages; the buffer is the library's own (zero-copy view)
+        if overlap:
+            # bucket by bucket, on a second stream: a bucket's all-reduce starts when the backward pass (still running --
+            # the call above only enqueued it) has completed that bucket, and runs beside the rest of the pass
+            main = torch.cuda.current_stream(diffusion.device)
+            if unet._comm_stream is None:
+                unet._comm_stream = torch.cuda.Stream(device=diffusion.device)
+            side = unet._comm_stream
+            for b, (off, n) in enumerate(unet.grad_buckets()):
+                unet.bucket_wait(b, side)
+                with torch.cuda.stream(side):
+                    span = flat[off:off + n]
+                    dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group)
+                    span.div_(world)
+            main.wait_stream(side)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            flat.div_(world)
         if ev is not None:
             ev[1].record()
             timing.setdefault("allreduce_events", []).append(ev)

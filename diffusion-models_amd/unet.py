@@ -83,6 +83,8 @@ class Unet:
         self._lib = _lib.load()
         self._handle = C.c_void_p()
         self._loaded = False
+        self._bucketed = False  # data-parallel gradient buckets (grad_buckets)
+        self._comm_stream = None
 
         c = _lib.UnetCfg()
         c.dim, c.init_dim, c.out_dim = cfg.dim, cfg.init_dim or 0, cfg.out_dim_
@@ -211,6 +213,27 @@ class Unet:
                                         "version": 2}
 
         return torch.as_tensor(_View(), device=self.device)
+
+    def grad_buckets(self, enable: Optional[bool] = None):
+        """[(offset, length)] spans (floats) of ``grads_flat()`` in the order the backward pass completes them -- torch DDP's
+        gradient buckets.  ``enable=True`` makes every later loss / backward call finish a bucket's weight gradients as soon
+        as it has left the bucket's stages (``bucket_wait`` then lets a collective run beside the rest of the pass)."""
+        n = self._lib.dm_unet_train_buckets(self._handle, int(bool(enable)) if enable is not None else int(self._bucketed))
+        if n < 0:
+            raise RuntimeError("grad_buckets() needs a model in training mode")
+        if enable is not None:
+            self._bucketed = bool(enable)
+        spans = []
+        for i in range(n):
+            off, cnt = C.c_int64(0), C.c_int64(0)
+            _lib.check(self._lib.dm_unet_train_bucket(self._handle, i, C.byref(off), C.byref(cnt), 0, None))
+            spans.append((int(off.value), int(cnt.value)))
+        return spans
+
+    def bucket_wait(self, i: int, stream: "torch.cuda.Stream"):
+        """Make ``stream`` wait until bucket ``i`` of the last loss / backward call is complete."""
+        off, cnt = C.c_int64(0), C.c_int64(0)
+        _lib.check(self._lib.dm_unet_train_bucket(self._handle, i, C.byref(off), C.byref(cnt), 1, stream.cuda_stream))
 
     def optimizer_step(self, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=1.0, sync=True):
         """``clip_grad_norm_(max_grad_norm)`` + ``Adam(lr, betas).step()`` of ``Trainer.train``

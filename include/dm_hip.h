@@ -310,6 +310,17 @@ int64_t dm_unet_grad_floats(dm_unet* u);
 /* the flat gradient buffer itself (device pointer, dm_unet_grad_floats floats): data-parallel training (accelerate / DDP in
  * the reference's Trainer) all-reduces it in place -- ONE collective for all gradients -- before dm_unet_optimizer_step */
 int dm_unet_grads_flat(dm_unet* u, float** ptr_out, int64_t* n_out);
+/* Gradient buckets for data-parallel training -- what torch DDP's 25 MB buckets are to the reference's Trainer under accelerate
+ * (DD/denoising_diffusion.py:971-974, :1175): the flat buffer is laid out bucket by bucket in the order the backward pass
+ * completes them (convolution weights of the stages it leaves first; the last bucket holds the last stages and every
+ * parameter only the end of the pass completes), DM_TRAIN_BUCKET_MB (default 25) per bucket.
+ *   dm_unet_train_buckets(u, enable): returns the number of buckets; with enable != 0 every later dm_unet_loss_backward runs a
+ *     bucket's weight gradients as soon as the pass has left the bucket's stages, and records an event.
+ *   dm_unet_train_bucket(u, i, &off, &n, wait, stream): bucket i's span of the flat buffer in floats; with wait != 0 `stream`
+ *     is made to wait for the bucket's event of the last pass, so that a collective enqueued on it runs beside the rest of
+ *     the pass (the caller joins the streams before dm_unet_optimizer_step). */
+int dm_unet_train_buckets(dm_unet* u, int enable);
+int dm_unet_train_bucket(dm_unet* u, int i, int64_t* off_out, int64_t* n_out, int wait, void* wait_stream);
 /* copy the gradient of one parameter (names as in dm_unet_set_param) into a DEVICE buffer of the parameter's size */
 int dm_unet_get_grad(dm_unet* u, const char* name, float* out_dev, void* stream);
 /* One p_losses call (:823-889) + backward:

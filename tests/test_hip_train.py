@@ -667,3 +667,39 @@ def test_non_ddpm_loss_weight_training_step_vs_oracle():
     got = d.model.grads()
     worst = max((rel_l2(got[k].cpu(), want[k]), k) for k in want)
     assert worst[0] < GRAD_TOL, worst
+
+
+def test_bucketed_backward_gives_the_same_gradients():
+    """Data-parallel gradient buckets (Unet.grad_buckets): the spans tile the flat gradient buffer in order, the full U-Net
+    has several of them at the default 25 MB, and a backward pass that finishes its weight gradients bucket by bucket leaves
+    the same gradients as the pass that runs them all at the end (other split tables: equal to rounding, not bit for bit)."""
+    cfg = UnetConfig()
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=0)
+    u = dm.Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=3, device=DEV)
+    u.load_state_dict(sd)
+    d = dm.DenoisingDiffusion(u, image_size=32, timesteps=1000).train()
+    g = torch.Generator().manual_seed(21)
+    x_start = torch.rand((8, 3, 32, 32), generator=g) * 2 - 1
+    t = torch.randint(0, 1000, (8,), generator=g)
+    noise = torch.randn((8, 3, 32, 32), generator=g)
+    loss_a = float(d.p_losses(x_start, t, noise=noise))
+    ga = {k: v.clone() for k, v in d.model.grads().items()}
+    spans = u.grad_buckets(enable=True)
+    print("buckets (MB):", [round(4 * n / 2 ** 20, 1) for _, n in spans])
+    assert len(spans) >= 3 and spans[0][0] == 0
+    for (o0, n0), (o1, _) in zip(spans, spans[1:]):
+        assert o0 + n0 == o1 and n0 > 0
+    assert spans[-1][0] + spans[-1][1] == u.grads_flat().numel()
+    loss_b = float(d.p_losses(x_start, t, noise=noise))
+    gb = d.model.grads()
+    assert loss_a == loss_b
+    worst = max((rel_l2(gb[k], ga[k]), k) for k in ga)
+    print("bucketed vs end-of-pass weight gradients, worst", worst)
+    assert worst[0] < 1e-5
+    # the spans are spans of grads_flat(), which holds every gradient exactly once (and zero padding)
+    flat = u.grads_flat().double()
+    total = sum(float(v.double().pow(2).sum()) for v in gb.values())
+    assert abs(float(flat.pow(2).sum()) - total) <= 1e-9 * total
+    assert all(float(flat[o:o + n].abs().sum()) > 0 for o, n in spans)
+    u.grad_buckets(enable=False)
+    assert float(d.p_losses(x_start, t, noise=noise)) == loss_a

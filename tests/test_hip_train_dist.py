@@ -41,7 +41,12 @@ try:
     nz = torch.randn((B, 3, 16, 16), generator=g)
     lo, hi = rank * B // world, (rank + 1) * B // world
     d = model()
-    dm.train_step(d, [img[lo:hi]], lr=1e-3, t=[t[lo:hi]], noise=[nz[lo:hi]])       # sharded: all-reduce inside
+    bucketed = os.environ.get("DM_TEST_BUCKETED") == "1"   # False: ONE collective over the whole buffer
+    if bucketed:
+        assert len(d.model.grad_buckets()) >= 2, d.model.grad_buckets()   # DM_TRAIN_BUCKET_MB=1: several buckets on this net
+    # sharded: the all-reduce(s) inside; asynchronous, so that a bucket's collective really is enqueued beside the pass
+    loss, norm = dm.train_step(d, [img[lo:hi]], lr=1e-3, t=[t[lo:hi]], noise=[nz[lo:hi]], sync=False, bucketed=bucketed)
+    assert d.model._bucketed == bool(bucketed) and float(loss) > 0 and float(norm) > 0
     got = d.model.state_dict()
     if rank == 0:
         dist_was = dist.is_initialized()
@@ -69,12 +74,14 @@ def _free_port():
     return p
 
 
-def _run(world, backend):
+def _run(world, backend, bucketed=False):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, DM_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r),
                    WORLD_SIZE=str(world), LOCAL_RANK=str(r), DM_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if bucketed:  # 1 MB buckets: the two-stage test net (15 MB of gradients) then has several
+            env.update(DM_TEST_BUCKETED="1", DM_TRAIN_BUCKET_MB="1")
         procs.append(subprocess.Popen([sys.executable, "-c", CHILD], cwd=ROOT, env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
@@ -90,3 +97,14 @@ def test_two_ranks_gloo_equal_one_process_on_the_whole_batch():
 
 def test_world1_nccl_all_reduce_of_the_flat_gradient_buffer():
     _run(1, "nccl")
+
+
+def test_two_ranks_gloo_bucketed_all_reduce_overlapping_the_backward_pass():
+    """The same equality with the gradient buffer all-reduced bucket by bucket on a second stream, each bucket as soon as the
+    backward pass has completed it (torch DDP's overlap; Unet.grad_buckets / dm_unet_train_bucket)."""
+    outs = _run(2, "gloo", bucketed=True)
+    print(outs[0][0])
+
+
+def test_world1_nccl_bucketed_all_reduce():
+    _run(1, "nccl", bucketed=True)

@@ -1,12 +1,5 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-for k in 0 8; do
-echo "== DM_WINO4_ROUND_K=$k"
-DM_WINO4_ROUND_K=$k python3 tools/step_time.py --batch 256 --size 32
-DM_WINO4_ROUND_K=$k python3 tools/step_time.py --batch 64 --size 32
-DM_WINO4_ROUND_K=$k python3 tools/step_time.py --batch 32 --size 64
-DM_WINO4_ROUND_K=$k python3 tools/step_time.py --batch 8 --size 64
-done
-python3 tools/layer_report.py --batch 8 --size 64 > gpurun_out/r4_layer_report_b8_64.txt 2>&1
-python3 tools/layer_report.py --batch 256 --size 32 > gpurun_out/r4_layer_report_b256_32.txt 2>&1
-tail -5 gpurun_out/r4_layer_report_b8_64.txt
+DM_BENCH_DEBUG=1 DM_BENCH_REHEARSE=1 timeout -k 10 600 python3 bench.py --gpus 2 --steps 1 --warmup 1 --batch 32 --workload ddim50 --no-cpu-baseline --no-roofline --no-other-configs > gpurun_out/r4_rehearse2.json 2> gpurun_out/r4_rehearse2.err || (tail -20 gpurun_out/r4_rehearse2.err; false)
+grep "host ms" gpurun_out/r4_rehearse2.err
+tail -c 500 gpurun_out/r4_rehearse2.json
