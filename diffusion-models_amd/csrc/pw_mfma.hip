@@ -9,7 +9,10 @@
 // flight per wave and two workgroups share a CU.  (The generic kernel conv_mfma.hip stages a pixel window and the weights
 // through LDS for every 16 channels: at these shapes less than half of its time is MFMA issue.)
 // One wave = 64 pixels x 64 couts (4 x 4 MFMA tiles, 64 accumulators); one workgroup = 4 waves as 256 px x 64 couts
-// (WGN = 1) or 128 px x 128 couts (WGN = 2).  The 16-row MFMA is chosen for its operand addressing: the four kq lanes
+// (WGN = 1) or 128 px x 128 couts (WGN = 2).  RT < 4 (32 or 16 pixels per wave): for grids that cannot fill the chip -- a
+// wave's time is its MFMA chain, chunks x RT x 512 cycles, so a 1024-pixel projection on 48 workgroups takes 14 us of
+// matrix issue per wave while 3/4 of the CUs idle; with RT = 1 it is 192 workgroups and a quarter of the chain (the weights
+// are then pulled through L2 four times as often, which at these sizes is megabytes).  The 16-row MFMA is chosen for its operand addressing: the four kq lanes
 // of a pixel row read 64 consecutive bytes, 16 cache lines per load instruction instead of the 64 of the 32x32x2
 // mapping (measured 3 % faster over the 1x1 layers of a forward).  Epilogue: the shared row epilogue (conv_device.h)
 // after a per-wave transposition through LDS, 32 pixel rows at a time.
@@ -69,22 +72,36 @@ ConvGeom pw_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_spl
     g.WN = Cout % 128 == 0 ? 2 : 1;
     g.WM = 4 / g.WN;
     g.CK = PWCK;
-    g.TW = g.TH = g.NB = 1;
+    g.TW = g.NB = 1;
+    g.TH = 4;  // RT: 16-pixel row tiles per wave (4, 2 or 1; chosen below)
     g.tiles_x = (int)((M + 64 * g.WM - 1) / (64 * g.WM));  // pixel blocks
     g.tiles_y = 1;
     g.groups = 1;
     g.n_tiles_n = Cout / (64 * g.WN);
     g.TPS = 1;
     const int n_chunks = (C0 + C1) / PWCK;
-    const int wgs = g.tiles_x * g.n_tiles_n;
+    // A grid that leaves CUs idle is bound by the MFMA chain of ONE wave (chunks x RT x 512 cycles): first fewer pixels per
+    // wave (RT 4 -> 2 -> 1: more workgroups, a shorter chain, no extra output traffic), then K splits (partial sums + a
+    // landing pass).  DM_PW_RT_FIRST=0: the other order.
+    static const int rt_target = env_int("DM_PW_RT_TARGET_WGS", 512);
+    static const int rt_min = env_int("DM_PW_RT_MIN", 1);
+    static const bool rt_first = env_int("DM_PW_RT_FIRST", 1) != 0;
+    auto shrink_rt = [&](int splits_now) {
+        while (g.TH > rt_min && g.tiles_x * g.n_tiles_n * splits_now < rt_target) {
+            g.TH /= 2;
+            g.tiles_x = (int)((M + 16 * g.TH * g.WM - 1) / (16 * g.TH * g.WM));
+        }
+    };
+    if (rt_first) shrink_rt(1);
     int splits = 1;
     if (allow_split) {
         static const int target = env_int("DM_PW_TARGET_WGS", 256);
         static const int min_chunks = env_int("DM_PW_MIN_CHUNKS", 8);
-        while (wgs * splits < target && splits < 8 && n_chunks / (splits * 2) >= min_chunks) splits *= 2;
+        while (g.tiles_x * g.n_tiles_n * splits < target && splits < 8 && n_chunks / (splits * 2) >= min_chunks) splits *= 2;
     }
     g.chunks_per_split = (n_chunks + splits - 1) / splits;
     g.splits = (n_chunks + g.chunks_per_split - 1) / g.chunks_per_split;
+    if (!rt_first) shrink_rt(g.splits);
     g.fused_norm = Cout == 64 && g.splits == 1;
     g.lds_bytes = 4 * 32 * PWTS * 4;
     return g;
@@ -95,7 +112,7 @@ bool pw_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1) {
     return M > 0 && M < (1u << 24) && M * (size_t)std::max(Cout, std::max(C0, C1)) < (1ull << 30);
 }
 
-template <int WGN>
+template <int WGN, int RT>
 __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
     constexpr int WGM = 4 / WGN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -111,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
     block_to_tile(g, blockIdx.x, gridDim.x, n_blk, m_blk);
     const int ct = n_blk * WGN + wn;  // 64-cout tile of this wave
     const unsigned M = (unsigned)((size_t)p.B * p.Ho * p.Wo);
-    const unsigned px0 = ((unsigned)m_blk * WGM + wm) * 64u;
+    const unsigned px0 = ((unsigned)m_blk * WGM + wm) * (16u * RT);
     const int split = blockIdx.y;
     const int cb = split * g.chunks_per_split;
     const int ce = min(cb + g.chunks_per_split, p.n_chunks);
@@ -126,9 +143,9 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
     const unsigned src_px = p.s2d ? 4u * M : M;
     const __amdgpu_buffer_rsrc_t rs_in0 = make_rsrc(p.in0, (size_t)src_px * p.C0 * 4);
     const __amdgpu_buffer_rsrc_t rs_in1 = make_rsrc(p.C1 ? p.in1 : p.in0, (size_t)M * (p.C1 ? p.C1 : p.C0) * 4);
-    unsigned avo0[4], avo1[4];
+    unsigned avo0[RT], avo1[RT];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
         unsigned px = min(px0 + 16u * rt + (unsigned)l15, M - 1u);
         avo1[rt] = (__umul24(px, (unsigned)p.C1) + 4u * kq) * 4u;
         if (p.s2d) {
@@ -143,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (size_t)p.n_chunks * w_chunk * 4);
     const unsigned wvo = (unsigned)(((4 * ct) * 64 + lane) * 4 * 4);  // cout tile 4 ct; the next tiles are 1024 bytes apart
 
-    f32x4 a[PWD][4], b[PWD][4];
+    f32x4 a[PWD][RT], b[PWD][4];
     auto load = [&](int c, int d) {
         const bool s1 = c >= p.chunks0;
         unsigned so = (unsigned)(s1 ? c - p.chunks0 : c) * (PWCK * 4);
@@ -152,16 +169,16 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
             so = (((sub >> 1) * 2u * p.Wo + (sub & 1u)) * (unsigned)p.C0 + cs * PWCK) * 4u;
         }
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) a[d][rt] = bufload4(s1 ? rs_in1 : rs_in0, s1 ? avo1[rt] : avo0[rt], so);
+        for (int rt = 0; rt < RT; ++rt) a[d][rt] = bufload4(s1 ? rs_in1 : rs_in0, s1 ? avo1[rt] : avo0[rt], so);
         const unsigned wo = (unsigned)c * (unsigned)(w_chunk * 4);
 #pragma unroll
         for (int t = 0; t < 4; ++t) b[d][t] = bufload4(rs_w, wvo + 1024u * t, wo);
     };
 
     const f32x4 z4 = make_f32x4(0.f, 0.f, 0.f, 0.f);
-    f32x4 acc[4][4];  // [row tile][cout tile]: register e of lane (n = l15, kq) = pixel 16 rt + 4 kq + e, cout 16 t + n
+    f32x4 acc[RT][4];  // [row tile][cout tile]: register e of lane (n = l15, kq) = pixel 16 rt + 4 kq + e, cout 16 t + n
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[rt][t] = z4;
 
@@ -174,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt)
+                    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
                             acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][rt][j], b[d][t][j], acc[rt][t], 0, 0, 0);
@@ -200,18 +217,19 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
     re.wn = 0;
     re.all_valid = true;
     float* T = smem + (size_t)wave * 32 * PWTS;
+    constexpr int NRE = RT >= 2 ? 8 : 4;  // pixel rows per lane group and pass: 32 rows (two row tiles) or the wave's 16
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        int pixv[8];
+    for (int r = 0; r < (RT + 1) / 2; ++r) {
+        int pixv[NRE];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NRE; ++j) {
             const unsigned px = px0 + 32u * r + 4u * j + (unsigned)rsub;
             pixv[j] = px < M ? (int)px : -1;
         }
-        RowsPrefetch<8, true> pf;
-        rows_prefetch<8, true>(p, re, pixv, cg, cvalid, pf);
+        RowsPrefetch<NRE, true> pf;
+        rows_prefetch<NRE, true>(p, re, pixv, cg, cvalid, pf);
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < (RT >= 2 ? 2 : 1); ++h)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float* dst = T + (16 * h + 4 * kq) * PWTS + 16 * t + l15;
@@ -222,17 +240,22 @@ __global__ __launch_bounds__(256, 2) void pw_mfma_kernel(const ConvParams p) {
                 dst[3 * PWTS] = v4.w;
             }
         __builtin_amdgcn_wave_barrier();
-        f32x4 v[8];
+        f32x4 v[NRE];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(T + (4 * j + rsub) * PWTS + c4);
+        for (int j = 0; j < NRE; ++j) v[j] = *reinterpret_cast<const f32x4*>(T + (4 * j + rsub) * PWTS + c4);
         __builtin_amdgcn_wave_barrier();
-        rows_epilogue<1, 8, true>(p, re, v, pixv, cg, cvalid, pf);
+        rows_epilogue<1, NRE, true>(p, re, v, pixv, cg, cvalid, pf);
     }
 }
 
 template <int WGN>
 static int pw_launch_t(const ConvParams& p, int blocks, hipStream_t s) {
-    hipLaunchKernelGGL(pw_mfma_kernel<WGN>, dim3(blocks, p.geo.splits, 1), dim3(256), p.geo.lds_bytes, s, p);
+    const dim3 grid(blocks, p.geo.splits, 1);
+    switch (p.geo.TH) {
+        case 4: hipLaunchKernelGGL((pw_mfma_kernel<WGN, 4>), grid, dim3(256), p.geo.lds_bytes, s, p); break;
+        case 2: hipLaunchKernelGGL((pw_mfma_kernel<WGN, 2>), grid, dim3(256), p.geo.lds_bytes, s, p); break;
+        default: hipLaunchKernelGGL((pw_mfma_kernel<WGN, 1>), grid, dim3(256), p.geo.lds_bytes, s, p); break;
+    }
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -260,8 +283,8 @@ int pw_launch(const ConvParams& pin, hipStream_t s) {
     DM_REQUIRE(M > 0 && M < (1u << 24) && M * (size_t)std::max(p.Cout, std::max(p.C0, p.C1)) < (1ull << 30),
                "pointwise: tensor too large for 24-bit pixel indices");
     DM_REQUIRE((g.WN == 1 || g.WN == 2) && g.WM * g.WN == 4 && p.Cout % (64 * g.WN) == 0 &&
-                   g.n_tiles_n == p.Cout / (64 * g.WN) && (size_t)g.tiles_x * 64 * g.WM >= M &&
-                   (size_t)(g.tiles_x - 1) * 64 * g.WM < M,
+                   (g.TH == 4 || g.TH == 2 || g.TH == 1) && g.n_tiles_n == p.Cout / (64 * g.WN) &&
+                   (size_t)g.tiles_x * 16 * g.TH * g.WM >= M && (size_t)(g.tiles_x - 1) * 16 * g.TH * g.WM < M,
                "pointwise: plan does not match the tensor");
     DM_REQUIRE(!(p.epi & EPI_NORM) || (p.Cout == 64 && g.splits == 1), "pointwise: fused RMSNorm needs all couts in one wave");
     DM_REQUIRE(g.splits == 1 || p.partial, "pointwise: split-K writes partial sums");
@@ -280,8 +303,8 @@ int pw_launch(const ConvParams& pin, hipStream_t s) {
         const double bytes = 4.0 * (cin * pix + (1.0 + res_rows) * p.Cout * pix + cin * p.Cout);
         char name[64];
         if (prof::detail())
-            snprintf(name, sizeof(name), "pw<%d> 1x1 %d+%d->%d @%dx%d%s e%d k%d", g.WN, p.C0, p.C1, p.Cout, p.Ho, p.Wo,
-                     p.s2d ? " s2d" : "", p.epi, g.splits);
+            snprintf(name, sizeof(name), "pw<%d> 1x1 %d+%d->%d @%dx%d%s e%d k%d g%d r%d", g.WN, p.C0, p.C1, p.Cout, p.Ho,
+                     p.Wo, p.s2d ? " s2d" : "", p.epi, g.splits, blocks * g.splits, g.TH);
         else
             snprintf(name, sizeof(name), "pw_mfma_kernel<%d>", g.WN);
         if (prof::begin(name, flops, bytes, s)) return 1;

@@ -421,8 +421,8 @@ int upwino_launch(const ConvParams& pin, hipStream_t s) {
         const double bytes = 4.0 * (p.C0 * pix / 4 + (1.0 + res_rows) * p.Cout * pix + 9.0 * p.C0 * p.Cout);
         char name[64];
         if (prof::detail())
-            snprintf(name, sizeof(name), "upwino<%d> 3x3 up %d->%d @%dx%d e%d k%d", cls, p.C0, p.Cout, p.Ho, p.Wo, p.epi,
-                     g.splits);
+            snprintf(name, sizeof(name), "upwino<%d> 3x3 up %d->%d @%dx%d e%d k%d g%d", cls, p.C0, p.Cout, p.Ho, p.Wo, p.epi,
+                     g.splits, blocks * g.splits);
         else
             snprintf(name, sizeof(name), "upwino_mfma_kernel<%d>", cls);
         if (prof::begin(name, flops, bytes, s)) return 1;

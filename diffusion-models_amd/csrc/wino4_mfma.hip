@@ -631,8 +631,8 @@ int wino4_launch(const ConvParams& pin, hipStream_t s) {
         const double bytes = 4.0 * (cin * pix + (1.0 + res_rows) * p.Cout * pix + 9.0 * cin * p.Cout);
         char name[64];
         if (prof::detail())
-            snprintf(name, sizeof(name), "wino4<%d> 3x3 s1 %d+%d->%d @%dx%d e%d k%d", ltw, p.C0, p.C1, p.Cout, p.Ho, p.Wo,
-                     p.epi, g.splits);
+            snprintf(name, sizeof(name), "wino4<%d> 3x3 s1 %d+%d->%d @%dx%d e%d k%d g%d", ltw, p.C0, p.C1, p.Cout, p.Ho, p.Wo,
+                     p.epi, g.splits, blocks * g.splits);
         else
             snprintf(name, sizeof(name), "wino4_mfma_kernel<%d>", ltw);
         if (prof::begin(name, flops, bytes, s)) return 1;

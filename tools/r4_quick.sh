@@ -1,5 +1,10 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-DM_BENCH_DEBUG=1 DM_BENCH_REHEARSE=1 timeout -k 10 600 python3 bench.py --gpus 2 --steps 1 --warmup 1 --batch 32 --workload ddim50 --no-cpu-baseline --no-roofline --no-other-configs > gpurun_out/r4_rehearse2.json 2> gpurun_out/r4_rehearse2.err || (tail -20 gpurun_out/r4_rehearse2.err; false)
-grep "host ms" gpurun_out/r4_rehearse2.err
-tail -c 500 gpurun_out/r4_rehearse2.json
+for cfg in "DM_PW_RT_FIRST=1" "DM_PW_RT_FIRST=0" "DM_PW_RT_FIRST=1 DM_PW_TARGET_WGS=512" "DM_PW_RT_FIRST=1 DM_PW_MIN_CHUNKS=4"; do
+echo "== $cfg"
+env $cfg python3 tools/step_time.py --batch 256 --size 32
+env $cfg python3 tools/step_time.py --batch 64 --size 32
+env $cfg python3 tools/step_time.py --batch 32 --size 64
+env $cfg python3 tools/step_time.py --batch 8 --size 64
+env $cfg python3 tools/train_time.py --batch 64 --steps 30 --dropout 0.1 | tail -1
+done
