@@ -90,6 +90,7 @@ struct ConvGeom {
     int magic_win, magic_row;  // winograd: ceil(2^24 / (IH*IW)), ceil(2^24 / IW): divisions of the window setup
     int lds_bytes;
     int xcd_groups;      // 3x3 kernels: XCDs that share a cout tile (8 / n_tiles_n), 0 = blocks in raw order
+    int NQ;              // winograd F(2x2): 32-cout MFMA blocks per workgroup (2: 64 couts; 1: 32, for grids that leave CUs idle)
 };
 
 struct ConvParams {

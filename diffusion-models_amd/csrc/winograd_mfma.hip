@@ -113,6 +113,15 @@ ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_s
     g.chunks_per_split = (n_chunks + splits - 1) / splits;
     g.splits = (n_chunks + g.chunks_per_split - 1) / g.chunks_per_split;
     g.fused_norm = g.n_tiles_n == 1 && g.splits == 1;
+    // A grid that still leaves workgroup slots empty is bound by the MFMA chain of ONE wave (chunks x 32 MFMAs x 64 cycles):
+    // with 32 instead of 64 couts per workgroup the chain halves and the workgroups double.  Not where the 64-cout tile
+    // holds a pixel's whole row (the RMSNorm then runs in the kernel's epilogue instead of a landing pass).
+    g.NQ = 2;
+    static const int q_target = env_int("DM_WINO_Q_TARGET_WGS", 512);
+    if (R == 1 && !g.fused_norm && wgs * g.splits < q_target) {
+        g.NQ = 1;
+        g.n_tiles_n = Cout / 32;
+    }
     g.w_floats = 0;
     // two windows + a scratch slot reachable from both; the epilogue reuses the space for 4 x 2 transposed tiles;
     // behind both: the output-pixel table [wave][2a+b][tile of the wave] (built once, read by the epilogue)
@@ -129,9 +138,10 @@ bool wino_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1) {
            (size_t)B * Ho * Wo < (1u << 24) && (size_t)B * Ho * Wo * std::max(C0, C1) < (1ull << 30);
 }
 
-template <int R>
+template <int R, int Q>
 __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams p) {
     constexpr int TILES = 32 * R;         // Winograd tiles per workgroup
+    constexpr int NC = 32 * Q;            // couts per workgroup
     constexpr int HR = R == 2 ? 5 : 3;    // window staging registers (16 B each) per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ConvGeom& g = p.geo;
@@ -262,19 +272,19 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
     }
 
     f32x4 A[4][R];  // V[wave][j] of tile r: channels 4*lh .. 4*lh+3 of the chunk
-    f32x4 U[4][2];  // U[wave*4 + j][cout 32*q + l31][channels 4*lh ..]
+    f32x4 U[4][Q];  // U[wave*4 + j][cout 32*q + l31][channels 4*lh ..]
     const size_t u_chunk = (size_t)16 * p.Cout * WCK;
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (size_t)p.n_chunks * u_chunk * 4);
     const unsigned uvo = (l31 * WCK + 4 * lh) * 4;  // bytes
     const unsigned u_row = (unsigned)p.Cout * WCK * 4;  // bytes between consecutive xi
-    const unsigned u_wave = ((unsigned)(4 * wave) * p.Cout + n_tile * 64) * WCK * 4;
-    auto load_u = [&](int chunk, int j) {  // U of (chunk, xi = 4*wave + j): couts l31 and 32 + l31
+    const unsigned u_wave = ((unsigned)(4 * wave) * p.Cout + n_tile * NC) * WCK * 4;
+    auto load_u = [&](int chunk, int j) {  // U of (chunk, xi = 4*wave + j): couts l31 and (Q == 2) 32 + l31
         const unsigned so = (unsigned)chunk * (unsigned)(u_chunk * 4) + u_wave + j * u_row;
         U[j][0] = bufload4(rs_w, uvo, so);
-        U[j][1] = bufload4(rs_w, uvo, so + 32 * WCK * 4);
+        if constexpr (Q == 2) U[j][1] = bufload4(rs_w, uvo, so + 32 * WCK * 4);
     };
 
-    f32x16 acc[4][R][2];  // first written by the first chunk's MFMAs (C = 0)
+    f32x16 acc[4][R][Q];  // first written by the first chunk's MFMAs (C = 0)
 
     DM_STAMP_ADD(4)
     // ---- prologue: chunks cb and cb + 1 -> LDS (both loads in flight together), operands of chunk cb -> registers
@@ -337,6 +347,7 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
         auto rdn = [&](int r, int ab, int b) { return *reinterpret_cast<const f32x4*>(rdp[BN][r][ab][b]); };
         f32x4 T[R][4];
         if constexpr (R == 2) {
+            static_assert(R == 1 || Q == 2, "the 64-tile form keeps 64 couts");
             f32x4 d[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -376,31 +387,41 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
             A[3][1] = sub4(T[1][1], T[1][3]);
         } else {
             f32x4 d[4];
+            // the hooks of the 32-MFMA stream (Q == 2: one per MFMA slot; Q == 1: two per slot of its 16 MFMAs -- "the MFMAs
+            // of j are issued" holds at the same hook index either way, MFMA (j, s, q) sitting at index ((4 j + s) 2 + q 2 / Q))
+            auto hook = [&](int m) {
+                if (m < HR) hreg[m] = window_value(cw, m);
+                if (m >= 3 && m < 7) d[m - 3] = rdn(0, (m - 3) & 1, (m - 3) >> 1);  // columns 0, 1
+                if (m == 8) load_u(unext, 0);  // j = 0 done at m = 7
+                if (m == 11) T[0][0] = fma4(d[1], sgn2, d[0]);
+                if (m == 12) T[0][1] = fma4(d[3], sgn2, d[2]);
+                if (m >= 13 && m < 17) d[m - 13] = rdn(0, (m - 13) & 1, 2 + ((m - 13) >> 1));  // columns 2, 3
+                if (m == 17) load_u(unext, 1);  // j = 1 done at m = 15
+                if (m == 21) T[0][2] = fma4(d[1], sgn2, d[0]);
+                if (m == 22) {
+                    T[0][3] = fma4(d[3], sgn2, d[2]);
+                    A[0][0] = sub4(T[0][0], T[0][2]);
+                }
+                if (m == 23) A[1][0] = add4(T[0][1], T[0][2]);
+                if (m == 24) load_u(unext, 2);  // j = 2 done at m = 23
+                if (m == 25) A[2][0] = sub4(T[0][2], T[0][1]);
+                if (m >= 27 && m < 27 + HR) *reinterpret_cast<f32x4*>(stp[BS][m - 27]) = hreg[m - 27];
+            };
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int m = (j * 4 + s) * 2 + q;  // 0..31
+                    for (int q = 0; q < Q; ++q) {
+                        const int m = (j * 4 + s) * Q + q;  // 0 .. 16 Q - 1
                         acc[j][0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                             A[j][0][s], U[j][q][s], (FIRST && s == 0) ? zero16 : acc[j][0][q], 0, 0, 0);
-                        if (m < HR) hreg[m] = window_value(cw, m);
-                        if (m >= 3 && m < 7) d[m - 3] = rdn(0, (m - 3) & 1, (m - 3) >> 1);  // columns 0, 1
-                        if (m == 8) load_u(unext, 0);  // j = 0 done at m = 7
-                        if (m == 11) T[0][0] = fma4(d[1], sgn2, d[0]);
-                        if (m == 12) T[0][1] = fma4(d[3], sgn2, d[2]);
-                        if (m >= 13 && m < 17) d[m - 13] = rdn(0, (m - 13) & 1, 2 + ((m - 13) >> 1));  // columns 2, 3
-                        if (m == 17) load_u(unext, 1);  // j = 1 done at m = 15
-                        if (m == 21) T[0][2] = fma4(d[1], sgn2, d[0]);
-                        if (m == 22) {
-                            T[0][3] = fma4(d[3], sgn2, d[2]);
-                            A[0][0] = sub4(T[0][0], T[0][2]);
+                        if constexpr (Q == 2) {
+                            hook(m);
+                        } else {
+                            hook(2 * m);
+                            hook(2 * m + 1);
                         }
-                        if (m == 23) A[1][0] = add4(T[0][1], T[0][2]);
-                        if (m == 24) load_u(unext, 2);  // j = 2 done at m = 23
-                        if (m == 25) A[2][0] = sub4(T[0][2], T[0][1]);
-                        if (m >= 27 && m < 27 + HR) *reinterpret_cast<f32x4*>(stp[BS][m - 27]) = hreg[m - 27];
                         __builtin_amdgcn_sched_barrier(0);
                     }
             A[3][0] = sub4(T[0][1], T[0][3]);
@@ -428,8 +449,8 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
     const int rsub = lane >> 4;
     const int oa = rsub >> 1, ob = rsub & 1;
     const int c4 = (lane & 15) * 4;
-    const int cg = n_tile * 64 + c4;
-    const bool cvalid = cg < p.Cout;
+    const int cg = n_tile * NC + c4;
+    const bool cvalid = c4 < NC && cg < p.Cout;  // Q == 1: the upper half of a 16-lane row has no couts
     int pixv[NR];
     {
         const int* pt = reinterpret_cast<const int*>(smem + g.ptab_off) + wave * (4 * NR) + rsub * NR;
@@ -452,7 +473,7 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
     re.rows_per_wg = 4 * TILES;
     re.row_in_wg0 = wave * 4 * NR;
     re.wn = 0;
-    re.all_valid = true;
+    re.all_valid = Q == 2;
     RowsPrefetch<NR, true> pf;
     rows_prefetch<NR, true>(p, re, pixv, cg, cvalid, pf);
 
@@ -460,7 +481,7 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < Q; ++q) {
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {  // two accumulator registers per packed instruction
                 const f32x2 a0 = {acc[0][r][q][e], acc[0][r][q][e + 1]}, a1 = {acc[1][r][q][e], acc[1][r][q][e + 1]};
@@ -492,10 +513,10 @@ __global__ __launch_bounds__(256, 3 - R) void wino_mfma_kernel(const ConvParams 
     DM_STAMP_FLUSH
 }
 
-template <int R>
+template <int R, int Q>
 static int wino_launch_r(const ConvParams& p, int blocks, hipStream_t s) {
     static LdsOptIn lds_flag;
-    if (lds_opt_in(lds_flag, reinterpret_cast<const void*>(wino_mfma_kernel<R>), 1)) return 1;
+    if (lds_opt_in(lds_flag, reinterpret_cast<const void*>(wino_mfma_kernel<R, Q>), 1)) return 1;
 #ifdef DM_STAMPS
     // diagnostic build: run the launch synchronously with a stamp buffer and print the phase averages
     {
@@ -505,7 +526,7 @@ static int wino_launch_r(const ConvParams& p, int blocks, hipStream_t s) {
         DM_CHECK_HIP(hipMemsetAsync(dbuf, 0, nblk * 8 * sizeof(unsigned long long), s));
         ConvParams ps = p;
         ps.stamps = dbuf;
-        hipLaunchKernelGGL(wino_mfma_kernel<R>, dim3(blocks, p.geo.splits, 1), dim3(256), p.geo.lds_bytes, s, ps);
+        hipLaunchKernelGGL((wino_mfma_kernel<R, Q>), dim3(blocks, p.geo.splits, 1), dim3(256), p.geo.lds_bytes, s, ps);
         DM_CHECK_HIP(hipStreamSynchronize(s));
         std::vector<unsigned long long> h(nblk * 8);
         DM_CHECK_HIP(hipMemcpy(h.data(), dbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -520,7 +541,7 @@ static int wino_launch_r(const ConvParams& p, int blocks, hipStream_t s) {
         return 0;
     }
 #endif
-    hipLaunchKernelGGL(wino_mfma_kernel<R>, dim3(blocks, p.geo.splits, 1), dim3(256), p.geo.lds_bytes, s, p);
+    hipLaunchKernelGGL((wino_mfma_kernel<R, Q>), dim3(blocks, p.geo.splits, 1), dim3(256), p.geo.lds_bytes, s, p);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -535,6 +556,7 @@ int wino_launch(const ConvParams& pin, hipStream_t s) {
     DM_REQUIRE(p.Hin == p.Ho && p.Win == p.Wo, "winograd: same-size convolution");
     const int R = g.WM;
     DM_REQUIRE(R == 1 || R == 2, "winograd: tiles per lane");
+    DM_REQUIRE((g.NQ == 2 || (g.NQ == 1 && R == 1)) && g.n_tiles_n == p.Cout / (32 * g.NQ), "winograd: cout tile");
     DM_REQUIRE(g.TW * g.TH * g.NB == 32 * R, "winograd: 32 R tiles per workgroup");
     DM_REQUIRE(g.NB * g.IH * g.IW * 2 <= 256 * (R == 2 ? 5 : 3), "winograd: window exceeds staging registers");
     DM_REQUIRE((size_t)p.B * p.Ho * p.Wo < (1u << 24) && p.C0 < (1 << 24) && p.C1 < (1 << 24) &&
@@ -559,13 +581,14 @@ int wino_launch(const ConvParams& pin, hipStream_t s) {
         const double bytes = 4.0 * (cin * pix + (1.0 + res_rows) * p.Cout * pix + 9.0 * cin * p.Cout);
         char name[64];
         if (prof::detail())
-            snprintf(name, sizeof(name), "wino<%d> 3x3 s1 %d+%d->%d @%dx%d e%d k%d g%d", R, p.C0, p.C1, p.Cout, p.Ho, p.Wo,
-                     p.epi, g.splits, blocks * g.splits);
+            snprintf(name, sizeof(name), "wino<%d> 3x3 s1 %d+%d->%d @%dx%d e%d k%d g%d q%d", R, p.C0, p.C1, p.Cout, p.Ho,
+                     p.Wo, p.epi, g.splits, blocks * g.splits, g.NQ);
         else
             snprintf(name, sizeof(name), "wino_mfma_kernel<%d>", R);
         if (prof::begin(name, flops, bytes, s)) return 1;
     }
-    if (R == 2 ? wino_launch_r<2>(p, blocks, s) : wino_launch_r<1>(p, blocks, s)) return 1;
+    if (R == 2 ? wino_launch_r<2, 2>(p, blocks, s) : (g.NQ == 1 ? wino_launch_r<1, 1>(p, blocks, s) : wino_launch_r<1, 2>(p, blocks, s)))
+        return 1;
     if (timed && prof::end(s)) return 1;
     return 0;
 }

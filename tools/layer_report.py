@@ -62,7 +62,7 @@ for r in rows:
 
 if args.bounds:
     PEAK, CLK, L2B = 157.3e12, 2.4e9, 64.0
-    pat = re.compile(r"^(wino4|wino|upwino|pw)<(\d)> \S+ (?:s1 |up )?(\d+)(?:\+(\d+))?->(\d+) @(\d+)x(\d+)( s2d)? e\d+ k(\d+) g(\d+)(?: r(\d))?")
+    pat = re.compile(r"^(wino4|wino|upwino|pw)<(\d)> \S+ (?:s1 |up )?(\d+)(?:\+(\d+))?->(\d+) @(\d+)x(\d+)( s2d)? e\d+ k(\d+) g(\d+)(?: [rq](\d))?")
     print()
     print(f"{'layer':58s} {'n':>3s} {'us':>6s} {'t_mfma':>6s} {'t_chain':>7s} {'t_wts':>6s} {'fill':>5s} {'x bound':>7s}")
     worst = []
@@ -81,12 +81,15 @@ if args.bounds:
         taps = 1 if kind == "pw" else 9
         if kind == "pw" and rt:  # 16-pixel row tiles per wave (4, 2, 1): the chain and the weight reuse scale with it
             cyc = cyc * int(rt) // 4
+        if kind == "wino" and rt:  # 32-cout blocks per workgroup (2, 1)
+            cyc = cyc * int(rt) // 2
         busy = min(g, 256)
         t_mfma = 1e6 * direct * share / (PEAK * busy / 256)
         rounds = -(-g // (256 * per_cu))
         chunks = -(-(cin // ck) // k)
         t_chain = 1e6 * rounds * chunks * cyc / CLK
-        wbytes = g * (cin / k) * taps * wfac * 64 * 4.0   # every workgroup streams its 64-cout slice of its K range
+        nc = 32 * int(rt) if (kind == "wino" and rt) else 64
+        wbytes = g * (cin / k) * taps * wfac * nc * 4.0   # every workgroup streams its cout slice of its K range
         t_wts = 1e6 * wbytes / (L2B * CLK * busy)
         bound = max(t_mfma, t_chain, t_wts)
         n = r["launches"] // args.iters
