@@ -365,6 +365,7 @@ int launch_wgrad_naive(const float* x, int x_nchw, const float* dy, int dy_nchw,
                        int B, int H, int W, float* ws, float* dw, int accumulate, hipStream_t s, WgradJob* defer = nullptr);
 // jobs_dev: n_jobs descriptors in device memory with first_block filled in, total_blocks = the last prefix
 int launch_wgrad_reduce_jobs(const WgradJob* jobs_dev, int n_jobs, int total_blocks, hipStream_t s);
+int wgrad_reduce_pairs(int T, long long oc);  // (cout, cin) pairs per workgroup of the reduce kernels for a job
 size_t norm_act_bwd_ws_floats(int B, int pix_per_image, int C);
 // the two reduction stages behind a norm_act_bwd_kernel / the two passes of a column sum, as deferred table entries
 struct RowgradJob {

@@ -399,20 +399,69 @@ __device__ __forceinline__ void wgrad_reduce_block(const WgradJob& j, int lb, fl
     float* o = j.out + i0 * T;
     for (int k = threadIdx.x; k < n; k += 256) o[k] = j.accumulate ? o[k] + tile[k] : tile[k];
 }
+// The same for 256 consecutive (cout, cin) pairs per workgroup, 16 bytes per lane (T >= 4, oc % 4 == 0): the 64-pair form
+// is ~88 000 workgroups of 4 KB each for the U-Net's 3x3 layers -- bound by workgroup dispatch, not by the 0.4 GB it moves
+// (0.31 ms at any batch); this one is a quarter of the workgroups with four times the bytes in flight per lane.
+constexpr int WRP = 256;  // pairs per workgroup of the wide form
+__device__ __forceinline__ void wgrad_reduce_block_wide(const WgradJob& j, int lb, float* tile) {
+    const int T = j.T;
+    const int TS = T | 1;  // odd row stride: the nine-tap gather below walks rows
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t i0 = (int64_t)lb * WRP, i = i0 + 4 * li;
+    for (int t = q; t < T; t += 4) {
+        f32x4 s = make_f32x4(0.f, 0.f, 0.f, 0.f);
+        if (i < j.oc)
+            for (int sp = 0; sp < j.splits; ++sp) s += *reinterpret_cast<const f32x4*>(j.partial + ((int64_t)sp * T + t) * j.oc + i);
+        tile[(4 * li + 0) * TS + t] = s.x;
+        tile[(4 * li + 1) * TS + t] = s.y;
+        tile[(4 * li + 2) * TS + t] = s.z;
+        tile[(4 * li + 3) * TS + t] = s.w;
+    }
+    __syncthreads();
+    const int pairs = (int)min((int64_t)WRP, j.oc - i0);
+    if (T == 16) {
+        float* o = j.out + i0 * 9;
+        for (int k = threadIdx.x; k < pairs * 9; k += 256) {
+            const int pr = k / 9, uv = k - pr * 9, u = uv / 3, v = uv - u * 3;
+            const float* M = tile + pr * TS;
+            float r[4];  // r[jj] = sum_i G[i][u] M[i][jj]   (G columns as in wgrad_reduce_block)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float m0 = M[jj], m1 = M[4 + jj], m2 = M[8 + jj], m3 = M[12 + jj];
+                r[jj] = u == 0 ? m0 + 0.5f * (m1 + m2) : (u == 1 ? 0.5f * (m1 - m2) : 0.5f * (m1 + m2) + m3);
+            }
+            const float val = v == 0 ? r[0] + 0.5f * (r[1] + r[2]) : (v == 1 ? 0.5f * (r[1] - r[2]) : 0.5f * (r[1] + r[2]) + r[3]);
+            o[k] = j.accumulate ? o[k] + val : val;
+        }
+        return;
+    }
+    const int64_t n = (int64_t)pairs * T;
+    float* o = j.out + i0 * T;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const int pr = k / T, t = k - pr * T;
+        const float val = tile[pr * TS + t];
+        o[k] = j.accumulate ? o[k] + val : val;
+    }
+}
+// pairs one workgroup of the reduce kernels takes for a job
+int wgrad_reduce_pairs(int T, long long oc) { return (T >= 4 && T <= 16 && oc % 4 == 0) ? WRP : 64; }
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradJob j) {
-    __shared__ float tile[64 * 17 + 4 * 64];
-    wgrad_reduce_block(j, blockIdx.x, tile);
+    __shared__ float tile[WRP * 17];
+    if (j.T >= 4 && j.T <= 16 && j.oc % 4 == 0) wgrad_reduce_block_wide(j, blockIdx.x, tile);
+    else wgrad_reduce_block(j, blockIdx.x, tile);
 }
 // the same sum for a table of layers: workgroup -> job by binary search over the block prefix
 __global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const WgradJob* __restrict__ jobs, int n_jobs) {
-    __shared__ float tile[64 * 17 + 4 * 64];
+    __shared__ float tile[WRP * 17];
     int lo = 0, hi = n_jobs - 1;
     while (lo < hi) {  // last job whose first_block <= blockIdx.x
         const int mid = (lo + hi + 1) >> 1;
         if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const WgradJob j = jobs[lo];
-    wgrad_reduce_block(j, blockIdx.x - j.first_block, tile);
+    if (j.T >= 4 && j.T <= 16 && j.oc % 4 == 0) wgrad_reduce_block_wide(j, blockIdx.x - j.first_block, tile);
+    else wgrad_reduce_block(j, blockIdx.x - j.first_block, tile);
 }
 int launch_wgrad_reduce_jobs(const WgradJob* jobs_dev, int n_jobs, int total_blocks, hipStream_t s) {
     if (n_jobs <= 0) return 0;
@@ -535,7 +584,8 @@ int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float
         *defer = WgradJob{ws, dw, oc, splits, T, accumulate, 0};
         return 0;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((oc + 63) / 64)), dim3(256), 0, s,
+    const int rp = wgrad_reduce_pairs(T, (long long)oc);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((oc + rp - 1) / rp)), dim3(256), 0, s,
                        WgradJob{ws, dw, oc, splits, T, accumulate, 0});
     DM_CHECK_HIP(hipGetLastError());
     return 0;
@@ -746,7 +796,8 @@ int launch_wgrad_naive(const float* x, int x_nchw, const float* dy, int dy_nchw,
         *defer = WgradJob{ws, dw, (long long)n_out, splits, 1, accumulate, 0};
         return 0;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 63) / 64), dim3(256), 0, s,
+    const int rpn = wgrad_reduce_pairs(1, 1);  // T = 1 jobs of the thin layers: the 64-pair form
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + rpn - 1) / rpn), dim3(256), 0, s,
                        WgradJob{ws, dw, (long long)n_out, splits, 1, accumulate, 0});
     DM_CHECK_HIP(hipGetLastError());
     return 0;
