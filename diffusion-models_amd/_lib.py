@@ -48,6 +48,7 @@ class UnetCfg(C.Structure):
         ("dim_mults", C.c_int32 * DM_MAX_STAGES), ("full_attn", C.c_int32 * DM_MAX_STAGES),
         ("attn_heads", C.c_int32), ("attn_dim_head", C.c_int32),
         ("text_mode", C.c_int32), ("text_emb_dim", C.c_int32), ("sinusoidal_theta", C.c_float),
+        ("learned_sinusoidal_dim", C.c_int32),
     ]
 
 

@@ -699,7 +699,10 @@ static int build_all(dm_unet* u) {
     const dm_unet_cfg& cfg = u->cfg;
     const int n = cfg.n_stages;
     // sinusoid frequencies, fp32 as the reference computes them (DD/denoising_diffusion.py:79-81)
-    if (weight_group(u, "#freqs", [&]() -> int {
+    if (cfg.learned_sinusoidal_dim > 0) {
+        // RandomOrLearnedSinusoidalPosEmb (:86-101): the frequencies are the parameter time_mlp.0.weights
+        if (weight_group(u, "time_mlp.0", [&]() -> int { return up1(u, "time_mlp.0.weights", &u->freqs); })) return 1;
+    } else if (weight_group(u, "#freqs", [&]() -> int {
             int half = cfg.dim / 2;
             double k = std::log((double)cfg.sinusoidal_theta) / (half - 1);
             float kf = (float)(-k);
@@ -1221,7 +1224,9 @@ static int unet_forward_impl(dm_unet* u, Arena& A, const float* x_nchw, const in
     // the time embedding is one row when the whole batch shares t (samplers), else one row per sample
     const int Bt = (step_times && !text_concat) ? 1 : B;
     const int Rt = step_times ? 1 : B;  // rows of the sinusoid / time_mlp
-    float* e0 = A.alloc((size_t)Rt * cfg.dim);
+    const int lsd = cfg.learned_sinusoidal_dim;  // > 0: cat(t, sin(t w 2 pi), cos(t w 2 pi)) of width lsd + 1 (:96-101)
+    const int fdim = lsd > 0 ? lsd + 1 : cfg.dim;
+    float* e0 = A.alloc((size_t)Rt * fdim);
     float* e1 = A.alloc((size_t)Rt * td);
     float* temb = A.alloc((size_t)B * td);
     float* ss = A.alloc((size_t)Bt * u->ss_total);
@@ -1231,8 +1236,8 @@ static int unet_forward_impl(dm_unet* u, Arena& A, const float* x_nchw, const in
     hipStream_t ts = s;
     if (c.par && fork_side(c, &ts)) return 1;
     if (!A.dry) {
-        if (launch_sinusoid(t_dev, step_times, step_dev, u->freqs, e0, Rt, cfg.dim / 2, ts)) return 1;
-        if (launch_linear_rows(e0, cfg.dim, u->tw1, u->tb1, e1, td, Rt, cfg.dim, td, 0, 2, ts)) return 1;
+        if (launch_sinusoid(t_dev, step_times, step_dev, u->freqs, e0, Rt, (lsd > 0 ? lsd : cfg.dim) / 2, ts, lsd > 0)) return 1;
+        if (launch_linear_rows(e0, fdim, u->tw1, u->tb1, e1, td, Rt, fdim, td, 0, 2, ts)) return 1;
         if (launch_linear_rows(e1, td, u->tw2, u->tb2, temb, td, Rt, td, td, 0, 0, ts)) return 1;
     }
     const float* tfinal = temb;
@@ -1407,7 +1412,8 @@ int dm_unet_create(const dm_unet_cfg* cfg, int device, dm_unet** out) {
     const int n = cfg->n_stages, td = u->time_dim;
     expect(p, "init_conv.weight", {u->init_dim, cfg->input_channels, 7, 7});
     expect(p, "init_conv.bias", {u->init_dim});
-    expect(p, "time_mlp.1.weight", {td, cfg->dim});
+    if (cfg->learned_sinusoidal_dim > 0) expect(p, "time_mlp.0.weights", {cfg->learned_sinusoidal_dim / 2});
+    expect(p, "time_mlp.1.weight", {td, cfg->learned_sinusoidal_dim > 0 ? cfg->learned_sinusoidal_dim + 1 : cfg->dim});
     expect(p, "time_mlp.1.bias", {td});
     expect(p, "time_mlp.3.weight", {td, td});
     expect(p, "time_mlp.3.bias", {td});

@@ -245,8 +245,8 @@ struct SamplerState {
     uint64_t off4;       // Philox counter of this shard's first element = global element index / 4
 };
 // e[r] = cat(sin(t[r]*f), cos(t[r]*f)); t int64; if step_times != nullptr t = step_times[state->step]
-int launch_sinusoid(const int64_t* t, const int64_t* step_times, const SamplerState* state, const float* freqs, float* e,
-                    int R, int half, hipStream_t s);
+int launch_sinusoid(const int64_t* t, const int64_t* step_times, const SamplerState* step, const float* freqs, float* e,
+                    int R, int half, hipStream_t s, bool learned = false);
 // VAE kernels (vae_kernels.hip): MFMA flash attention of AttnBlock, coalesced GroupNorm statistics
 bool vae_attn_mfma_ok(int n, int C);
 int launch_vae_attn_mfma(const float* q, const float* k, const float* v, float* out, int B, int n, int C, hipStream_t s);

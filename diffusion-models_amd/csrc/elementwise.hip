@@ -306,20 +306,30 @@ int launch_linear_rows(const float* x, int ldx, const float* W, const float* bia
 // exactly as the reference computes them (fp32) so only sin/cos run here.
 __global__ void sinusoid_kernel(const int64_t* __restrict__ t, const int64_t* __restrict__ step_times,
                                 const SamplerState* __restrict__ st, const float* __restrict__ freqs,
-                                float* __restrict__ e, int R, int half) {
+                                float* __restrict__ e, int R, int half, int learned) {
+#pragma clang fp contract(off)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R * half) return;
     int r = i / half, k = i - r * half;
     int64_t tv = step_times ? step_times[st->step] : t[r];
+    if (learned) {
+        // RandomOrLearnedSinusoidalPosEmb (:96-101): (x * w) * 2 pi in fp32, row = [x | sin | cos]
+        const float a = ((float)tv * freqs[k]) * 6.283185307179586f;
+        float* row = e + (size_t)r * (2 * half + 1);
+        if (k == 0) row[0] = (float)tv;
+        row[1 + k] = sinf(a);
+        row[1 + half + k] = cosf(a);
+        return;
+    }
     float a = (float)tv * freqs[k];
     e[(size_t)r * 2 * half + k] = sinf(a);
     e[(size_t)r * 2 * half + half + k] = cosf(a);
 }
 int launch_sinusoid(const int64_t* t, const int64_t* step_times, const SamplerState* step, const float* freqs, float* e,
-                    int R, int half, hipStream_t s) {
+                    int R, int half, hipStream_t s, bool learned) {
     int n = R * half;
     hipLaunchKernelGGL(sinusoid_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, step_times, step, freqs, e, R,
-                       half);
+                       half, learned ? 1 : 0);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -34,8 +34,8 @@ class UnetConfig:
 
     Mirrors denoising_diffusion.py:234-252 (and the text subclass,
     denoising_diffusion_text_conditional.py:97).  Options the sampling path
-    never uses with ``DenoisingDiffusion`` (learned sinusoidal embedding,
-    dropout at eval time, flash attention) are deliberately absent.
+    never uses (dropout at eval time, flash attention) are deliberately absent.  The random / learned sinusoidal
+    embedding (:86-100) is here for ``Unet.forward`` alone: ``DenoisingDiffusion`` refuses such a U-Net (:456-457).
     """
 
     dim: int = 64
@@ -46,6 +46,9 @@ class UnetConfig:
     self_condition: bool = False
     learned_variance: bool = False
     sinusoidal_pos_emb_theta: float = 10000.0
+    learned_sinusoidal_cond: bool = False
+    random_fourier_features: bool = False
+    learned_sinusoidal_dim: int = 16
     attn_dim_head: int = 32
     attn_heads: int = 4
     full_attn: Optional[Tuple[bool, ...]] = None
@@ -74,6 +77,15 @@ class UnetConfig:
     @property
     def time_dim(self) -> int:
         return self.dim * 4
+
+    @property
+    def random_or_learned_sinusoidal_cond(self) -> bool:
+        return self.learned_sinusoidal_cond or self.random_fourier_features
+
+    @property
+    def fourier_dim(self) -> int:
+        """Width of the time embedding in front of time_mlp.1 (:271-278)."""
+        return self.learned_sinusoidal_dim + 1 if self.random_or_learned_sinusoidal_cond else self.dim
 
     @property
     def dims(self) -> List[int]:
@@ -165,7 +177,8 @@ def unet_param_spec(cfg: UnetConfig, prefix: str = "") -> ParamSpec:
     spec: ParamSpec = [
         (f"{p}init_conv.weight", (cfg.init_dim_, cfg.input_channels, 7, 7)),
         (f"{p}init_conv.bias", (cfg.init_dim_,)),
-        (f"{p}time_mlp.1.weight", (td, cfg.dim)),
+        *([(f"{p}time_mlp.0.weights", (cfg.learned_sinusoidal_dim // 2,))] if cfg.random_or_learned_sinusoidal_cond else []),
+        (f"{p}time_mlp.1.weight", (td, cfg.fourier_dim)),
         (f"{p}time_mlp.1.bias", (td,)),
         (f"{p}time_mlp.3.weight", (td, td)),
         (f"{p}time_mlp.3.bias", (td,)),

@@ -31,7 +31,7 @@ def synth_tensor(name: str, shape: Tuple[int, ...], salt: int = 0) -> torch.Tens
     leaf = name.rsplit(".", 1)[-1]
     if leaf == "g":  # RMSNorm / RMSNorm1D gain
         return 1.0 + 0.25 * torch.randn(shape, generator=g)
-    if leaf == "mem_kv":
+    if leaf in ("mem_kv", "weights"):  # `weights`: RandomOrLearnedSinusoidalPosEmb, N(0, 1) (denoising_diffusion.py:94)
         return torch.randn(shape, generator=g)
     if leaf in ("weight", "bias") and (".norm" in name or "norm_out" in name) and len(shape) == 1:
         # GroupNorm affine (VAE decoder)

@@ -57,15 +57,16 @@ class Unet:
         cond_channels=0,
         device="cuda:0",
     ):
-        if learned_sinusoidal_cond or random_fourier_features:
-            # DenoisingDiffusion asserts this combination away (denoising_diffusion.py:457)
-            raise NotImplementedError("random / learned sinusoidal embeddings are not on the sampling path")
+        # learned_sinusoidal_cond / random_fourier_features (denoising_diffusion.py:86-101, :271-273): forward() only --
+        # DenoisingDiffusion asserts such a U-Net away (:456-457), and so does ours
         if not isinstance(attn_heads, int) or not isinstance(attn_dim_head, int):
             raise NotImplementedError("per-stage attention head settings are not supported by the HIP path")
         self.cfg = UnetConfig(
             dim=dim, init_dim=init_dim, out_dim=out_dim, dim_mults=tuple(dim_mults), channels=channels,
             self_condition=self_condition, learned_variance=learned_variance,
-            sinusoidal_pos_emb_theta=float(sinusoidal_pos_emb_theta), attn_dim_head=attn_dim_head,
+            sinusoidal_pos_emb_theta=float(sinusoidal_pos_emb_theta), learned_sinusoidal_cond=bool(learned_sinusoidal_cond),
+            random_fourier_features=bool(random_fourier_features), learned_sinusoidal_dim=int(learned_sinusoidal_dim),
+            attn_dim_head=attn_dim_head,
             attn_heads=attn_heads, full_attn=tuple(full_attn) if full_attn else None,
             cond_channels=cond_channels, text_condition=text_condition, use_cross_attn=use_cross_attn,
             text_emb_dim=text_emb_dim,
@@ -77,7 +78,7 @@ class Unet:
         self.out_dim = cfg.out_dim_
         self.text_condition = text_condition
         self.use_cross_attn = use_cross_attn
-        self.random_or_learned_sinusoidal_cond = False
+        self.random_or_learned_sinusoidal_cond = cfg.random_or_learned_sinusoidal_cond
         self.device = torch.device(device)
         self._dev_index = _device_index(device)
         self._lib = _lib.load()
@@ -97,6 +98,7 @@ class Unet:
         c.text_mode = 0 if not text_condition else (2 if use_cross_attn else 1)
         c.text_emb_dim = text_emb_dim
         c.sinusoidal_theta = float(sinusoidal_pos_emb_theta)
+        c.learned_sinusoidal_dim = cfg.learned_sinusoidal_dim if cfg.random_or_learned_sinusoidal_cond else 0
         _lib.check(self._lib.dm_unet_create(C.byref(c), self._dev_index, C.byref(self._handle)))
 
     # -- lifecycle -------------------------------------------------------------------------
@@ -176,7 +178,12 @@ class Unet:
             if not self._loaded:
                 raise RuntimeError("load_state_dict() must be called before train()")
             if self.self_condition and self.cfg.cond_channels:
-                raise NotImplementedError("the HIP training step does not combine self-conditioning with an image condition")
+                # the reference's own combination is broken: its image-conditional Unet.forward concatenates cond in front
+                # of the base forward, whose default x_self_cond = zeros_like(x) then has channels + cond_channels channels
+                # against the channels * 2 + cond_channels init_conv expects (denoising_diffusion_image_conditional.py:51-55,
+                # denoising_diffusion.py:352-354): every call without a predicted x_self_cond raises
+                raise NotImplementedError("self-conditioning with an image condition: the reference's own forward raises "
+                                          "whenever x_self_cond is not given (zeros_like of the concatenated input)")
             _lib.check(self._lib.dm_unet_train_enable(self._handle))
             if not getattr(self, "_training", False):
                 self.set_dropout_seed(int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()))

@@ -51,6 +51,9 @@ typedef struct dm_unet_cfg {
     int32_t text_mode;
     int32_t text_emb_dim;
     float sinusoidal_theta;
+    int32_t learned_sinusoidal_dim; /* 0: SinusoidalPosEmb(dim, theta); > 0: RandomOrLearnedSinusoidalPosEmb of that
+                                       dimension (DD/denoising_diffusion.py:86-101, parameter time_mlp.0.weights) --
+                                       dm_unet_forward only: DenoisingDiffusion refuses such a U-Net (:456-457) */
 } dm_unet_cfg;
 
 typedef struct dm_unet dm_unet;

@@ -44,9 +44,19 @@ def sinusoidal_pos_emb(t: torch.Tensor, dim: int, theta: float = 10000.0) -> tor
     return torch.cat((ang.sin(), ang.cos()), dim=-1)
 
 
+def learned_sinusoidal_pos_emb(t: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+    """RandomOrLearnedSinusoidalPosEmb.forward (DD/denoising_diffusion.py:96-101): cat(x, sin(x w 2 pi), cos(x w 2 pi))."""
+    x = t.to(weights.dtype)[:, None]
+    freqs = x * weights[None, :] * 2 * math.pi
+    return torch.cat((x, freqs.sin(), freqs.cos()), dim=-1)
+
+
 def time_mlp(sd: SD, p: str, t: torch.Tensor, dim: int, theta: float) -> torch.Tensor:
     """DD/denoising_diffusion.py:280-285: sinusoid -> Linear -> GELU(erf) -> Linear."""
-    e = sinusoidal_pos_emb(t, dim, theta)
+    if p + "time_mlp.0.weights" in sd:  # random / learned sinusoidal embedding (:271-273)
+        e = learned_sinusoidal_pos_emb(t, sd[p + "time_mlp.0.weights"])
+    else:
+        e = sinusoidal_pos_emb(t, dim, theta)
     e = F.linear(e, sd[p + "time_mlp.1.weight"], sd[p + "time_mlp.1.bias"])
     e = F.gelu(e)
     return F.linear(e, sd[p + "time_mlp.3.weight"], sd[p + "time_mlp.3.bias"])

@@ -89,6 +89,12 @@ def golden_train():
 
 
 @pytest.fixture(scope="session")
+def golden_r4():
+    """Round-4 fixtures from the reference (tests/golden/make_golden_r4.py): the learned / random sinusoidal U-Net forward."""
+    return load_golden("r4.pt")
+
+
+@pytest.fixture(scope="session")
 def golden_hybrid():
     """The hybrid (KL) loss branch of p_losses and the ddpm=False loss weights, from the reference
     (tests/golden/make_golden_hybrid.py)."""

@@ -47,6 +47,25 @@ def test_unet_rejects_bad_size(small_unet):
         small_unet(torch.zeros(1, 3, 15, 16), torch.zeros(1, dtype=torch.long))
 
 
+@pytest.mark.parametrize("key", ["learned", "random", "learned_dim8"])
+def test_learned_sinusoidal_unet_forward(golden_r4, key):
+    """Unet(learned_sinusoidal_cond=True / random_fourier_features=True) (denoising_diffusion.py:86-101, :271-278: the time
+    embedding is cat(t, sin(t w 2 pi), cos(t w 2 pi)) with the parameter time_mlp.0.weights) against the reference's own
+    forward.  Forward only: the reference's DenoisingDiffusion refuses such a U-Net (:456-457), and so do ours and train()."""
+    b = golden_r4["unet_" + key]
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3, **b["kw"])
+    u = dm.Unet(dim=32, dim_mults=(1, 2), channels=3, device=DEV, **b["kw"])
+    u.load_state_dict(dm.synth_state_dict(dm.unet_param_spec(cfg), salt=51))
+    err = rel_l2(u(b["x"].to(DEV), b["t"].to(DEV)).cpu(), b["y"])
+    print("learned sinusoidal", key, err)
+    assert err < FWD_TOL
+    assert u.random_or_learned_sinusoidal_cond
+    with pytest.raises(AssertionError):
+        dm.DenoisingDiffusion(u, image_size=16)
+    with pytest.raises(RuntimeError):
+        u.train()
+
+
 def test_unet_text_variants(golden_blocks):
     g = golden_blocks
     u = build_unet(salt=2, dim=32, dim_mults=(1, 2), channels=3, text_condition=True, use_cross_attn=True)

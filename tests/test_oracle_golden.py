@@ -480,6 +480,19 @@ def test_loss_weight_buffers(golden_hybrid):
         assert torch.equal(got["loss_weight"], want), key
 
 
+@pytest.mark.parametrize("key", ["learned", "random", "learned_dim8"])
+def test_learned_sinusoidal_unet_forward(golden_r4, key):
+    """Unet(learned_sinusoidal_cond / random_fourier_features) forward (DD/denoising_diffusion.py:86-101) in the oracle
+    against the reference's own output; the reference's DenoisingDiffusion refuses such a U-Net (:456-457)."""
+    b = golden_r4["unet_" + key]
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2), channels=3, **b["kw"])
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=51)
+    assert "time_mlp.0.weights" in sd and b["diffusion_refuses"]
+    with torch.inference_mode():
+        y = uo.unet_forward(sd, cfg, b["x"], b["t"])
+    assert rel_l2(y, b["y"]) < 1e-5
+
+
 def test_prediction_helpers_and_guided_ddim(golden_guided):
     """oracle/sampler_oracle.py: model_predictions / p_mean_variance / q_posterior with a batch of different timesteps for the
     three objectives, and ddim_sample_guided (with and without a guide), against the reference's own outputs."""
