@@ -408,13 +408,23 @@ int launch_pointwise_small_dgrad(const float* dy_nchw, const float* w_oc, float*
 int launch_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, float* dw, int R, int I, int O, int act_in,
                         int accumulate, hipStream_t s);
 int launch_mlp_rows_wgrad(const float* dy, int ldy, const float* x, int ldx, float* const* dw_rows, float* const* db_rows,
-                          int R, int I, int O, int accumulate, hipStream_t s);
+                          int R, int I, int O, int accumulate, hipStream_t s, const float* x_act = nullptr);
 int launch_lincomb(const float* x, const float* y, const float* coef_dev, float* out, int B, int64_t per_sample, int mode,
                    int clamp, hipStream_t s);
 int launch_mask_mix(const float* a, const float* b, const float* mask, float* out, int64_t n, hipStream_t s);
 int launch_offset_noise(float* noise, const float* offset, float strength, int BC, int HW, hipStream_t s);
 int launch_cdist(const float* x, const float* y, float* out, int n, int m, int64_t D, hipStream_t s);
 size_t linear_dgrad_ws_floats(int R, int I, int O);
+// small_gemm.hip: the batch-row Linear layers of the training step as MFMA GEMMs
+bool rows_gemm_nt_ok(int R, int I, int O, int ldx);
+int launch_rows_gemm_nt(const float* x, int ldx, const float* W, const float* bias, float* y, int ldy, int R, int I, int O,
+                        hipStream_t s);
+bool rows_gemm_nn_ok(int R, int I, int O, int ldy, int ldx);
+int rows_gemm_nn_shares(int O);
+int launch_rows_gemm_nn(const float* dy, int ldy, const float* W, float* dx_or_ws, int ldx, int R, int I, int O, hipStream_t s);
+bool rows_gemm_tn_ok(int R, int I, int O, int ldy, int ldx);
+int launch_rows_gemm_tn(const float* dy, int ldy, const float* x, int ldx, float* const* dw_rows, float* const* db_rows, float* dw,
+                        int ldw, float* db, int R, int I, int O, int accumulate, hipStream_t s);
 int launch_linear_dgrad(const float* dy, int ldy, const float* W, float* dx, int ldx, int R, int I, int O, float* ws,
                         hipStream_t s);
 // per-sample scalars of the training step, gathered on the host as `extract` does: [0] sqrt_alphas_cumprod[t],

@@ -290,6 +290,9 @@ __global__ __launch_bounds__(256) void linear_rows8_kernel(const float* __restri
 int launch_linear_rows(const float* x, int ldx, const float* W, const float* bias, float* y, int ldy, int R, int I,
                        int O, int act_in, int act_out, hipStream_t s) {
     if (R == 0 || O == 0) return 0;
+    static const bool no_mfma = std::getenv("DM_NO_SMALL_GEMM") != nullptr;
+    if (!no_mfma && act_in == 0 && act_out == 0 && rows_gemm_nt_ok(R, I, O, ldx))
+        return launch_rows_gemm_nt(x, ldx, W, bias, y, ldy, R, I, O, s);  // a batch of rows: MFMA GEMM (small_gemm.hip)
     if (R >= 8) {
         hipLaunchKernelGGL(linear_rows8_kernel, dim3((O + 3) / 4, (R + 7) / 8), dim3(256), 0, s, x, ldx, W, bias, y, ldy, R, I, O,
                            act_in, act_out);

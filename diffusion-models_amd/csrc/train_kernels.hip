@@ -807,6 +807,9 @@ __global__ void linear_wgrad_kernel(const float* __restrict__ dy, int ldy, const
 }
 int launch_linear_wgrad(const float* dy, int ldy, const float* x, int ldx, float* dw, int R, int I, int O, int act_in,
                         int accumulate, hipStream_t s) {
+    static const bool no_mfma = std::getenv("DM_NO_SMALL_GEMM") != nullptr;
+    if (!no_mfma && act_in == 0 && rows_gemm_tn_ok(R, I, O, ldy, ldx))
+        return launch_rows_gemm_tn(dy, ldy, x, ldx, nullptr, nullptr, dw, I, nullptr, R, I, O, accumulate, s);
     hipLaunchKernelGGL(linear_wgrad_kernel, dim3((I + 63) / 64, O), dim3(64), 0, s, dy, ldy, x, ldx, dw, R, I, O, act_in,
                        accumulate);
     DM_CHECK_HIP(hipGetLastError());
@@ -861,7 +864,10 @@ __global__ __launch_bounds__(64) void mlp_rows_wgrad_kernel(const float* __restr
     }
 }
 int launch_mlp_rows_wgrad(const float* dy, int ldy, const float* x, int ldx, float* const* dw_rows, float* const* db_rows,
-                          int R, int I, int O, int accumulate, hipStream_t s) {
+                          int R, int I, int O, int accumulate, hipStream_t s, const float* x_act) {
+    static const bool no_mfma = std::getenv("DM_NO_SMALL_GEMM") != nullptr;
+    if (!no_mfma && x_act && rows_gemm_tn_ok(R, I, O, ldy, ldx))  // x_act = SiLU(x), formed once by the forward pass
+        return launch_rows_gemm_tn(dy, ldy, x_act, ldx, dw_rows, db_rows, nullptr, 0, nullptr, R, I, O, accumulate, s);
     hipLaunchKernelGGL(mlp_rows_wgrad_kernel, dim3((I + 63) / 64, (O + MLP_ROWS - 1) / MLP_ROWS), dim3(64), 0, s, dy, ldy, x, ldx,
                        dw_rows, db_rows, R, I, O, accumulate);
     DM_CHECK_HIP(hipGetLastError());
@@ -920,12 +926,24 @@ __global__ void linear_dgrad_sum_kernel(const float* __restrict__ part, int shar
 }
 static int linear_dgrad_shares(int I, int O) { return O >= 2048 ? 16 : 1; }
 size_t linear_dgrad_ws_floats(int R, int I, int O) {
-    const int sh = linear_dgrad_shares(I, O);
+    const int sh = std::max(linear_dgrad_shares(I, O), rows_gemm_nn_shares(O));
     return sh > 1 ? (size_t)sh * R * I : 0;
 }
 // ws: linear_dgrad_ws_floats(R, I, O) floats (may be nullptr when that is 0, or to force the one-pass form)
 int launch_linear_dgrad(const float* dy, int ldy, const float* W, float* dx, int ldx, int R, int I, int O, float* ws,
                         hipStream_t s) {
+    static const bool no_mfma = std::getenv("DM_NO_SMALL_GEMM") != nullptr;  // A/B: the VALU kernels below
+    if (!no_mfma && rows_gemm_nn_ok(R, I, O, ldy, ldx)) {  // batch rows as an MFMA GEMM (small_gemm.hip)
+        const int nsh = rows_gemm_nn_shares(O);
+        if (nsh == 1) return launch_rows_gemm_nn(dy, ldy, W, dx, ldx, R, I, O, s);
+        if (ws && ldx == I) {
+            if (launch_rows_gemm_nn(dy, ldy, W, ws, ldx, R, I, O, s)) return 1;
+            const int64_t n = (int64_t)R * I;
+            hipLaunchKernelGGL(linear_dgrad_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, nsh, n, dx);
+            DM_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     const int sh = (ws && ldx == I) ? linear_dgrad_shares(I, O) : 1;
     const int o_share = (O + sh - 1) / sh;
     const dim3 grid((I + 63) / 64, (R + LD_ROWS - 1) / LD_ROWS, sh);

@@ -1,7 +1,8 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python3 tools/conv_stamps.py --batch 256 2> gpurun_out/r4_conv_stamps_b256.txt > /dev/null || true
-grep -c STAMPS gpurun_out/r4_conv_stamps_b256.txt
-python3 tools/layer_report.py --batch 256 --size 32 --bounds > gpurun_out/r4_layer_report_b256_32.txt 2>&1
-python3 tools/layer_report.py --batch 8 --size 64 --bounds > gpurun_out/r4_layer_report_b8_64.txt 2>&1
-tail -12 gpurun_out/r4_layer_report_b8_64.txt
+python -m pytest tests/test_hip_train.py tests/test_hip_train_ops.py tests/test_hip_train_bench_shape.py tests/test_hip_model.py -x -q 2>&1 | grep -v "amdgpu.ids" | tail -3
+for v in 0 1; do
+if [ $v = 1 ]; then export DM_NO_SMALL_GEMM=1; fi
+python3 tools/train_time.py --batch 64 --steps 30 --dropout 0.1 | tail -1
+python3 tools/train_time.py --batch 16 --steps 30 | tail -1
+done
