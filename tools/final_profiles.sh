@@ -10,7 +10,6 @@ echo "== rocprof stats (ddpm1000, 1 call)"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -o s -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-other-configs --no-train > gpurun_out/${tag}_stats.log 2>&1
 rm -f gpurun_out/${tag}_stats/*kernel_trace.csv; ls gpurun_out/${tag}_stats
 cp gpurun_out/${tag}_stats/s_kernel_stats.csv profiles/${tag}_kernel_stats.csv   # bench.py reads the family shares from it
-echo "== bench"; python3 bench.py --steps 3 --warmup 1 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 600 gpurun_out/${tag}_bench.json
 echo "== configs"; python3 tools/config_bench.py > gpurun_out/${tag}_other_configs.txt 2>&1; tail -12 gpurun_out/${tag}_other_configs.txt
 echo "== b8 stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_b8 -o s -- python3 tools/step_time.py --batch 8 --size 64 > gpurun_out/${tag}_b8.log 2>&1
@@ -26,3 +25,4 @@ bash tools/pmc_run.sh ${tag}_trainpmc
 python3 tools/pmc_summary.py gpurun_out/${tag}_trainpmc > gpurun_out/${tag}_train_pmc.json
 cp gpurun_out/${tag}_train_pmc.json profiles/${tag}_train_pmc.json
 unset PMC_ITERS PMC_CMD
+echo "== bench"; python3 bench.py --steps 3 --warmup 1 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 600 gpurun_out/${tag}_bench.json
