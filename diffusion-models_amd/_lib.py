@@ -30,7 +30,7 @@ EXPORTS = (
     "dm_op_attention", "dm_op_sampler_update",
     "dm_conv_create", "dm_conv_destroy", "dm_conv_forward", "dm_op_pool2d", "dm_op_resize_bilinear",
     "dm_op_copy_channels_nhwc", "dm_op_global_avgpool", "dm_op_linear",
-    "dm_unet_train_enable", "dm_unet_grad_floats", "dm_unet_grads_flat", "dm_unet_train_buckets", "dm_unet_train_bucket", "dm_unet_get_grad", "dm_unet_loss_backward", "dm_unet_loss_backward_ex", "dm_op_q_sample",
+    "dm_unet_train_enable", "dm_unet_grad_floats", "dm_unet_grads_flat", "dm_unet_train_buckets", "dm_unet_train_bucket", "dm_unet_get_grad", "dm_unet_loss_backward", "dm_unet_loss_backward_ex", "dm_op_q_sample", "dm_op_linear_bwd",
     "dm_op_offset_noise", "dm_op_cdist", "dm_op_gather_rows", "dm_op_lincomb", "dm_op_mask_mix",
     "dm_unet_optimizer_step", "dm_unet_train_scalar", "dm_unet_ema_update", "dm_unet_get_param", "dm_unet_set_train_tensor", "dm_unet_adam_step",
     "dm_unet_train_sync", "dm_unet_check_device_pack",
@@ -174,6 +174,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.dm_op_mask_mix.argtypes = [fp, fp, fp, fp, i64, vp]
     lib.dm_op_cdist.argtypes = [fp, fp, fp, i32, i32, i64, vp]
     lib.dm_op_gather_rows.argtypes = [fp, C.POINTER(i64), fp, i32, i64, vp]
+    lib.dm_op_linear_bwd.argtypes = [fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, vp]
     lib.dm_op_conv2d_bwd.argtypes = [fp, i32, fp, i32, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.dm_op_downsample_bwd.argtypes = [fp, i32, fp, fp, fp, fp, fp, i32, i32, i32, i32, vp]
     lib.dm_op_block_bwd.argtypes = [fp, i32] + [fp] * 12 + [i32, i32, i32, i32, vp]

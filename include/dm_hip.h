@@ -451,6 +451,10 @@ int dm_op_block_bwd(const float* x, int Cin, const float* weight, const float* b
                     const float* shift, const float* dy, float* dx, float* d_weight, float* d_bias, float* d_g,
                     float* d_scale, float* d_shift, int B, int H, int W, int Cout, void* stream);
 /* RMSNorm backward (:66-67) */
+/* nn.Linear backward on its own (time_mlp, ResnetBlock.mlp; DD/denoising_diffusion.py:127-130, :280-285): dx (R, I) = dy W,
+ * d_weight (O, I) (+)= dy^T x, d_bias (O) (+)= column sums of dy; any of the three outputs may be NULL */
+int dm_op_linear_bwd(const float* x, const float* weight, const float* dy, float* dx, float* d_weight, float* d_bias, int R,
+                     int I, int O, int accumulate, void* stream);
 int dm_op_rmsnorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* dg, int B, int C, int H, int W,
                       void* stream);
 /* LinearAttention / Attention backward (:173-193, :215-229) */

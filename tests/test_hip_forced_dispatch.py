@@ -24,6 +24,21 @@ def test_small_shapes_through_the_large_shape_kernels():
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
 
 
+def test_operator_cases_on_the_small_tile_kernel_forms():
+    """Round 4: the 1x1 GEMM kernel with 16-pixel wave tiles (RT = 1) and the F(2x2) Winograd kernel with 32-cout workgroups
+    (Q = 1) are chosen for grids that leave CUs idle; with the thresholds raised they take EVERY eligible shape of the operator
+    tests (ragged pixel blocks, concat inputs, K splits, residual / partial epilogues), at the unchanged tolerances.  Also the
+    other order of the 1x1 plan (K splits before smaller tiles) and RT = 2."""
+    for extra in (dict(DM_PW_RT_TARGET_WGS="1000000", DM_WINO_Q_TARGET_WGS="1000000"),
+                  dict(DM_PW_RT_TARGET_WGS="1000000", DM_PW_RT_MIN="2", DM_PW_RT_FIRST="0")):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_ops.py"),
+                            os.path.join(ROOT, "tests", "test_hip_train_ops.py"), "-q", "-x", "-m", "gpu", "-k",
+                            "conv2d or block or attention or downsample", "-p", "no:cacheprovider"],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
 MODEL_CASES = "test_unet_full_forward or test_unet_latent_and_text_full or test_full_samplers or test_unet_text_variants"
 
 
@@ -43,6 +58,11 @@ def test_model_goldens_with_the_alternative_kernels():
     landings, no fused attention kernels, the folded instead of the 9-multiply upsample conv."""
     _run_models(dict(DM_NO_WINO4="1", DM_NO_PW="1", DM_NO_CROSS1="1", DM_NO_RES_MERGE="1", DM_NO_UPWINO="1",
                      DM_NO_FUSED_LINATTN="1", DM_NO_ATTN16="1", DM_NO_INIT7="1"))
+
+
+def test_model_goldens_on_the_small_tile_kernel_forms():
+    """The model-level goldens with the small-tile forms of the 1x1 and F(2x2) kernels forced everywhere (see above)."""
+    _run_models(dict(DM_PW_RT_TARGET_WGS="1000000", DM_WINO_Q_TARGET_WGS="1000000"))
 
 
 def test_model_goldens_with_the_forked_step():

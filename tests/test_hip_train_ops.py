@@ -256,3 +256,35 @@ def test_conv_backward_random_shapes():
         if C1:
             errs["dx1"] = rel_l2(d1.cpu(), x1.grad)
         assert max(errs.values()) < TOL, ((B, C0, C1, H, W, Cout, k, up2), errs)
+
+
+@pytest.mark.parametrize("R,I,O", [(64, 256, 8064), (16, 64, 256), (20, 256, 256), (100, 512, 64), (7, 256, 128), (64, 48, 80)])
+def test_linear_forward_and_backward_vs_torch(R, I, O):
+    """The batch-row nn.Linear layers of the training step (time_mlp, the concatenated ResnetBlock.mlp matrix) through
+    dm_op_linear / dm_op_linear_bwd: MFMA GEMMs (small_gemm.hip) where the shapes allow -- 16-byte rows, I % 16 / 64, O % 16 / 64,
+    ragged row counts -- and the VALU kernels otherwise ((7, ...) rows, (.., 48, 80)); against torch on the CPU in double."""
+    import ctypes as C
+
+    from diffusion_models_amd import _lib
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(R * 1000 + I + O)
+    x = torch.randn((R, I), generator=g)
+    w = torch.randn((O, I), generator=g) / I ** 0.5
+    b = torch.randn((O,), generator=g)
+    dy = torch.randn((R, O), generator=g)
+    xd, wd, bd, dyd = (t.to(DEV) for t in (x, w, b, dy))
+    y = torch.empty((R, O), device=DEV)
+    _lib.check(lib.dm_op_linear(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), R, I, O, None))
+    want = x.double() @ w.double().T + b.double()
+    assert rel_l2(y.cpu(), want.float()) < 2e-6
+    dx = torch.empty((R, I), device=DEV)
+    dw = torch.full((O, I), 0.5, device=DEV)
+    db = torch.full((O,), -0.25, device=DEV)
+    for acc in (0, 1):  # overwrite, then accumulate on top of the first result
+        _lib.check(lib.dm_op_linear_bwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(dyd), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
+                                        R, I, O, acc, None))
+        k = acc + 1
+        assert rel_l2(dx.cpu(), (dy.double() @ w.double()).float()) < 2e-6
+        assert rel_l2(dw.cpu(), (k * (dy.double().T @ x.double())).float()) < 2e-6
+        assert rel_l2(db.cpu(), (k * dy.double().sum(0)).float()) < 2e-6
