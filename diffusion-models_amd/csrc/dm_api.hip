@@ -6,6 +6,7 @@
 #include "dm_common.h"
 
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>

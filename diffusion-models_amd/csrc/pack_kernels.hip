@@ -221,13 +221,40 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const PackJob j = jobs[lo];
+    if (j.kind == PJ_ROT) {
+        // 16 x 16 (cout, cin) pairs per workgroup through LDS: read with the lanes along cin (the source's inner index: 16 x
+        // K^2 contiguous floats per cout), written with the lanes along cout (the destination's): both sides move runs of
+        // 16 K^2 floats, where one thread per destination element read 36-byte pieces Cin * 36 bytes apart
+        __shared__ float tile[256 * 9];
+        const int K = j.a, KK = K * K, c_lo = j.b;
+        const int c_n = (int)(j.n / ((int64_t)j.Cout * KK));
+        const int tiles_c = (c_n + 15) / 16;
+        const int lb = (int)(blockIdx.x - j.first_block);
+        const int c0 = (lb % tiles_c) * 16, o0 = (lb / tiles_c) * 16;
+        const int lo16 = threadIdx.x & 15, hi16 = threadIdx.x >> 4;
+        {
+            const int o = o0 + hi16, c = c0 + lo16;
+            if (o < j.Cout && c < c_n) {
+                const float* sp = j.src + ((size_t)o * j.Cin + c_lo + c) * KK;
+                for (int t = 0; t < KK; ++t) tile[(hi16 * 16 + lo16) * KK + t] = sp[t];
+            }
+        }
+        __syncthreads();
+        {
+            const int c = c0 + hi16, o = o0 + lo16;
+            if (o < j.Cout && c < c_n) {
+                float* dp = j.dst + ((size_t)c * j.Cout + o) * KK;
+                for (int t = 0; t < KK; ++t) dp[t] = tile[(lo16 * 16 + hi16) * KK + (KK - 1 - t)];  // rotated by 180 degrees
+            }
+        }
+        return;
+    }
     const int64_t t = (int64_t)(blockIdx.x - j.first_block) * 256 + threadIdx.x;
     if (t >= j.n) return;
     // The element functions take (cout, cin) as i = cout * Cin + cin.  Here consecutive threads take the elements that are
     // neighbours in the PACKED layout, so every plane of a Winograd pack leaves as 256-byte runs (one thread per OIHW
     // element in OIHW order wrote 32-byte pieces).
     switch (j.kind) {
-        case PJ_ROT: rot_transpose_elem(j.src, j.dst, j.Cout, j.Cin, j.a, j.b, t); break;
         case PJ_S2D_T: s2d_transpose_elem(j.src, j.dst, j.Cout, j.Cin, t); break;
         case PJ_WINO: {  // [chunk of 8][xi][Cout][8]
             const int cc = (int)(t & 7), co = (int)((t >> 3) % j.Cout), chunk = (int)((t >> 3) / j.Cout);
@@ -258,7 +285,12 @@ int pack_jobs_prefix(std::vector<PackJob>& jobs) {
     int first = 0;
     for (PackJob& j : jobs) {
         j.first_block = first;
-        first += (int)((j.n + 255) / 256);
+        if (j.kind == PJ_ROT) {  // one workgroup per 16 x 16 (cout, cin) pairs (pack_jobs_kernel)
+            const long long c_n = j.n / ((long long)j.Cout * j.a * j.a);
+            first += (int)(((c_n + 15) / 16) * ((j.Cout + 15) / 16));
+        } else {
+            first += (int)((j.n + 255) / 256);
+        }
     }
     return first;
 }
