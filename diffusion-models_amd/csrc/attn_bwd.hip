@@ -296,6 +296,11 @@ struct AttnBwdParams {
     float scale;
 };
 
+// CACHE (short sequences: nq * (nk + n_mem) <= 4096, e.g. the 16 tokens + 4 memory rows of the 32x32 U-Net's bottleneck): the
+// scores q_i . k_j and dP_ij are formed ONCE and kept in LDS -- the plain form recomputes the 32-wide dot products in each of
+// its three passes over the keys and again per (key, query) in the second phase, and with one thread per query that serial
+// chain IS the kernel's time (42 us at any batch for 16 queries); same summation order within every dot product.
+template <bool CACHE>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int nkt = p.nk + p.n_mem, n = p.nq;
@@ -306,6 +311,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdParams p) {
     float* rm = Ds + n * (BDH + 1);       // [n] row max
     float* rl = rm + n;                   // [n] 1 / row sum
     float* rD = rl + n;                   // [n] D_i
+    float* Pc = rD + n;                   // CACHE: [n][nkt] scores -> exp -> P_ij
+    float* Sc = Pc + (CACHE ? n * nkt : 0);  // CACHE: [n][nkt] dP_ij -> dS_ij
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int hid = p.heads * BDH;
     const float scale = p.scale;
@@ -336,40 +343,71 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdParams p) {
             q[d] = Qs[i * (BDH + 1) + d];
             dov[d] = Ds[i * (BDH + 1) + d];
         }
-        float m = -INFINITY;
-        for (int j = 0; j < nkt; ++j) {
-            float sc = 0.f;
-#pragma unroll
-            for (int d = 0; d < BDH; ++d) sc += q[d] * Ks[j * (BDH + 1) + d];
-            m = fmaxf(m, sc * scale);
-        }
-        float l = 0.f, D = 0.f;
-        for (int j = 0; j < nkt; ++j) {
-            float sc = 0.f, dp = 0.f;
-#pragma unroll
-            for (int d = 0; d < BDH; ++d) {
-                sc += q[d] * Ks[j * (BDH + 1) + d];
-                dp += dov[d] * Vs[j * (BDH + 1) + d];
-            }
-            const float e = __expf(sc * scale - m);
-            l += e;
-            D += e * dp;
-        }
-        const float linv = 1.0f / l;
-        D *= linv;
+        float m = -INFINITY, l = 0.f, D = 0.f, linv;
         float dq[BDH];
 #pragma unroll
         for (int d = 0; d < BDH; ++d) dq[d] = 0.f;
-        for (int j = 0; j < nkt; ++j) {
-            float sc = 0.f, dp = 0.f;
+        if constexpr (CACHE) {
+            float* Pi = Pc + i * nkt;
+            float* Si = Sc + i * nkt;
+            for (int j = 0; j < nkt; ++j) {
+                float sc = 0.f, dp = 0.f;
 #pragma unroll
-            for (int d = 0; d < BDH; ++d) {
-                sc += q[d] * Ks[j * (BDH + 1) + d];
-                dp += dov[d] * Vs[j * (BDH + 1) + d];
+                for (int d = 0; d < BDH; ++d) {
+                    sc += q[d] * Ks[j * (BDH + 1) + d];
+                    dp += dov[d] * Vs[j * (BDH + 1) + d];
+                }
+                Pi[j] = sc * scale;
+                Si[j] = dp;
+                m = fmaxf(m, sc * scale);
             }
-            const float dS = __expf(sc * scale - m) * linv * (dp - D);
+            for (int j = 0; j < nkt; ++j) {
+                const float e = __expf(Pi[j] - m);
+                Pi[j] = e;
+                l += e;
+                D += e * Si[j];
+            }
+            linv = 1.0f / l;
+            D *= linv;
+            for (int j = 0; j < nkt; ++j) {
+                const float P = Pi[j] * linv;
+                const float dS = P * (Si[j] - D);
+                Pi[j] = P;
+                Si[j] = dS;
 #pragma unroll
-            for (int d = 0; d < BDH; ++d) dq[d] += dS * Ks[j * (BDH + 1) + d];
+                for (int d = 0; d < BDH; ++d) dq[d] += dS * Ks[j * (BDH + 1) + d];
+            }
+        } else {
+            for (int j = 0; j < nkt; ++j) {
+                float sc = 0.f;
+#pragma unroll
+                for (int d = 0; d < BDH; ++d) sc += q[d] * Ks[j * (BDH + 1) + d];
+                m = fmaxf(m, sc * scale);
+            }
+            for (int j = 0; j < nkt; ++j) {
+                float sc = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < BDH; ++d) {
+                    sc += q[d] * Ks[j * (BDH + 1) + d];
+                    dp += dov[d] * Vs[j * (BDH + 1) + d];
+                }
+                const float e = __expf(sc * scale - m);
+                l += e;
+                D += e * dp;
+            }
+            linv = 1.0f / l;
+            D *= linv;
+            for (int j = 0; j < nkt; ++j) {
+                float sc = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < BDH; ++d) {
+                    sc += q[d] * Ks[j * (BDH + 1) + d];
+                    dp += dov[d] * Vs[j * (BDH + 1) + d];
+                }
+                const float dS = __expf(sc * scale - m) * linv * (dp - D);
+#pragma unroll
+                for (int d = 0; d < BDH; ++d) dq[d] += dS * Ks[j * (BDH + 1) + d];
+            }
         }
         rm[i] = m;
         rl[i] = linv;
@@ -389,14 +427,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdParams p) {
             dv[d] = 0.f;
         }
         for (int i = 0; i < n; ++i) {
-            float sc = 0.f, dp = 0.f;
+            float P, dS;
+            if constexpr (CACHE) {
+                P = Pc[i * nkt + j];
+                dS = Sc[i * nkt + j];
+            } else {
+                float sc = 0.f, dp = 0.f;
 #pragma unroll
-            for (int d = 0; d < BDH; ++d) {
-                sc += Qs[i * (BDH + 1) + d] * kk[d];
-                dp += Ds[i * (BDH + 1) + d] * vv[d];
+                for (int d = 0; d < BDH; ++d) {
+                    sc += Qs[i * (BDH + 1) + d] * kk[d];
+                    dp += Ds[i * (BDH + 1) + d] * vv[d];
+                }
+                P = __expf(sc * scale - rm[i]) * rl[i];
+                dS = P * (dp - rD[i]);
             }
-            const float P = __expf(sc * scale - rm[i]) * rl[i];
-            const float dS = P * (dp - rD[i]);
 #pragma unroll
             for (int d = 0; d < BDH; ++d) {
                 dk[d] += dS * Qs[i * (BDH + 1) + d];
@@ -562,8 +606,13 @@ __global__ __launch_bounds__(64) void attn_bwd_kv_tiled_kernel(const AttnBwdPara
     }
 }
 
+static bool attn_bwd_cached(int nq, int nk, int n_mem) {
+    static const bool off = std::getenv("DM_ATTN_BWD_NO_CACHE") != nullptr;  // A/B, and the tests' other path
+    return !off && (size_t)nq * (nk + n_mem) <= 4096;
+}
 static size_t attn_bwd_lds_bytes(int nq, int nk, int n_mem) {
-    return ((size_t)(2 * (nk + n_mem) + 2 * nq) * (BDH + 1) + 3 * nq) * sizeof(float);
+    const size_t cache = attn_bwd_cached(nq, nk, n_mem) ? (size_t)2 * nq * (nk + n_mem) : 0;
+    return ((size_t)(2 * (nk + n_mem) + 2 * nq) * (BDH + 1) + 3 * nq + cache) * sizeof(float);
 }
 static bool attn_bwd_tiled(int nq, int nk, int n_mem) {
     static const bool force = std::getenv("DM_ATTN_BWD_TILED") != nullptr;  // tests: the tiled form on small shapes too
@@ -585,9 +634,16 @@ static int launch_attn_bwd(const AttnBwdParams& p, int B, float* ws, hipStream_t
         DM_CHECK_HIP(hipGetLastError());
         return 0;
     }
+    if (attn_bwd_cached(p.nq, p.nk, p.n_mem)) {
+        static LdsOptIn flagc;
+        if (lds_opt_in(flagc, reinterpret_cast<const void*>(attn_bwd_kernel<true>), 1)) return 1;
+        hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(p.heads, B), dim3(256), lds, s, p);
+        DM_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     static LdsOptIn flag;
-    if (lds_opt_in(flag, reinterpret_cast<const void*>(attn_bwd_kernel), 1)) return 1;
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(p.heads, B), dim3(256), lds, s, p);
+    if (lds_opt_in(flag, reinterpret_cast<const void*>(attn_bwd_kernel<false>), 1)) return 1;
+    hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(p.heads, B), dim3(256), lds, s, p);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -92,13 +92,21 @@ def test_training_goldens_with_one_launch_per_layer():
     """The gradient goldens of the reference's autograd, the three-iteration Adam loop and the checkpoint round trip with the
     per-layer forms of everything the training step batches by default: one weight-gradient launch and one split-K sum per
     layer (no grouped launch, no deferred reductions), the direct 3x3 weight gradient instead of the Winograd-domain one,
-    lazy instead of grouped re-packing."""
-    _run_training(dict(DM_WGRAD_NO_DEFER="1", DM_WGRAD_NO_WINO="1", DM_NO_BATCH_REPACK="1"))
+    lazy instead of grouped re-packing; round 4: separate landing passes, the VALU Linear kernels, the attention backward
+    without its score cache."""
+    _run_training(dict(DM_WGRAD_NO_DEFER="1", DM_WGRAD_NO_WINO="1", DM_NO_BATCH_REPACK="1", DM_TRAIN_NO_LANDING_FUSE="1",
+                       DM_NO_SMALL_GEMM="1", DM_ATTN_BWD_NO_CACHE="1"))
 
 
 def test_attention_backward_tiled_form_on_every_shape():
     """The operator-level attention backward cases and the text-conditional training step (mid_attn + CrossAttention) with the
-    tiled kernels forced on the short sequences the LDS-resident kernel normally takes."""
+    tiled kernels forced on the short sequences the LDS-resident kernel normally takes; and the LDS-resident kernel without
+    its score cache (the form longer sequences take)."""
+    env0 = dict(os.environ, DM_ATTN_BWD_NO_CACHE="1")
+    r0 = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_train_ops.py"), "-q", "-x", "-m",
+                         "gpu", "-k", "test_attention_bwd", "-p", "no:cacheprovider"],
+                        cwd=ROOT, env=env0, capture_output=True, text=True, timeout=600)
+    assert r0.returncode == 0, r0.stdout[-4000:] + r0.stderr[-2000:]
     env = dict(os.environ, DM_ATTN_BWD_TILED="1", DM_ATTN_TILED="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_train_ops.py"),
                         os.path.join(ROOT, "tests", "test_hip_train.py"), "-q", "-x", "-m", "gpu", "-k",

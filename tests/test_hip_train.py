@@ -703,3 +703,20 @@ def test_bucketed_backward_gives_the_same_gradients():
     assert all(float(flat[o:o + n].abs().sum()) > 0 for o, n in spans)
     u.grad_buckets(enable=False)
     assert float(d.p_losses(x_start, t, noise=noise)) == loss_a
+
+
+def test_asynchronous_calls_keep_their_own_timesteps_and_coefficients():
+    """sync=False returns before the GPU has run the call; the per-sample timesteps and schedule coefficients are host data
+    handed over at call time.  Four calls with different (t, noise) enqueued back to back must give the losses the same calls
+    give one at a time."""
+    cfg = UnetConfig(dim=64, dim_mults=(1, 2), channels=3)
+    d = _model(cfg, 42, "pred_noise", 1000)
+    g = torch.Generator().manual_seed(31)
+    x_start = torch.rand((8, 3, 16, 16), generator=g) * 2 - 1
+    ts = [torch.randint(0, 1000, (8,), generator=g) for _ in range(4)]
+    noises = [torch.randn((8, 3, 16, 16), generator=g).to(DEV) for _ in range(4)]
+    xs = x_start.to(DEV)
+    want = [float(d.p_losses(xs, t, noise=n)) for t, n in zip(ts, noises)]
+    got = [d.p_losses(xs, t, noise=n, sync=False) for t, n in zip(ts, noises)]
+    assert all(v.is_cuda for v in got)
+    assert [float(v) for v in got] == want and len(set(want)) == 4
