@@ -39,7 +39,8 @@ using f32x16_t = __attribute__((ext_vector_type(16))) float;
 
 __global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(const float* __restrict__ qkv,
                                                                const float* __restrict__ mem_kv,
-                                                               float* __restrict__ ctx, int n, int heads) {
+                                                               float* __restrict__ ctx, float* __restrict__ kstats,
+                                                               int n, int heads) {
     constexpr int NMEM = 4;
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -114,7 +115,13 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(const float* __re
 #pragma unroll
     for (int e = 0; e < 16; ++e) part[wave][((e & 3) + 8 * (e >> 2) + 4 * half) * DH + c] = acc[e];
     __syncthreads();
-    if (tid < DH) ksum_s[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid < DH) {
+        ksum_s[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        if (kstats) {  // the training tape keeps the column statistics: the backward pass starts from them
+            kstats[(size_t)(b * heads + h) * 2 * DH + tid] = kmax_s[tid];
+            kstats[(size_t)(b * heads + h) * 2 * DH + DH + tid] = ksum_s[tid];
+        }
+    }
     __syncthreads();
     float* cp = ctx + (size_t)(b * heads + h) * DH * DH;
     for (int i = tid; i < DH * DH; i += 256) {
@@ -257,15 +264,24 @@ __global__ void linattn_out_kernel(const float* __restrict__ qkv, const float* _
         *reinterpret_cast<float4*>(op + 4 * i) = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
 }
 
+// the training tape keeps the key statistics unless the VALU context kernel is forced or DM_LINATTN_NO_KSTATS asks for the
+// recomputing backward (tests/test_hip_forced_dispatch.py)
+bool linattn_keeps_kstats() {
+    static const bool keep = !std::getenv("DM_LINATTN_VALU") && !std::getenv("DM_LINATTN_NO_KSTATS");
+    return keep;
+}
+
 int launch_linear_attention_core(const float* qkv, const float* mem_kv, float* ctx_ws, float* out, int B, int n,
-                                 int heads, int dh, hipStream_t s) {
+                                 int heads, int dh, hipStream_t s, float* kstats) {
     DM_REQUIRE(dh == DH, "LinearAttention kernel is specialised for dim_head == 32");
     DM_REQUIRE(heads >= 1 && heads <= 16, "LinearAttention kernel supports 1..16 heads");
     static const bool valu_ctx = std::getenv("DM_LINATTN_VALU") != nullptr;
-    if (valu_ctx)
+    if (valu_ctx) {
+        DM_REQUIRE(!kstats, "DM_LINATTN_VALU: the VALU context kernel does not keep the key statistics");
         hipLaunchKernelGGL(linattn_ctx_kernel, dim3(heads, B), dim3(256), 0, s, qkv, mem_kv, ctx_ws, n, heads, 4);
-    else
-        hipLaunchKernelGGL(linattn_ctx_mfma_kernel, dim3(heads, B), dim3(256), 0, s, qkv, mem_kv, ctx_ws, n, heads);
+    } else
+        hipLaunchKernelGGL(linattn_ctx_mfma_kernel, dim3(heads, B), dim3(256), 0, s, qkv, mem_kv, ctx_ws, kstats, n,
+                           heads);
     DM_CHECK_HIP(hipGetLastError());
     size_t lds = (size_t)heads * DH * DH * sizeof(float);
     hipLaunchKernelGGL(linattn_out_kernel, dim3((n + 63) / 64, B), dim3(64 * heads), lds, s, qkv, ctx_ws, out, n,

@@ -117,7 +117,8 @@ __global__ __launch_bounds__(64) void linattn_bwd_q_kernel(const float* __restri
 __global__ __launch_bounds__(256) void linattn_bwd_stats_kernel(const float* __restrict__ qkv, const float* __restrict__ mem_kv,
                                                                 const float* __restrict__ ctx, float* __restrict__ dctx_part,
                                                                 int nblk, float* __restrict__ stats,
-                                                                float* __restrict__ dmem_part, int n, int heads) {
+                                                                float* __restrict__ dmem_part,
+                                                                const float* __restrict__ kstats, int n, int heads) {
     __shared__ float dctx[BDH][BDH + 1];
     __shared__ float kmax[BDH], kinv[BDH], S[BDH];
     __shared__ float red[8][BDH];
@@ -131,43 +132,55 @@ __global__ __launch_bounds__(256) void linattn_bwd_stats_kernel(const float* __r
         dctx[i >> 5][i & 31] = s;
         dctx_part[((size_t)b * nblk * heads + h) * BDH * BDH + i] = s;
     }
-    const int d = tid & 31, part = tid >> 5;
-    float m = part < NMEM ? mk[d * NMEM + part] : -INFINITY;
-    {
-        int t = part;
-        for (; t + 56 < n; t += 64) {  // 8 independent row loads in flight
-            float kv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) kv[j] = kbase[(size_t)(t + 8 * j) * ld + d];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) m = fmaxf(m, kv[j]);
+    // kstats (max and sum over tokens of exp(k - max), per column) as the forward context kernel left them on the tape; without
+    // them (kstats == nullptr) the two passes over the n key rows are redone here, 8 lanes deep per column
+    if (kstats) {
+        if (tid < BDH) {
+            kmax[tid] = kstats[(size_t)(b * heads + h) * 2 * BDH + tid];
+            red[0][tid] = kstats[(size_t)(b * heads + h) * 2 * BDH + BDH + tid];
+        } else if (tid < 8 * BDH) {
+            red[tid >> 5][tid & 31] = 0.f;
         }
-        for (; t < n; t += 8) m = fmaxf(m, kbase[(size_t)t * ld + d]);
-    }
-    red[part][d] = m;
-    __syncthreads();
-    if (tid < BDH) {
-        float mm = red[0][tid];
-        for (int q = 1; q < 8; ++q) mm = fmaxf(mm, red[q][tid]);
-        kmax[tid] = mm;
-    }
-    __syncthreads();
-    const float km = kmax[d];
-    float s = part < NMEM ? __expf(mk[d * NMEM + part] - km) : 0.f;
-    {
-        int t = part;
-        for (; t + 56 < n; t += 64) {
-            float kv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) kv[j] = kbase[(size_t)(t + 8 * j) * ld + d];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += __expf(kv[j] - km);
+        __syncthreads();
+    } else {
+        const int d = tid & 31, part = tid >> 5;
+        float m = part < NMEM ? mk[d * NMEM + part] : -INFINITY;
+        {
+            int t = part;
+            for (; t + 56 < n; t += 64) {  // 8 independent row loads in flight
+                float kv[8];
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) kv[j] = kbase[(size_t)(t + 8 * j) * ld + d];
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) m = fmaxf(m, kv[j]);
+            }
+            for (; t < n; t += 8) m = fmaxf(m, kbase[(size_t)t * ld + d]);
         }
-        for (; t < n; t += 8) s += __expf(kbase[(size_t)t * ld + d] - km);
+        red[part][d] = m;
+        __syncthreads();
+        if (tid < BDH) {
+            float mm = red[0][tid];
+            for (int q = 1; q < 8; ++q) mm = fmaxf(mm, red[q][tid]);
+            kmax[tid] = mm;
+        }
+        __syncthreads();
+        const float km = kmax[d];
+        float s = part < NMEM ? __expf(mk[d * NMEM + part] - km) : 0.f;
+        {
+            int t = part;
+            for (; t + 56 < n; t += 64) {
+                float kv[8];
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) kv[j] = kbase[(size_t)(t + 8 * j) * ld + d];
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) s += __expf(kv[j] - km);
+            }
+            for (; t < n; t += 8) s += __expf(kbase[(size_t)t * ld + d] - km);
+        }
+        __syncthreads();
+        red[part][d] = s;
+        __syncthreads();
     }
-    __syncthreads();
-    red[part][d] = s;
-    __syncthreads();
     if (tid < BDH) {
         float ss = 0.f;
         for (int q = 0; q < 8; ++q) ss += red[q][tid];
@@ -262,7 +275,8 @@ size_t linattn_bwd_ws_floats(int B, int n, int heads) {
 // qkv (B, n, 3*heads*32), ctx (B, heads, 32, 32) as the forward core left it, dout (B, n, heads*32) -> dqkv (same shape as
 // qkv), dmem_part (B, 2, heads, 32, 4) per-image memory key/value gradients (the caller sums over B)
 int launch_linear_attention_core_bwd(const float* qkv, const float* mem_kv, const float* ctx, const float* dout, float* ws,
-                                     float* dqkv, float* dmem_part, int B, int n, int heads, int dh, hipStream_t s) {
+                                     float* dqkv, float* dmem_part, int B, int n, int heads, int dh, hipStream_t s,
+                                     const float* kstats) {
     DM_REQUIRE(dh == BDH && heads >= 1 && heads <= 16, "linear attention backward: dim_head 32");
     DM_REQUIRE(B <= 65535 && n >= 1, "linear attention backward: batch");
     const int nblk = (n + 63) / 64;
@@ -271,7 +285,7 @@ int launch_linear_attention_core_bwd(const float* qkv, const float* mem_kv, cons
                        1.0f / sqrtf((float)dh));
     DM_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(linattn_bwd_stats_kernel, dim3(heads, B), dim3(256), 0, s, qkv, mem_kv, ctx, ws, nblk, stats, dmem_part,
-                       n, heads);
+                       kstats, n, heads);
     DM_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(linattn_bwd_kv_kernel, dim3(nblk, heads, B), dim3(64), 0, s, qkv, ws, nblk, stats, dqkv, n, heads);
     DM_CHECK_HIP(hipGetLastError());

@@ -287,8 +287,11 @@ int launch_broadcast_rows(const float* src, float* dst, int rows, int n, int ld,
 // Attention cores (attention.hip); qkv is NHWC (B, n, 3*heads*dh) = [q | k | v] per pixel
 // ---------------------------------------------------------------------------------------
 // LinearAttention core: out (B, n, heads*dh)
+bool linattn_keeps_kstats();
 int launch_linear_attention_core(const float* qkv, const float* mem_kv, float* ctx_ws, float* out, int B, int n,
-                                 int heads, int dh, hipStream_t s);
+                                 int heads, int dh, hipStream_t s, float* kstats = nullptr);
+// kstats (optional, B * heads * 64 floats): per (image, head) the column max and the column sum of exp(k - max) the
+// context kernel formed; launch_linear_attention_core_bwd starts from them instead of two more passes over the keys.
 // softmax(q k^T * scale) v with `n_mem` learned key/value rows prepended.
 //   q: rows of length ldq per query token (head h at column h*dh), k/v likewise with ldk
 //   mem_k/mem_v: (heads, n_mem, dh) or nullptr
@@ -467,7 +470,8 @@ int launch_adam_ema(float* p, const float* g, float* m, float* v, float* ema, co
                     float b1, float b2, float eps, int step, float ema_decay, hipStream_t s);
 size_t linattn_bwd_ws_floats(int B, int n, int heads);
 int launch_linear_attention_core_bwd(const float* qkv, const float* mem_kv, const float* ctx, const float* dout, float* ws,
-                                     float* dqkv, float* dmem_part, int B, int n, int heads, int dh, hipStream_t s);
+                                     float* dqkv, float* dmem_part, int B, int n, int heads, int dh, hipStream_t s,
+                                     const float* kstats = nullptr);
 // ws: attn_bwd_ws_floats() floats (row statistics of the tiled form; 0 floats when the sequence fits LDS)
 size_t attn_bwd_ws_floats(int B, int nq, int nk, int n_mem, int heads);
 int launch_attention_core_bwd(const float* qkv, const float* mem_kv, const float* dout, float* dqkv, float* dmem_part, float* ws,
