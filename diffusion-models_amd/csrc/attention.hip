@@ -37,10 +37,14 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // ---------------------------------------------------------------------------------------
 using f32x16_t = __attribute__((ext_vector_type(16))) float;
 
-__global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(const float* __restrict__ qkv,
-                                                               const float* __restrict__ mem_kv,
-                                                               float* __restrict__ ctx, float* __restrict__ kstats,
-                                                               int n, int heads) {
+// NW waves per (image, head): the token loop is a chain of load round trips (8 loads in flight per lane, then 4 MFMAs), so with
+// heads x B workgroups and nothing else to overlap, the kernel's time is one wave's chain; 16 waves on the 1024 tokens of a 32x32
+// stage make that chain 8 rounds instead of 32 (45 -> about 15 us in the B = 64 training step).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void linattn_ctx_mfma_kernel(const float* __restrict__ qkv,
+                                                                   const float* __restrict__ mem_kv,
+                                                                   float* __restrict__ ctx, float* __restrict__ kstats,
+                                                                   int n, int heads) {
     constexpr int NMEM = 4;
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -50,17 +54,28 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(const float* __re
     const float* vb = qkv + (size_t)b * n * ld + 2 * heads * DH + h * DH + c;
     const float* mk = mem_kv + (size_t)h * DH * NMEM;            // [d][j]
     const float* mv = mem_kv + (size_t)(heads + h) * DH * NMEM;  // [e][j]
-    __shared__ float red[4][DH];
+    __shared__ float red[NW][DH];
     __shared__ float kmax_s[DH], ksum_s[DH];
-    __shared__ __attribute__((aligned(16))) float part[4][DH * DH];
+    constexpr int NP = NW > 8 ? NW / 2 : NW;  // 16 waves fold in two rounds: 64 KB of static LDS would not fit with the rest
+    __shared__ __attribute__((aligned(16))) float part[NP][DH * DH];
 
     // tokens of this wave: [t0, t1), visited two at a time (one per lane half)
-    const int per = ((n + 7) / 8) * 2;  // even number of tokens per wave
-    const int t0 = wave * per, t1 = min(n, t0 + per);
+    const int per = ((n + 2 * NW - 1) / (2 * NW)) * 2;  // even number of tokens per wave
+    const int t0 = min(n, wave * per), t1 = min(n, t0 + per);
 
     // pass 1: max over all tokens (incl. memory) of k[.][d]
     float m = -INFINITY;
-    for (int t = t0 + half; t < t1; t += 2) m = fmaxf(m, kb[(size_t)t * ld]);
+    {
+        int t = t0;
+        for (; t + 16 <= t1; t += 16) {
+            float kv[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) kv[s] = kb[(size_t)(t + 2 * s + half) * ld];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) m = fmaxf(m, kv[s]);
+        }
+        for (t += half; t < t1; t += 2) m = fmaxf(m, kb[(size_t)t * ld]);
+    }
     if (wave == 0) {
         m = fmaxf(m, mk[c * NMEM + half]);
         m = fmaxf(m, mk[c * NMEM + 2 + half]);
@@ -68,7 +83,12 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(const float* __re
     m = fmaxf(m, __shfl_xor(m, 32));
     if (half == 0) red[wave][c] = m;
     __syncthreads();
-    if (tid < DH) kmax_s[tid] = fmaxf(fmaxf(red[0][tid], red[1][tid]), fmaxf(red[2][tid], red[3][tid]));
+    if (tid < DH) {
+        float mm = red[0][tid];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) mm = fmaxf(mm, red[w][tid]);
+        kmax_s[tid] = mm;
+    }
     __syncthreads();
     const float kmax = kmax_s[c];
 
@@ -112,21 +132,40 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(const float* __re
     __syncthreads();  // red is reused
     if (half == 0) red[wave][c] = ksum;
     // accumulator element e of lane: row d = (e&3) + 8*(e>>2) + 4*half, column e-index = lane&31
+    if constexpr (NP < NW) {
+        if (wave >= NP) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) part[wave][((e & 3) + 8 * (e >> 2) + 4 * half) * DH + c] = acc[e];
+            for (int e = 0; e < 16; ++e) part[wave - NP][((e & 3) + 8 * (e >> 2) + 4 * half) * DH + c] = acc[e];
+        }
+        __syncthreads();
+        if (wave < NP) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += part[wave][((e & 3) + 8 * (e >> 2) + 4 * half) * DH + c];
+        }
+    }
+    if (wave < NP) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[wave][((e & 3) + 8 * (e >> 2) + 4 * half) * DH + c] = acc[e];
+    }
     __syncthreads();
     if (tid < DH) {
-        ksum_s[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        float ss = red[0][tid];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) ss += red[w][tid];
+        ksum_s[tid] = ss;
         if (kstats) {  // the training tape keeps the column statistics: the backward pass starts from them
             kstats[(size_t)(b * heads + h) * 2 * DH + tid] = kmax_s[tid];
-            kstats[(size_t)(b * heads + h) * 2 * DH + DH + tid] = ksum_s[tid];
+            kstats[(size_t)(b * heads + h) * 2 * DH + DH + tid] = ss;
         }
     }
     __syncthreads();
     float* cp = ctx + (size_t)(b * heads + h) * DH * DH;
-    for (int i = tid; i < DH * DH; i += 256) {
+    for (int i = tid; i < DH * DH; i += 64 * NW) {
         const int d = i >> 5;
-        cp[i] = (part[0][i] + part[1][i] + part[2][i] + part[3][i]) / ksum_s[d];
+        float sum = part[0][i];
+#pragma unroll
+        for (int w = 1; w < NP; ++w) sum += part[w][i];
+        cp[i] = sum / ksum_s[d];
     }
 }
 
@@ -279,9 +318,20 @@ int launch_linear_attention_core(const float* qkv, const float* mem_kv, float* c
     if (valu_ctx) {
         DM_REQUIRE(!kstats, "DM_LINATTN_VALU: the VALU context kernel does not keep the key statistics");
         hipLaunchKernelGGL(linattn_ctx_kernel, dim3(heads, B), dim3(256), 0, s, qkv, mem_kv, ctx_ws, n, heads, 4);
-    } else
-        hipLaunchKernelGGL(linattn_ctx_mfma_kernel, dim3(heads, B), dim3(256), 0, s, qkv, mem_kv, ctx_ws, kstats, n,
-                           heads);
+    } else {
+        // waves per (image, head) by the sequence length alone, so that a sample's result does not depend on its batch
+        static const int force = std::getenv("DM_LINATTN_CTX_WAVES") ? atoi(std::getenv("DM_LINATTN_CTX_WAVES")) : 0;
+        const int nw = force ? force : n >= 1024 ? 16 : n >= 256 ? 8 : 4;
+        if (nw == 16)
+            hipLaunchKernelGGL(linattn_ctx_mfma_kernel<16>, dim3(heads, B), dim3(1024), 0, s, qkv, mem_kv, ctx_ws, kstats,
+                               n, heads);
+        else if (nw == 8)
+            hipLaunchKernelGGL(linattn_ctx_mfma_kernel<8>, dim3(heads, B), dim3(512), 0, s, qkv, mem_kv, ctx_ws, kstats, n,
+                               heads);
+        else
+            hipLaunchKernelGGL(linattn_ctx_mfma_kernel<4>, dim3(heads, B), dim3(256), 0, s, qkv, mem_kv, ctx_ws, kstats, n,
+                               heads);
+    }
     DM_CHECK_HIP(hipGetLastError());
     size_t lds = (size_t)heads * DH * DH * sizeof(float);
     hipLaunchKernelGGL(linattn_out_kernel, dim3((n + 63) / 64, B), dim3(64 * heads), lds, s, qkv, ctx_ws, out, n,

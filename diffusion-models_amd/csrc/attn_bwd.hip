@@ -126,11 +126,31 @@ __global__ __launch_bounds__(256) void linattn_bwd_stats_kernel(const float* __r
     const int ld = 3 * heads * BDH;
     const float* kbase = qkv + (size_t)b * n * ld + heads * BDH + h * BDH;
     const float* mk = mem_kv + (size_t)h * BDH * NMEM;  // [d][j]
-    for (int i = tid; i < BDH * BDH; i += 256) {
-        float s = 0.f;
-        for (int k = 0; k < nblk; ++k) s += dctx_part[(((size_t)b * nblk + k) * heads + h) * BDH * BDH + i];
-        dctx[i >> 5][i & 31] = s;
-        dctx_part[((size_t)b * nblk * heads + h) * BDH * BDH + i] = s;
+    {  // the block shares of dctx, summed in block order; the 4 elements of a thread x 4 shares are in flight together
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* src = dctx_part + ((size_t)b * nblk * heads + h) * BDH * BDH + tid;
+        const size_t kst = (size_t)heads * BDH * BDH;
+        int k = 0;
+        for (; k + 4 <= nblk; k += 4) {
+            float v[4][4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[kk][j] = src[(k + kk) * kst + 256 * j];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] += v[kk][j];
+        }
+        for (; k < nblk; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += src[k * kst + 256 * j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 256 * j;
+            dctx[i >> 5][i & 31] = s[j];
+            dctx_part[((size_t)b * nblk * heads + h) * BDH * BDH + i] = s[j];
+        }
     }
     // kstats (max and sum over tokens of exp(k - max), per column) as the forward context kernel left them on the tape; without
     // them (kstats == nullptr) the two passes over the n key rows are redone here, 8 lanes deep per column
