@@ -17,15 +17,17 @@ namespace dm {
 
 static constexpr int SG_D = 4;  // K chunks in flight per wave
 
-// ---- NT: wave = 16 outputs x 64 rows, workgroup = 4 waves = 64 outputs; grid (ceil(O / 64), ceil(R / 64)).
-// x rows of the block are read by every wave (L1 / L2 hits: 64 KB at I = 256)
+// ---- NT: workgroup = 16 outputs x 64 rows; its 4 waves take the 16-wide K chunks c = wave, wave + 4, ... (at I = 256 that is
+// four chunks per wave, all in flight at once: these launches have few workgroups and nothing to overlap with, so their time
+// is the number of load round trips of one wave -- 16 in a row cost 35 us for the 256 x 256 time MLP, one costs 6), the partial
+// tiles meet in LDS and wave w finishes row tile w (fixed order over the waves).  grid (ceil(O / 16), ceil(R / 64)).
 __global__ __launch_bounds__(256) void rows_gemm_nt_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
                                                            const float* __restrict__ bias, float* __restrict__ y, int ldy, int R,
                                                            int I, int O) {
+    __shared__ f32x4 part[4][4][64];  // [wave][row tile][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
-    const int o0 = (blockIdx.x * 4 + wave) * 16;
-    if (o0 >= O) return;
+    const int o0 = blockIdx.x * 16;
     const int r0 = blockIdx.y * 64;
     const int nrt = min(4, (R - r0 + 15) / 16);
     const float* wp = W + (size_t)min(o0 + l15, O - 1) * I + 4 * kq;
@@ -43,36 +45,38 @@ __global__ __launch_bounds__(256) void rows_gemm_nt_kernel(const float* __restri
             if (rt < nrt) a[d][rt] = *reinterpret_cast<const f32x4*>(xp[rt] + 16 * c);
     };
 #pragma unroll
-    for (int d = 0; d < SG_D; ++d) load(min(d, nc - 1), d);
-    for (int c = 0; c < nc; c += SG_D) {
+    for (int d = 0; d < SG_D; ++d) load(min(wave + 4 * d, nc - 1), d);
+    for (int c = wave; c < nc; c += 4 * SG_D) {
 #pragma unroll
         for (int d = 0; d < SG_D; ++d) {
-            if (c + d < nc) {
+            if (c + 4 * d < nc) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int rt = 0; rt < 4; ++rt)
                         if (rt < nrt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][rt][j], b[d][j], acc[rt], 0, 0, 0);
-                if (c + d + SG_D < nc) load(c + d + SG_D, d);
+                if (c + 4 * (d + SG_D) < nc) load(c + 4 * (d + SG_D), d);
             }
         }
     }
-    const int o = o0 + l15;
-    if (o >= O) return;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) part[wave][rt][lane] = acc[rt];
+    __syncthreads();
+    const int o = o0 + l15, rt = wave;
+    if (o >= O || rt >= nrt) return;
+    const f32x4 sum = ((part[0][rt][lane] + part[1][rt][lane]) + part[2][rt][lane]) + part[3][rt][lane];
     const float bv = bias ? bias[o] : 0.f;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int r = r0 + 16 * rt + 4 * kq + e;  // D layout: register e of lane (n = l15, kq) = row 4 kq + e, column n
-            if (rt < nrt && r < R) y[(size_t)r * ldy + o] = acc[rt][e] + bv;
-        }
+    for (int e = 0; e < 4; ++e) {
+        const int r = r0 + 16 * rt + 4 * kq + e;  // D layout: register e of lane (n = l15, kq) = row 4 kq + e, column n
+        if (r < R) y[(size_t)r * ldy + o] = sum[e] + bv;
+    }
 }
 bool rows_gemm_nt_ok(int R, int I, int O, int ldx) { return R >= 16 && I % 16 == 0 && O % 16 == 0 && ldx % 4 == 0; }
 int launch_rows_gemm_nt(const float* x, int ldx, const float* W, const float* bias, float* y, int ldy, int R, int I, int O,
                         hipStream_t s) {
     DM_REQUIRE(rows_gemm_nt_ok(R, I, O, ldx), "rows_gemm_nt: shape");
-    hipLaunchKernelGGL(rows_gemm_nt_kernel, dim3((O + 63) / 64, (R + 63) / 64), dim3(256), 0, s, x, ldx, W, bias, y, ldy, R, I, O);
+    hipLaunchKernelGGL(rows_gemm_nt_kernel, dim3((O + 15) / 16, (R + 63) / 64), dim3(256), 0, s, x, ldx, W, bias, y, ldy, R, I, O);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -156,7 +160,8 @@ __global__ __launch_bounds__(256) void rows_gemm_tn_kernel(const float* __restri
         for (int j = 0; j < 4; ++j) acc[sgi][j] = z4;
     f32x4 colsum = z4;
     const int nk = (R + 3) / 4;
-    f32x4 a[SG_D], b[SG_D];
+    constexpr int TD = 8;  // 8 of the batch's 4-row steps in flight: B = 64 is two load rounds
+    f32x4 a[TD], b[TD];
     auto load = [&](int k, int d) {
         const bool ok = 4 * k + kq < R;
         const int kk = ok ? k : 0;
@@ -165,10 +170,10 @@ __global__ __launch_bounds__(256) void rows_gemm_tn_kernel(const float* __restri
         if (!ok) a[d] = z4;  // rows past the batch contribute nothing
     };
 #pragma unroll
-    for (int d = 0; d < SG_D; ++d) load(min(d, nk - 1), d);
-    for (int k = 0; k < nk; k += SG_D) {
+    for (int d = 0; d < TD; ++d) load(min(d, nk - 1), d);
+    for (int k = 0; k < nk; k += TD) {
 #pragma unroll
-        for (int d = 0; d < SG_D; ++d) {
+        for (int d = 0; d < TD; ++d) {
             if (k + d < nk) {
                 colsum += a[d];
 #pragma unroll
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256) void rows_gemm_tn_kernel(const float* __restri
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[sgi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][sgi], b[d][j], acc[sgi][j], 0, 0, 0);
-                if (k + d + SG_D < nk) load(k + d + SG_D, d);
+                if (k + d + TD < nk) load(k + d + TD, d);
             }
         }
     }
