@@ -363,6 +363,12 @@ void wgrad_group_plan(const std::vector<WgradDesc>& descs, int mode, std::vector
 int wgrad_group_fill(const std::vector<WgradDesc>& descs, int mode, const std::vector<int>& splits, const std::vector<float*>& ws,
                      std::vector<WgradParams>& table, std::vector<WgradJob>& jobs, int* total_wgs, size_t* lds_bytes);
 int launch_wgrad_group(const WgradParams* table_dev, int n_jobs, int total_wgs, size_t lds_bytes, int mode, hipStream_t s);
+// final_conv backward (1x1, <= 4 outputs, dy NCHW) in one pass: dw, db (through split partials in ws) and dx
+size_t thin_out_bwd_ws_floats(int B, int H, int W, int Cout, int Cin);
+bool thin_out_bwd_ok(int Cout, int HW);
+int launch_thin_out_bwd(const float* x, const float* dy_nchw, const float* w_oc, float* dx, float* ws, float* dw, float* db,
+                        int B, int H, int W, int Cin, int Cout, int accumulate, hipStream_t s, WgradJob* defer_w,
+                        WgradJob* defer_b);
 size_t wgrad_naive_ws_floats(int B, int H, int Cout, int Cin, int KH, int KW, int* splits_out);
 int launch_wgrad_naive(const float* x, int x_nchw, const float* dy, int dy_nchw, int Cin, int Cout, int KH, int KW, int pad,
                        int B, int H, int W, float* ws, float* dw, int accumulate, hipStream_t s, WgradJob* defer = nullptr);

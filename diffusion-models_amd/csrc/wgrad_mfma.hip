@@ -736,6 +736,97 @@ __global__ __launch_bounds__(64) void wgrad_init_kernel(const WgradNaive p) {
             for (int k = 0; k < KW; ++k) q[a * KW + k] = acc[a][k];
     }
 }
+// init_conv on the matrix core (v_mfma_f32_32x32x2_f32): dW[o][n] = sum_px dy[px][o] * X[px + tap(n)], n = (c, ky, kx) -- the
+// 147 (Cin = 3) or 294 (with self-conditioning) columns are 5 / 10 tiles of 32, the 64 couts of the workgroup 2 tiles, a pair of
+// neighbouring pixels of one image row the K index.  Wave (mt, nh) of the 4 owns cout tile mt and the column tiles nh, nh + 2,
+// ..: A = dy (registers, one row of the image at a time, loaded while the previous row multiplies), B = the zero-padded 7-row
+// window of every input channel in LDS (lane (n, k) reads win[c][ky][2 s + k + kx]), double-buffered: one barrier per row.
+// Same split partials as wgrad_init_kernel ([split][Cout][Cin][7][7]); 89 -> 20 us at B = 64, 32x32.
+template <int NTW, int NS>
+__global__ __launch_bounds__(256) void wgrad_init_mfma_kernel(const WgradNaive p) {
+    extern __shared__ float win[];  // [2][Cin * 7 * WP + 2 NS + 2]: the tail of a buffer stays zero (columns n >= Cin * 49)
+    constexpr int SI = 12;          // window staging items per thread (checked by the launcher)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int mt = wave & 1, nh = wave >> 1;
+    const int WP = 2 * NS + 6, WIN = p.Cin * 7 * WP, WBUF = WIN + 2 * NS + 2;
+    const int NTOT = p.Cin * 49;
+    const int row0 = blockIdx.y * p.rows_per_split, row1 = min(row0 + p.rows_per_split, p.B * p.H);
+    const int co = blockIdx.z * 64 + mt * 32 + l31;
+    const bool co_ok = co < p.Cout;
+    int base[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int n = (nh + 2 * j) * 32 + l31;
+        const int c = n / 49, r = n - c * 49, ky = r / 7, kx = r - ky * 7;
+        base[j] = (n < NTOT ? (c * 7 + ky) * WP + kx : WIN) + kh;  // WIN: the zero tail
+    }
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    for (int i = tid; i < 2 * WBUF; i += 256) win[i] = 0.f;
+
+    float wreg[SI], areg[NS];
+    auto fetch = [&](int row) {  // the row's window (all channels) and its dy values into registers
+        const int b = row / p.H, y = row - b * p.H;
+#pragma unroll
+        for (int q = 0; q < SI; ++q) {
+            const int i = tid + 256 * q;
+            float v = 0.f;
+            if (i < WIN) {
+                const int cky = i / WP, sx = i - cky * WP - 3, c = cky / 7, sy = y + (cky - c * 7) - 3;
+                if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) v = p.x[b * p.xs_b + c * p.xs_c + (int64_t)sy * p.W + sx];
+            }
+            wreg[q] = v;
+        }
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const int x = 2 * st + kh;
+            areg[st] = (co_ok && x < p.W) ? p.dy[((int64_t)row * p.W + x) * p.Cout + co] : 0.f;
+        }
+    };
+    if (row0 < row1) fetch(row0);
+    __syncthreads();  // the zero fill
+    for (int row = row0; row < row1; ++row) {
+        float* wb = win + ((row - row0) & 1) * WBUF;
+#pragma unroll
+        for (int q = 0; q < SI; ++q)
+            if (tid + 256 * q < WIN) wb[tid + 256 * q] = wreg[q];
+        float a[NS];
+#pragma unroll
+        for (int st = 0; st < NS; ++st) a[st] = areg[st];
+        __syncthreads();
+        if (row + 1 < row1) fetch(row + 1);
+#pragma unroll
+        for (int st = 0; st < NS; ++st)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], wb[base[j] + 2 * st], acc[j], 0, 0, 0);
+            }
+    }
+    // D register e of lane (n = l31, half kh) = cout row (e & 3) + 8 (e >> 2) + 4 kh of the tile, column n
+    float* out = p.partial + (size_t)blockIdx.y * p.Cout * NTOT;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int n = (nh + 2 * j) * 32 + l31;
+        if (n >= NTOT) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int o = blockIdx.z * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            if (o < p.Cout) out[(size_t)o * NTOT + n] = acc[j][e];
+        }
+    }
+}
+// column tiles per wave needed for Cin channels (0: the VALU kernel takes the layer)
+static int wgrad_init_mfma_ntw(int Cin, int W) {
+    const int tiles = (Cin * 49 + 31) / 32, ntw = (tiles + 1) / 2;
+    const int ns = W <= 32 ? 16 : 32;
+    if (W > 64 || ntw > 5 || Cin * 7 * (2 * ns + 6) > 12 * 256) return 0;
+    return ntw <= 3 ? 3 : 5;
+}
+
 // final_conv (:343): 1x1 with a handful of outputs, x NHWC, dy NCHW.  256 threads = 64 input channels x 4 pixel lanes.
 __global__ __launch_bounds__(256) void wgrad_thin_out_kernel(const WgradNaive p) {
     __shared__ float red[4][4][64];
@@ -761,6 +852,113 @@ __global__ __launch_bounds__(256) void wgrad_thin_out_kernel(const WgradNaive p)
                 (red[o][0][li] + red[o][1][li]) + (red[o][2][li] + red[o][3][li]);
 }
 
+// final_conv (:343) backward in one pass over its input: weight gradient, bias gradient and input gradient of a 1x1 convolution
+// with at most 4 outputs, x NHWC, dy NCHW (the loss gradient).  256 threads = 64 input channels x 4 pixel lanes; a thread keeps 16
+// pixels in flight (x and the Cout dy values of each), and the pixel's dx row -- sum_o w[o][c] dy[o][px] -- leaves with the same
+// registers.  Split partials: [split][Cout * Cin] then [split][Cout] (bias), summed by the reduce jobs in split order.
+struct ThinOutBwd {
+    const float *x, *dy, *w;  // x (B, H, W, Cin), dy (B, Cout, H, W), w (Cout, Cin)
+    float *dx, *part_w, *part_b;
+    int Cin, Cout, HW, px_per_split;
+    long long pixels;
+};
+__global__ __launch_bounds__(256) void thin_out_bwd_kernel(const ThinOutBwd p) {
+    __shared__ float red[4][4][64];
+    __shared__ float redb[4][4];
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + li;
+    const bool cok = c < p.Cin;
+    const long long px0 = (long long)blockIdx.y * p.px_per_split, px1 = min(px0 + (long long)p.px_per_split, p.pixels);
+    float wv[4], acc[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) wv[o] = (cok && o < p.Cout) ? p.w[o * p.Cin + c] : 0.f;
+    long long px = px0 + q;
+    long long b = px / p.HW;
+    int r = (int)(px - b * p.HW);
+    const int cc = cok ? c : 0;
+    while (px < px1) {  // branch-free body: clamped addresses, masked values (HW >= 4: one wrap per step at most)
+        constexpr int NP = 16;  // pixels in flight per thread
+        float xv[NP], dv[NP][4];
+        long long pxs[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const bool ok = px < px1;
+            const long long pc = ok ? px : px1 - 1;
+            const long long bc = ok ? b : 0;
+            const int rc = ok ? r : 0;
+            pxs[k] = ok ? px : -1;
+            xv[k] = p.x[pc * p.Cin + cc];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) dv[k][o] = p.dy[(bc * p.Cout + min(o, p.Cout - 1)) * p.HW + rc];
+            px += 4;
+            r += 4;
+            const bool wrap = r >= p.HW;
+            r = wrap ? r - p.HW : r;
+            b = wrap ? b + 1 : b;
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const float m = pxs[k] >= 0 ? 1.f : 0.f;
+            float d = 0.f;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const float dvm = dv[k][o] * m;
+                acc[o] += xv[k] * dvm;
+                bs[o] += dvm;
+                d += wv[o] * dvm;  // wv[o] = 0 for o >= Cout
+            }
+            if (pxs[k] >= 0 && cok) p.dx[pxs[k] * p.Cin + c] = d;
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) red[o][q][li] = acc[o];
+    if (li == 0)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) redb[o][q] = bs[o];
+    __syncthreads();
+    if (q == 0 && cok)
+        for (int o = 0; o < p.Cout; ++o)
+            p.part_w[(size_t)blockIdx.y * p.Cout * p.Cin + (size_t)o * p.Cin + c] =
+                (red[o][0][li] + red[o][1][li]) + (red[o][2][li] + red[o][3][li]);
+    if (blockIdx.x == 0 && threadIdx.x < p.Cout) {
+        const int o = threadIdx.x;
+        p.part_b[(size_t)blockIdx.y * p.Cout + o] = (redb[o][0] + redb[o][1]) + (redb[o][2] + redb[o][3]);
+    }
+}
+static int thin_out_bwd_splits(long long pixels) { return (int)std::min<long long>(256, std::max<long long>(1, pixels / 64)); }
+size_t thin_out_bwd_ws_floats(int B, int H, int W, int Cout, int Cin) {
+    return (size_t)thin_out_bwd_splits((long long)B * H * W) * ((size_t)Cout * Cin + Cout);
+}
+bool thin_out_bwd_ok(int Cout, int HW) { return Cout >= 1 && Cout <= 4 && HW >= 4; }
+// defer_w / defer_b: both set (the training step's grouped split sums) or both null (summed here)
+int launch_thin_out_bwd(const float* x, const float* dy_nchw, const float* w_oc, float* dx, float* ws, float* dw, float* db,
+                        int B, int H, int W, int Cin, int Cout, int accumulate, hipStream_t s, WgradJob* defer_w,
+                        WgradJob* defer_b) {
+    DM_REQUIRE(thin_out_bwd_ok(Cout, H * W), "thin_out_bwd: 1 to 4 outputs");
+    ThinOutBwd p{};
+    p.pixels = (long long)B * H * W;
+    const int splits0 = thin_out_bwd_splits(p.pixels);
+    p.px_per_split = (int)((p.pixels + splits0 - 1) / splits0);
+    const int splits = (int)((p.pixels + p.px_per_split - 1) / p.px_per_split);
+    p.x = x; p.dy = dy_nchw; p.w = w_oc; p.dx = dx;
+    p.part_w = ws; p.part_b = ws + (size_t)splits * Cout * Cin;
+    p.Cin = Cin; p.Cout = Cout; p.HW = H * W;
+    hipLaunchKernelGGL(thin_out_bwd_kernel, dim3((Cin + 63) / 64, splits), dim3(256), 0, s, p);
+    DM_CHECK_HIP(hipGetLastError());
+    const WgradJob jw{p.part_w, dw, (long long)Cout * Cin, splits, 1, accumulate, 0};
+    const WgradJob jb{p.part_b, db, (long long)Cout, splits, 1, accumulate, 0};
+    if (defer_w && defer_b) {
+        *defer_w = jw;
+        *defer_b = jb;
+        return 0;
+    }
+    const int rpn = wgrad_reduce_pairs(1, 1);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Cout * Cin + rpn - 1) / rpn), dim3(256), 0, s, jw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Cout + rpn - 1) / rpn), dim3(256), 0, s, jb);
+    DM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 size_t wgrad_naive_ws_floats(int B, int H, int Cout, int Cin, int KH, int KW, int* splits_out) {
     const int rows = B * H;
     int splits = std::min(rows, 256);
@@ -784,7 +982,17 @@ int launch_wgrad_naive(const float* x, int x_nchw, const float* dy, int dy_nchw,
     (void)wgrad_naive_ws_floats(B, H, Cout, Cin, KH, KW, &splits);
     p.rows_per_split = (B * H + splits - 1) / splits;
     const int n_out = Cout * Cin * KH * KW;
-    if (x_nchw && !dy_nchw && KW == 7 && KH == 7 && (size_t)7 * (W + 6) * sizeof(float) <= 48 * 1024)
+    static const bool no_init_mfma = std::getenv("DM_WGRAD_INIT_VALU") != nullptr;
+    const int ntw = (x_nchw && !dy_nchw && KW == 7 && KH == 7 && pad == 3 && !no_init_mfma) ? wgrad_init_mfma_ntw(Cin, W) : 0;
+    if (ntw) {
+        const int ns = W <= 32 ? 16 : 32;
+        const size_t lds = 2 * ((size_t)Cin * 7 * (2 * ns + 6) + 2 * ns + 2) * sizeof(float);
+        const dim3 grid(1, splits, (Cout + 63) / 64);
+        if (ntw == 3 && ns == 16) hipLaunchKernelGGL((wgrad_init_mfma_kernel<3, 16>), grid, dim3(256), lds, s, p);
+        else if (ntw == 3) hipLaunchKernelGGL((wgrad_init_mfma_kernel<3, 32>), grid, dim3(256), lds, s, p);
+        else if (ns == 16) hipLaunchKernelGGL((wgrad_init_mfma_kernel<5, 16>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((wgrad_init_mfma_kernel<5, 32>), grid, dim3(256), lds, s, p);
+    } else if (x_nchw && !dy_nchw && KW == 7 && KH == 7 && (size_t)7 * (W + 6) * sizeof(float) <= 48 * 1024)
         hipLaunchKernelGGL((wgrad_init_kernel<7, 7>), dim3(Cin, splits, (Cout + 63) / 64), dim3(64), 7 * (W + 6) * sizeof(float), s,
                            p);
     else if (!x_nchw && dy_nchw && KH == 1 && KW == 1 && Cout <= 4)

@@ -419,11 +419,12 @@ def test_image_conditional_training_step_vs_oracle():
     assert worst[0] < GRAD_TOL
 
 
-@pytest.mark.parametrize("shape", [(24, 24), (20, 12), (8, 8)])
+@pytest.mark.parametrize("shape", [(24, 24), (20, 12), (8, 8), (16, 40)])
 def test_training_step_at_other_image_sizes_vs_oracle(shape):
     """Loss and every gradient against the oracle's autograd on images that are not powers of two: 24x24 (stages 24, 12, 6),
     20x12 (non-square; a 5x3 bottleneck: odd maps take the direct weight-gradient kernel, even ones the Winograd-domain one)
-    and 8x8 (a 2x2 bottleneck: several whole images per pixel block), B = 3."""
+    and 8x8 (a 2x2 bottleneck: several whole images per pixel block), 16x40 (rows wider than 32 pixels: the two-chunk form of
+    init_conv's weight gradient), B = 3."""
     from oracle import train_oracle as to
 
     H, W = shape
