@@ -464,6 +464,7 @@ struct PackJob {
     float* dst;
     long long n;  // threads (elements) of the job
     int kind, Cout, Cin, a, b, first_block;  // a, b: PJ_ROT K, c_lo; PJ_PW s2d_C0
+    int rs = 0, rc = 0;  // packs: rs != 0 reads the rotated / transposed weight of an input-gradient layer in place (load_taps9)
 };
 int pack_jobs_prefix(std::vector<PackJob>& jobs);
 int launch_pack_jobs(const PackJob* jobs_dev, int n_jobs, int total_blocks, hipStream_t s);

@@ -64,13 +64,30 @@ __global__ void fold_taps_kernel(const float* __restrict__ oihw, float* __restri
         }
 }
 
+// the nine taps of pair i = cout * Cin + cin of an OIHW 3x3 weight; rs != 0: the pair of the ROTATED weight an input-gradient
+// convolution reads -- w_b[cout][cin][ky][kx] = w[cin][rc + cout][2 - ky][2 - kx] with rs the Cin of w -- read in place (the
+// grouped re-pack no longer materialises the rotated tensor; the reads are runs of 9 x (consecutive couts) floats)
+__device__ __forceinline__ void load_taps9(const float* __restrict__ w, int Cin, int rs, int rc, int64_t i, float* g) {
+    if (rs == 0) {
+        const float* p = w + i * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) g[k] = p[k];
+    } else {
+        const int co = (int)(i / Cin), ci = (int)(i % Cin);
+        const float* p = w + ((size_t)ci * rs + rc + co) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) g[k] = p[8 - k];
+    }
+}
+
 // wino_pack_weights: U = G g G^T (4x4) -> [chunk of 8 cin][xi 16][Cout][8]; one thread per (cout, cin)
 __device__ __forceinline__ void pack_wino_elem(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin,
-                                               int64_t i) {
+                                               int64_t i, int rs = 0, int rc = 0) {
 #pragma clang fp contract(off)  // the host packer (x86-64 baseline) rounds every product and sum separately
     const int co = (int)(i / Cin), ci = (int)(i % Cin);
     const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-    const float* gk = oihw + i * 9;
+    float gk[9];
+    load_taps9(oihw, Cin, rs, rc, i, gk);
     double Gg[4][3];
     for (int a = 0; a < 4; ++a)
         for (int b = 0; b < 3; ++b) Gg[a][b] = G[a][0] * gk[b] + G[a][1] * gk[3 + b] + G[a][2] * gk[6 + b];
@@ -88,13 +105,14 @@ __global__ void pack_wino_kernel(const float* __restrict__ oihw, float* __restri
 }
 // wino4_pack_weights: U = G g G^T (6x6) -> [chunk][wave 4][slot 9][cout tile][kq 4][n 16][gq 4][st 2]
 __device__ __forceinline__ void pack_wino4_elem(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin,
-                                                int64_t i) {
+                                                int64_t i, int rs = 0, int rc = 0) {
 #pragma clang fp contract(off)  // the host packer (x86-64 baseline) rounds every product and sum separately
     const int co = (int)(i / Cin), ci = (int)(i % Cin);
     const double G[6][3] = {{0.25, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                             {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
     const int lo[3] = {0, 1, 2}, hi[3] = {5, 3, 4};
-    const float* gk = oihw + i * 9;
+    float gk[9];
+    load_taps9(oihw, Cin, rs, rc, i, gk);
     double Gg[6][3];
     for (int a = 0; a < 6; ++a)
         for (int b = 0; b < 3; ++b) Gg[a][b] = G[a][0] * gk[b] + G[a][1] * gk[3 + b] + G[a][2] * gk[6 + b];
@@ -118,11 +136,12 @@ __global__ void pack_wino4_kernel(const float* __restrict__ oihw, float* __restr
 }
 // upwino_pack_weights: G = [1 0 0; 1 1 1; 0 0 1] -> [chunk][xi 9][cout tile][kq 4][n 16][gq 4][st 2]
 __device__ __forceinline__ void pack_upwino_elem(const float* __restrict__ oihw, float* __restrict__ packed, int Cout, int Cin,
-                                                 int64_t i) {
+                                                 int64_t i, int rs = 0, int rc = 0) {
 #pragma clang fp contract(off)  // the host packer (x86-64 baseline) rounds every product and sum separately
     const int co = (int)(i / Cin), ci = (int)(i % Cin);
     const double G[3][3] = {{1, 0, 0}, {1, 1, 1}, {0, 0, 1}};
-    const float* gk = oihw + i * 9;
+    float gk[9];
+    load_taps9(oihw, Cin, rs, rc, i, gk);
     double Gg[3][3];
     for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) Gg[a][b] = G[a][0] * gk[b] + G[a][1] * gk[3 + b] + G[a][2] * gk[6 + b];
@@ -142,10 +161,12 @@ __global__ void pack_upwino_kernel(const float* __restrict__ oihw, float* __rest
 // pw_pack_weights: (Cout, Cin) -> [chunk of 16][cout tile of 16][lane = 16 kq + l15][j 4];  s2d: the (Cout, C0, 2, 2)
 // Downsample weight read as (Cout, 4 C0) with K index sub * C0 + c
 __device__ __forceinline__ void pack_pw_elem(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin,
-                                             int s2d_C0, int64_t i) {
+                                             int s2d_C0, int64_t i, int rs = 0, int rc = 0) {
     const int co = (int)(i / Cin), ci = (int)(i % Cin);
     float v;
-    if (s2d_C0) {
+    if (rs) {  // the transposed 1x1 weight of an input-gradient convolution, read in place (load_taps9)
+        v = w[(size_t)ci * rs + rc + co];
+    } else if (s2d_C0) {
         const int sub = ci / s2d_C0, c = ci % s2d_C0;
         v = w[((size_t)co * s2d_C0 + c) * 4 + sub];
     } else {
@@ -258,7 +279,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         case PJ_S2D_T: s2d_transpose_elem(j.src, j.dst, j.Cout, j.Cin, t); break;
         case PJ_WINO: {  // [chunk of 8][xi][Cout][8]
             const int cc = (int)(t & 7), co = (int)((t >> 3) % j.Cout), chunk = (int)((t >> 3) / j.Cout);
-            pack_wino_elem(j.src, j.dst, j.Cout, j.Cin, (int64_t)co * j.Cin + chunk * 8 + cc);
+            pack_wino_elem(j.src, j.dst, j.Cout, j.Cin, (int64_t)co * j.Cin + chunk * 8 + cc, j.rs, j.rc);
             break;
         }
         case PJ_WINO4:
@@ -267,15 +288,15 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
             const int64_t rest = t >> 9;
             const int tiles = j.Cout / 64, ct = (int)(rest % tiles), chunk = (int)(rest / tiles);
             const int64_t i = (int64_t)(ct * 64 + 16 * gq + n) * j.Cin + chunk * 8 + 2 * kq + st;
-            if (j.kind == PJ_WINO4) pack_wino4_elem(j.src, j.dst, j.Cout, j.Cin, i);
-            else pack_upwino_elem(j.src, j.dst, j.Cout, j.Cin, i);
+            if (j.kind == PJ_WINO4) pack_wino4_elem(j.src, j.dst, j.Cout, j.Cin, i, j.rs, j.rc);
+            else pack_upwino_elem(j.src, j.dst, j.Cout, j.Cin, i, j.rs, j.rc);
             break;
         }
         case PJ_PW: {  // [chunk of 16][cout tile of 16][kq 4][l15 16][j 4]
             const int jj = (int)(t & 3), l15 = (int)((t >> 2) & 15), kq = (int)((t >> 6) & 3);
             const int64_t rest = t >> 8;
             const int tiles = j.Cout / 16, t16 = (int)(rest % tiles), chunk = (int)(rest / tiles);
-            pack_pw_elem(j.src, j.dst, j.Cout, j.Cin, j.a, (int64_t)(t16 * 16 + l15) * j.Cin + chunk * 16 + 4 * kq + jj);
+            pack_pw_elem(j.src, j.dst, j.Cout, j.Cin, j.a, (int64_t)(t16 * 16 + l15) * j.Cin + chunk * 16 + 4 * kq + jj, j.rs, j.rc);
             break;
         }
         default: j.dst[t] = j.src[t]; break;  // PJ_COPY

@@ -104,6 +104,12 @@ def test_device_packers_match_host_packers():
     for cfg, salt in ((UnetConfig(), 0), (UnetConfig(dim=32, dim_mults=(1, 2), channels=3), 41)):
         d = _model(cfg, salt, "pred_noise", 1000)
         assert d.model.check_device_pack() == 0
+        # after a step the model knows which buffers its shapes use: the grouped re-pack of exactly those (the rotated weights
+        # of the input-gradient layers are read in place there) is compared with the per-buffer packers as well
+        side = 32 if cfg.dim == 64 else 16
+        float(d.p_losses(torch.rand(2, 3, side, side) * 2 - 1, torch.tensor([5, 700])))
+        d.model.optimizer_step(lr=1e-4)
+        assert d.model.check_device_pack() == 0
 
 
 def _oracle_steps(cfg, sd, sched, batches, ts, noises, lr, n_steps, accumulate):
