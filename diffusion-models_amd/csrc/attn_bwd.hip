@@ -287,6 +287,177 @@ __global__ __launch_bounds__(64, 3) void linattn_bwd_kv_kernel(const float* __re
     for (int j = 0; j < BDH / 4; ++j) ok[j] = make_f32x4(kk[4 * j], kk[4 * j + 1], kk[4 * j + 2], kk[4 * j + 3]);
 }
 
+// ---- the same two passes on the matrix core (v_mfma_f32_32x32x2_f32), what the training step runs.  Every product of the
+// backward pass is a (tokens x 32) x (32 x 32) GEMM; computed TRANSPOSED -- the 32 x 32 matrix (ctx, dctx) is the A operand, the
+// token rows the B operand -- the result D[i][j = token] leaves lane (token, half) with the 16 columns
+//     dset(r) = (r & 3) + 8 (r >> 2) + 4 half,   r = 0 .. 15      (four float4 chunks 2 m + half of the token's 32-float row)
+// of its token, and with the K index enumerated in the same order (k-step s of half h = column dset(s)) the B operand of the
+// next product is exactly those registers: a lane loads 4 chunks of q / dout / k / v, keeps everything row-wise (softmax over
+// the columns, the dot products) in registers plus one exchange with lane ^ 32, and stores 4 chunks.  One wave = 64 tokens (two
+// 32-token tiles), 64 MFMAs per pass where the VALU form issued ~2000 FMAs and ~600 LDS broadcasts per lane.
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__global__ __launch_bounds__(64) void linattn_bwd_q_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                                const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                                float* __restrict__ dctx_part, int n, int heads, float scale) {
+    __shared__ __attribute__((aligned(16))) float ps[64 * LSTR];  // scale * p, [token][d]
+    __shared__ __attribute__((aligned(16))) float ds[64 * LSTR];  // dout,      [token][e]
+    const int blk = blockIdx.x, nblk = gridDim.x, h = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+    const int ld = 3 * heads * BDH, hid = heads * BDH;
+    // A operand of dqs^T = ctx . dout^T: ctx[d = l31][e = dset(s)]
+    float actx[16];
+    {
+        const f32x4* cr = reinterpret_cast<const f32x4*>(ctx + ((size_t)(b * heads + h) * BDH + l31) * BDH);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 v = cr[2 * m + half];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) actx[4 * m + i] = v[i];
+        }
+    }
+    float p[2][16], dv[2][16];
+    bool okt[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int tok = blk * 64 + nt * 32 + l31;
+        okt[nt] = tok < n;
+        const size_t row = (size_t)b * n + (okt[nt] ? tok : 0);
+        const f32x4* qp = reinterpret_cast<const f32x4*>(qkv + row * ld + h * BDH);
+        const f32x4* dp = reinterpret_cast<const f32x4*>(dout + row * hid + h * BDH);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 a = qp[2 * m + half], c = dp[2 * m + half];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                p[nt][4 * m + i] = a[i];
+                dv[nt][4 * m + i] = okt[nt] ? c[i] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, p[nt][r]);
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[nt][r] = __expf(p[nt][r] - m);
+            sum += p[nt][r];
+        }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[nt][r] *= inv;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(actx[s], dv[nt][s], acc, 0, 0, 0);
+        float dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dot += p[nt][r] * acc[r];
+        dot += __shfl_xor(dot, 32);
+        const int tok = blk * 64 + nt * 32 + l31;
+        if (okt[nt]) {
+            f32x4* o = reinterpret_cast<f32x4*>(dqkv + ((size_t)b * n + tok) * ld + h * BDH);
+#pragma unroll
+            for (int m4 = 0; m4 < 4; ++m4)
+                o[2 * m4 + half] = make_f32x4(scale * p[nt][4 * m4] * (acc[4 * m4] - dot),
+                                              scale * p[nt][4 * m4 + 1] * (acc[4 * m4 + 1] - dot),
+                                              scale * p[nt][4 * m4 + 2] * (acc[4 * m4 + 2] - dot),
+                                              scale * p[nt][4 * m4 + 3] * (acc[4 * m4 + 3] - dot));
+        }
+        const float z = okt[nt] ? scale : 0.f;
+        float* pr = ps + (nt * 32 + l31) * LSTR;
+        float* dr = ds + (nt * 32 + l31) * LSTR;
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) {
+            *reinterpret_cast<f32x4*>(pr + 4 * (2 * m4 + half)) =
+                make_f32x4(z * p[nt][4 * m4], z * p[nt][4 * m4 + 1], z * p[nt][4 * m4 + 2], z * p[nt][4 * m4 + 3]);
+            *reinterpret_cast<f32x4*>(dr + 4 * (2 * m4 + half)) =
+                make_f32x4(dv[nt][4 * m4], dv[nt][4 * m4 + 1], dv[nt][4 * m4 + 2], dv[nt][4 * m4 + 3]);
+        }
+    }
+    __syncthreads();
+    // dctx share of this block: D[i = d][j = e] = sum over the 64 tokens (k-step s, half -> token 2 s + half) ps[t][d] ds[t][e]
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ps[(2 * s + half) * LSTR + l31], ds[(2 * s + half) * LSTR + l31], acc, 0, 0, 0);
+    float* o = dctx_part + (((size_t)b * nblk + blk) * heads + h) * BDH * BDH;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * half) * BDH + l31] = acc[r];
+}
+
+__global__ __launch_bounds__(64) void linattn_bwd_kv_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx_part,
+                                                                 int nblk, const float* __restrict__ stats,
+                                                                 float* __restrict__ dqkv, int n, int heads) {
+    const int blk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+    const int ld = 3 * heads * BDH;
+    const float* dctx = dctx_part + ((size_t)b * nblk * heads + h) * BDH * BDH;  // share 0 holds the sum
+    // A operands: dv^T = dctx^T . ks^T needs dctx[d = dset(s)][e = l31]; dks^T = dctx . v^T needs dctx[d = l31][e = dset(s)]
+    float a3[16], a4[16], kmax[16], kinv[16], S[16];
+    {
+        const f32x4* row = reinterpret_cast<const f32x4*>(dctx + l31 * BDH);
+        const f32x4* st = reinterpret_cast<const f32x4*>(stats + (size_t)(b * heads + h) * 3 * BDH);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 v = row[2 * m + half], s0 = st[2 * m + half], s1 = st[8 + 2 * m + half], s2 = st[16 + 2 * m + half];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a4[4 * m + i] = v[i];
+                a3[4 * m + i] = dctx[(8 * m + 4 * half + i) * BDH + l31];
+                kmax[4 * m + i] = s0[i];
+                kinv[4 * m + i] = s1[i];
+                S[4 * m + i] = s2[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int tok = blk * 64 + nt * 32 + l31;
+        const bool ok = tok < n;
+        const size_t row = (size_t)b * n + (ok ? tok : 0);
+        const f32x4* kp = reinterpret_cast<const f32x4*>(qkv + row * ld + heads * BDH + h * BDH);
+        const f32x4* vp = reinterpret_cast<const f32x4*>(qkv + row * ld + 2 * heads * BDH + h * BDH);
+        float ks[16], vv[16];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 a = kp[2 * m + half], c = vp[2 * m + half];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ks[4 * m + i] = __expf(a[i] - kmax[4 * m + i]) * kinv[4 * m + i];
+                vv[4 * m + i] = c[i];
+            }
+        }
+        f32x16 dvt, dkt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dvt[r] = dkt[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            dvt = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[s], ks[s], dvt, 0, 0, 0);
+            dkt = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], vv[s], dkt, 0, 0, 0);
+        }
+        if (ok) {
+            f32x4* okp = reinterpret_cast<f32x4*>(dqkv + row * ld + heads * BDH + h * BDH);
+            f32x4* ovp = reinterpret_cast<f32x4*>(dqkv + row * ld + 2 * heads * BDH + h * BDH);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                ovp[2 * m + half] = make_f32x4(dvt[4 * m], dvt[4 * m + 1], dvt[4 * m + 2], dvt[4 * m + 3]);
+                okp[2 * m + half] = make_f32x4(ks[4 * m] * (dkt[4 * m] - S[4 * m]), ks[4 * m + 1] * (dkt[4 * m + 1] - S[4 * m + 1]),
+                                               ks[4 * m + 2] * (dkt[4 * m + 2] - S[4 * m + 2]),
+                                               ks[4 * m + 3] * (dkt[4 * m + 3] - S[4 * m + 3]));
+            }
+        }
+    }
+}
+
 // block shares of dctx (the sum lands in share 0) + the per-(image, head) statistics
 size_t linattn_bwd_ws_floats(int B, int n, int heads) {
     return (size_t)B * ((n + 63) / 64) * heads * BDH * BDH + (size_t)B * heads * 3 * BDH;
@@ -301,13 +472,21 @@ int launch_linear_attention_core_bwd(const float* qkv, const float* mem_kv, cons
     DM_REQUIRE(B <= 65535 && n >= 1, "linear attention backward: batch");
     const int nblk = (n + 63) / 64;
     float* stats = ws + (size_t)B * nblk * heads * BDH * BDH;
-    hipLaunchKernelGGL(linattn_bwd_q_kernel, dim3(nblk, heads, B), dim3(64), 0, s, qkv, ctx, dout, dqkv, ws, n, heads,
-                       1.0f / sqrtf((float)dh));
+    static const bool valu = std::getenv("DM_LINATTN_BWD_VALU") != nullptr;  // the lane-per-token VALU kernels (A/B, forced-path test)
+    if (valu)
+        hipLaunchKernelGGL(linattn_bwd_q_kernel, dim3(nblk, heads, B), dim3(64), 0, s, qkv, ctx, dout, dqkv, ws, n, heads,
+                           1.0f / sqrtf((float)dh));
+    else
+        hipLaunchKernelGGL(linattn_bwd_q_mfma_kernel, dim3(nblk, heads, B), dim3(64), 0, s, qkv, ctx, dout, dqkv, ws, n, heads,
+                           1.0f / sqrtf((float)dh));
     DM_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(linattn_bwd_stats_kernel, dim3(heads, B), dim3(256), 0, s, qkv, mem_kv, ctx, ws, nblk, stats, dmem_part,
                        kstats, n, heads);
     DM_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(linattn_bwd_kv_kernel, dim3(nblk, heads, B), dim3(64), 0, s, qkv, ws, nblk, stats, dqkv, n, heads);
+    if (valu)
+        hipLaunchKernelGGL(linattn_bwd_kv_kernel, dim3(nblk, heads, B), dim3(64), 0, s, qkv, ws, nblk, stats, dqkv, n, heads);
+    else
+        hipLaunchKernelGGL(linattn_bwd_kv_mfma_kernel, dim3(nblk, heads, B), dim3(64), 0, s, qkv, ws, nblk, stats, dqkv, n, heads);
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }

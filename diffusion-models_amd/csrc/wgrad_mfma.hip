@@ -595,7 +595,7 @@ int launch_wgrad(const float* in0, int C0, const float* in1, int C1, const float
 // Pass 1 (wgrad_group_plan): splits per layer such that every workgroup gets about the same number of pixel blocks and the
 // launch has about `target` workgroups; returns the floats of partial-sum workspace each layer needs.
 void wgrad_group_plan(const std::vector<WgradDesc>& descs, int mode, std::vector<int>& splits, std::vector<size_t>& ws_floats) {
-    static const int target = env_int("DM_WGRAD_GROUP_WGS", 3072);
+    static const int target = env_int("DM_WGRAD_GROUP_WGS", 2048);
     const int T = wgrad_taps(mode);
     long long units = 0;
     std::vector<WgradGeo> geo(descs.size());

@@ -94,10 +94,11 @@ def test_training_goldens_with_one_launch_per_layer():
     layer (no grouped launch, no deferred reductions), the direct 3x3 weight gradient instead of the Winograd-domain one,
     lazy instead of grouped re-packing; round 4: separate landing passes, the VALU Linear kernels, the attention backward
     without its score cache, the LinearAttention backward recomputing the key statistics instead of reading the tape's, final_conv's three
-    gradients as three launches, init_conv's weight gradient on the VALU."""
+    gradients as three launches, init_conv's weight gradient and the LinearAttention backward on the VALU, the rotated weights materialised before packing."""
     _run_training(dict(DM_WGRAD_NO_DEFER="1", DM_WGRAD_NO_WINO="1", DM_NO_BATCH_REPACK="1", DM_TRAIN_NO_LANDING_FUSE="1",
                        DM_NO_SMALL_GEMM="1", DM_ATTN_BWD_NO_CACHE="1", DM_LINATTN_NO_KSTATS="1",
-                       DM_TRAIN_NO_FINAL_FUSE="1", DM_WGRAD_INIT_VALU="1"))
+                       DM_TRAIN_NO_FINAL_FUSE="1", DM_WGRAD_INIT_VALU="1", DM_LINATTN_BWD_VALU="1",
+                       DM_REPACK_ROT_TMP="1"))
 
 
 def test_attention_backward_tiled_form_on_every_shape():
