@@ -303,6 +303,59 @@ __global__ void linattn_out_kernel(const float* __restrict__ qkv, const float* _
         *reinterpret_cast<float4*>(op + 4 * i) = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
 }
 
+// part 2 on the matrix core: out^T[e][token] = sum_d ctx[d][e] q_s[token][d] as 32x32x2 MFMA products with the token rows as the
+// B operand (attn_bwd.hip's linattn_bwd_*_mfma_kernel describe the layout): lane (token, half) holds the four float4 chunks
+// 2 m + half of its token's q row = the columns dset(r) = (r & 3) + 8 (r >> 2) + 4 half, the softmax over the 32 columns is 16
+// registers plus one exchange with lane ^ 32, the K index runs over d in the same order, and the result D[i = e][j = token]
+// leaves the lane with out[token][dset(r)]: four float4 stores.  grid (ceil(n / 64), heads, B), one wave = 64 tokens.
+__global__ __launch_bounds__(64) void linattn_out_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                              float* __restrict__ out, int n, int heads, float scale) {
+    const int blk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+    const int ld = 3 * heads * DH, hid = heads * DH;
+    float a[16];  // A[i = e = l31][k -> d = dset(s)] = ctx[d][e]
+    {
+        const float* cp = ctx + (size_t)(b * heads + h) * DH * DH + l31;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) a[s] = cp[((s & 3) + 8 * (s >> 2) + 4 * half) * DH];
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int tok = blk * 64 + nt * 32 + l31;
+        const bool ok = tok < n;
+        const size_t row = (size_t)b * n + (ok ? tok : 0);
+        const float4* qp = reinterpret_cast<const float4*>(qkv + row * ld + h * DH);
+        float q[16];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float4 t = qp[2 * m + half];
+            q[4 * m] = t.x; q[4 * m + 1] = t.y; q[4 * m + 2] = t.z; q[4 * m + 3] = t.w;
+        }
+        float mx = q[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, q[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            q[r] = __expf(q[r] - mx);
+            sum += q[r];
+        }
+        sum += __shfl_xor(sum, 32);
+        const float inv = scale / sum;
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], q[s] * inv, acc, 0, 0, 0);
+        if (ok) {
+            float4* op = reinterpret_cast<float4*>(out + row * hid + h * DH);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) op[2 * m + half] = make_float4(acc[4 * m], acc[4 * m + 1], acc[4 * m + 2], acc[4 * m + 3]);
+        }
+    }
+}
+
 // the training tape keeps the key statistics unless the VALU context kernel is forced or DM_LINATTN_NO_KSTATS asks for the
 // recomputing backward (tests/test_hip_forced_dispatch.py)
 bool linattn_keeps_kstats() {
@@ -333,9 +386,15 @@ int launch_linear_attention_core(const float* qkv, const float* mem_kv, float* c
                                heads);
     }
     DM_CHECK_HIP(hipGetLastError());
-    size_t lds = (size_t)heads * DH * DH * sizeof(float);
-    hipLaunchKernelGGL(linattn_out_kernel, dim3((n + 63) / 64, B), dim3(64 * heads), lds, s, qkv, ctx_ws, out, n,
-                       heads, 1.0f / sqrtf((float)dh));
+    if (valu_ctx) {
+        size_t lds = (size_t)heads * DH * DH * sizeof(float);
+        hipLaunchKernelGGL(linattn_out_kernel, dim3((n + 63) / 64, B), dim3(64 * heads), lds, s, qkv, ctx_ws, out, n,
+                           heads, 1.0f / sqrtf((float)dh));
+    } else {
+        DM_REQUIRE(B <= 65535, "LinearAttention: batch");
+        hipLaunchKernelGGL(linattn_out_mfma_kernel, dim3((n + 63) / 64, heads, B), dim3(64), 0, s, qkv, ctx_ws, out, n, heads,
+                           1.0f / sqrtf((float)dh));
+    }
     DM_CHECK_HIP(hipGetLastError());
     return 0;
 }

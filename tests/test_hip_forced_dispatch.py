@@ -55,9 +55,10 @@ def test_model_goldens_with_the_alternative_kernels():
     """The model-level goldens of the reference (full 32x32 U-Net, latent / text variants, DDPM + DDIM loops, the LDM YAML
     shapes) with every dispatch alternative forced: no F(4x4) Winograd and no 1x1 GEMM kernel (the F(2x2) / direct
     kernels take their layers), the general CrossAttention path instead of the one-token algebra, separate res_conv
-    landings, no fused attention kernels, the folded instead of the 9-multiply upsample conv."""
+    landings, no fused attention kernels (and the VALU forms of the unfused LinearAttention core), the folded instead of the
+    9-multiply upsample conv."""
     _run_models(dict(DM_NO_WINO4="1", DM_NO_PW="1", DM_NO_CROSS1="1", DM_NO_RES_MERGE="1", DM_NO_UPWINO="1",
-                     DM_NO_FUSED_LINATTN="1", DM_NO_ATTN16="1", DM_NO_INIT7="1"))
+                     DM_NO_FUSED_LINATTN="1", DM_NO_ATTN16="1", DM_NO_INIT7="1", DM_LINATTN_VALU="1"))
 
 
 def test_model_goldens_on_the_small_tile_kernel_forms():
