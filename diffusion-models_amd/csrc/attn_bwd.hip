@@ -678,6 +678,100 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdParams p) {
     }
 }
 
+// ---- short sequences (the CACHE condition), every phase spread over the 256 threads: the 16 tokens + 4 memory rows of the
+// 32x32 U-Net's bottleneck are 16 queries and 20 keys, so "thread = query" leaves 240 threads idle while 16 of them walk 20 keys
+// x three 32-wide dot products each (22 us at any batch).  Here (1) thread = (query, key) pair forms the score and dP, (2) thread
+// = query normalises its row (no dot products left), (3) thread = (query, d) forms dq, (4) thread = (key, d) forms dk and dv.
+// Every sum runs over the same index in the same order as attn_bwd_kernel's (d, then keys, then queries): identical results.
+__global__ __launch_bounds__(256) void attn_bwd_pairs_kernel(const AttnBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int nkt = p.nk + p.n_mem, n = p.nq;
+    float* Ks = sm;                       // [nkt][33]
+    float* Vs = Ks + nkt * (BDH + 1);     // [nkt][33]
+    float* Qs = Vs + nkt * (BDH + 1);     // [n][33]
+    float* Ds = Qs + n * (BDH + 1);       // [n][33]  dout
+    float* Pc = Ds + n * (BDH + 1) + 3 * n;  // (same offsets as attn_bwd_kernel<true>: one LDS size for both)
+    float* Sc = Pc + n * nkt;
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int hid = p.heads * BDH;
+    const float scale = p.scale;
+    for (int i = tid; i < nkt * BDH; i += 256) {
+        const int j = i >> 5, d = i & 31;
+        float kv, vv;
+        if (j < p.n_mem) {
+            kv = p.mem_k[((size_t)h * p.n_mem + j) * BDH + d];
+            vv = p.mem_v[((size_t)h * p.n_mem + j) * BDH + d];
+        } else {
+            const size_t row = ((size_t)b * p.nk + (j - p.n_mem)) * p.ldk + h * BDH + d;
+            kv = p.k[row];
+            vv = p.v[row];
+        }
+        Ks[j * (BDH + 1) + d] = kv;
+        Vs[j * (BDH + 1) + d] = vv;
+    }
+    for (int i = tid; i < n * BDH; i += 256) {
+        const int t = i >> 5, d = i & 31;
+        Qs[t * (BDH + 1) + d] = p.q[((size_t)b * n + t) * p.ldq + h * BDH + d];
+        Ds[t * (BDH + 1) + d] = p.dout[((size_t)b * n + t) * hid + h * BDH + d];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * nkt; idx += 256) {  // (1) scores and dP
+        const int i = idx / nkt, j = idx - i * nkt;
+        float sc = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < BDH; ++d) {
+            sc += Qs[i * (BDH + 1) + d] * Ks[j * (BDH + 1) + d];
+            dp += Ds[i * (BDH + 1) + d] * Vs[j * (BDH + 1) + d];
+        }
+        Pc[idx] = sc * scale;
+        Sc[idx] = dp;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {  // (2) row softmax, D_i, dS
+        float* Pi = Pc + i * nkt;
+        float* Si = Sc + i * nkt;
+        float m = -INFINITY, l = 0.f, D = 0.f;
+        for (int j = 0; j < nkt; ++j) m = fmaxf(m, Pi[j]);
+        for (int j = 0; j < nkt; ++j) {
+            const float e = __expf(Pi[j] - m);
+            Pi[j] = e;
+            l += e;
+            D += e * Si[j];
+        }
+        const float linv = 1.0f / l;
+        D *= linv;
+        for (int j = 0; j < nkt; ++j) {
+            const float P = Pi[j] * linv;
+            Si[j] = P * (Si[j] - D);
+            Pi[j] = P;
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * BDH; idx += 256) {  // (3) dq
+        const int i = idx >> 5, d = idx & 31;
+        float dq = 0.f;
+        for (int j = 0; j < nkt; ++j) dq += Sc[i * nkt + j] * Ks[j * (BDH + 1) + d];
+        p.dq[((size_t)b * n + i) * p.ldq + h * BDH + d] = scale * dq;
+    }
+    for (int idx = tid; idx < nkt * BDH; idx += 256) {  // (4) dk, dv
+        const int j = idx >> 5, d = idx & 31;
+        float dk = 0.f, dv = 0.f;
+        for (int i = 0; i < n; ++i) {
+            dk += Sc[i * nkt + j] * Qs[i * (BDH + 1) + d];
+            dv += Pc[i * nkt + j] * Ds[i * (BDH + 1) + d];
+        }
+        if (j < p.n_mem) {
+            float* o = p.dmem_part + (size_t)b * 2 * p.heads * p.n_mem * BDH;
+            o[((size_t)h * p.n_mem + j) * BDH + d] = scale * dk;
+            o[((size_t)(p.heads + h) * p.n_mem + j) * BDH + d] = dv;
+        } else {
+            const size_t row = ((size_t)b * p.nk + (j - p.n_mem)) * p.ldk + h * BDH;
+            p.dk[row + d] = scale * dk;
+            p.dv[row + d] = dv;
+        }
+    }
+}
+
 // ---- the same gradients for sequences that do not fit LDS: two tiled kernels, one wave per 64 queries / 64 keys.
 // attn_bwd_q_tiled_kernel   grid (ceil(nq / 64), heads, B): lane = query; the keys stream through LDS in tiles of 64 three
 //     times (row maximum; row sum and D_i; dq) -- the three loops of attn_bwd_kernel's first phase; writes dq and the row
@@ -844,6 +938,14 @@ static int launch_attn_bwd(const AttnBwdParams& p, int B, float* ws, hipStream_t
         hipLaunchKernelGGL(attn_bwd_q_tiled_kernel, dim3((p.nq + 63) / 64, p.heads, B), dim3(64), 0, s, p, ws);
         DM_CHECK_HIP(hipGetLastError());
         hipLaunchKernelGGL(attn_bwd_kv_tiled_kernel, dim3((p.nk + p.n_mem + 63) / 64, p.heads, B), dim3(64), 0, s, p, ws);
+        DM_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    static const bool no_pairs = std::getenv("DM_ATTN_BWD_NO_PAIRS") != nullptr;
+    if (attn_bwd_cached(p.nq, p.nk, p.n_mem) && !no_pairs) {
+        static LdsOptIn flagp;
+        if (lds_opt_in(flagp, reinterpret_cast<const void*>(attn_bwd_pairs_kernel), 1)) return 1;
+        hipLaunchKernelGGL(attn_bwd_pairs_kernel, dim3(p.heads, B), dim3(256), lds, s, p);
         DM_CHECK_HIP(hipGetLastError());
         return 0;
     }

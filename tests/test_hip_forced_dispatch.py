@@ -106,11 +106,12 @@ def test_attention_backward_tiled_form_on_every_shape():
     """The operator-level attention backward cases and the text-conditional training step (mid_attn + CrossAttention) with the
     tiled kernels forced on the short sequences the LDS-resident kernel normally takes; and the LDS-resident kernel without
     its score cache (the form longer sequences take)."""
-    env0 = dict(os.environ, DM_ATTN_BWD_NO_CACHE="1")
-    r0 = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_train_ops.py"), "-q", "-x", "-m",
-                         "gpu", "-k", "test_attention_bwd", "-p", "no:cacheprovider"],
-                        cwd=ROOT, env=env0, capture_output=True, text=True, timeout=600)
-    assert r0.returncode == 0, r0.stdout[-4000:] + r0.stderr[-2000:]
+    for extra in (dict(DM_ATTN_BWD_NO_CACHE="1"), dict(DM_ATTN_BWD_NO_PAIRS="1")):  # thread-per-query: uncached, cached
+        env0 = dict(os.environ, **extra)
+        r0 = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_train_ops.py"), "-q", "-x",
+                             "-m", "gpu", "-k", "test_attention_bwd", "-p", "no:cacheprovider"],
+                            cwd=ROOT, env=env0, capture_output=True, text=True, timeout=600)
+        assert r0.returncode == 0, r0.stdout[-4000:] + r0.stderr[-2000:]
     env = dict(os.environ, DM_ATTN_BWD_TILED="1", DM_ATTN_TILED="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_train_ops.py"),
                         os.path.join(ROOT, "tests", "test_hip_train.py"), "-q", "-x", "-m", "gpu", "-k",
