@@ -963,7 +963,7 @@ static int plan_conv(const Ctx& c, const ConvLayer& L, bool has_in1, int Hin, in
         p.w = L.ww;
         p.chunks0 = L.C0 / 8;
         p.n_chunks = (L.C0 + L.C1) / 8;
-        p.geo = wino_plan(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1, true);
+        p.geo = wino_plan(c.B, p.Ho, p.Wo, L.Cout, L.C0, L.C1, true, want_norm);
         P.kind = 1;
     }
     P.in_kernel = p.geo.splits == 1 && (!want_norm || p.geo.fused_norm);

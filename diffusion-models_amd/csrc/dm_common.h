@@ -149,7 +149,7 @@ bool wino_eligible(int Cout, int C0, int C1, int KH, int KW, int stride, int pad
 size_t wino_packed_floats(int Cout, int C0, int C1);
 // OIHW (Cout, C0+C1, 3, 3) -> U = G g G^T in kernel layout [chunk of 8 cin][16 xi][Cout][8]
 void wino_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C1);
-ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_split);
+ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_split, bool want_norm = true);
 // the shape-dependent half of eligibility: even size, window fits the staging registers, 24-bit pixel indices
 bool wino_shape_ok(int B, int Ho, int Wo, int Cout, int C0, int C1);
 int wino_launch(const ConvParams& p, hipStream_t s);

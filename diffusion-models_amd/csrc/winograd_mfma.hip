@@ -76,7 +76,7 @@ void wino_pack_weights(const float* oihw, float* packed, int Cout, int C0, int C
         }
 }
 
-ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_split) {
+ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_split, bool want_norm) {
     // R = Winograd tiles per lane: 2 -> 64 tiles per workgroup, 256 accumulator registers, one workgroup per CU;
     //                              1 -> 32 tiles per workgroup, 128 accumulator registers, two workgroups per CU
     static const int R = env_int("DM_WINO_R", 1) == 2 ? 2 : 1;
@@ -118,9 +118,12 @@ ConvGeom wino_plan(int B, int Ho, int Wo, int Cout, int C0, int C1, bool allow_s
     // holds a pixel's whole row (the RMSNorm then runs in the kernel's epilogue instead of a landing pass).
     g.NQ = 2;
     static const int q_target = env_int("DM_WINO_Q_TARGET_WGS", 512);
-    if (R == 1 && !g.fused_norm && wgs * g.splits < q_target) {
+    // (want_norm = false: the caller has no norm to fuse -- the training step's convolutions, whose norms are separate passes
+    // over the tape -- so a single 64-cout tile is no reason to keep it)
+    if (R == 1 && !(g.fused_norm && want_norm) && wgs * g.splits < q_target) {
         g.NQ = 1;
         g.n_tiles_n = Cout / 32;
+        g.fused_norm = 0;
     }
     g.w_floats = 0;
     // two windows + a scratch slot reachable from both; the epilogue reuses the space for 4 x 2 transposed tiles;
