@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DM_LIB") or os.path.join(_HERE, "libdm_hip.so")
 DM_MAX_STAGES = 8
 DM_COEFS = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/dm_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
@@ -48,7 +48,7 @@ class UnetCfg(C.Structure):
         ("dim_mults", C.c_int32 * DM_MAX_STAGES), ("full_attn", C.c_int32 * DM_MAX_STAGES),
         ("attn_heads", C.c_int32), ("attn_dim_head", C.c_int32),
         ("text_mode", C.c_int32), ("text_emb_dim", C.c_int32), ("sinusoidal_theta", C.c_float),
-        ("learned_sinusoidal_dim", C.c_int32),
+        ("learned_sinusoidal_dim", C.c_int32), ("attn_heads_stage", C.c_int32 * DM_MAX_STAGES),
     ]
 
 

@@ -253,7 +253,7 @@ struct ResBlock {
 
 struct AttnLayer {
     bool full = false;
-    int dim = 0;
+    int dim = 0, heads = 0;  // heads: attn_heads of the layer's stage (cast_tuple(attn_heads, num_stages), :294)
     float *norm_g = nullptr, *mem_kv = nullptr, *out_g = nullptr;
     ConvLayer qkv, out;
     bool has_fused = false;  // LinearAttention as two fused kernels (linattn_fused.hip)
@@ -398,16 +398,19 @@ static void expect_resnet(dm_unet* u, const std::string& p, int din, int dout) {
     }
 }
 
-static void expect_attn(dm_unet* u, const std::string& p, int dim, bool full) {
-    int hidden = u->heads * u->dh;
+// attn_heads of stage i (Unet(attn_heads = (..)), :294: cast_tuple over the stages; mid_attn takes the last stage's, :324)
+static int stage_heads(const dm_unet_cfg& cfg, int i) { return cfg.attn_heads_stage[i] > 0 ? cfg.attn_heads_stage[i] : cfg.attn_heads; }
+
+static void expect_attn(dm_unet* u, const std::string& p, int dim, bool full, int heads) {
+    int hidden = heads * u->dh;
     if (full) {
-        expect(u, p + ".mem_kv", {2, u->heads, 4, u->dh});
+        expect(u, p + ".mem_kv", {2, heads, 4, u->dh});
         expect(u, p + ".norm.g", {1, dim, 1, 1});
         expect(u, p + ".to_qkv.weight", {3 * hidden, dim, 1, 1});
         expect(u, p + ".to_out.weight", {dim, hidden, 1, 1});
         expect(u, p + ".to_out.bias", {dim});
     } else {
-        expect(u, p + ".mem_kv", {2, u->heads, u->dh, 4});
+        expect(u, p + ".mem_kv", {2, heads, u->dh, 4});
         expect(u, p + ".norm.g", {1, dim, 1, 1});
         expect(u, p + ".to_qkv.weight", {3 * hidden, dim, 1, 1});
         expect(u, p + ".to_out.0.weight", {dim, hidden, 1, 1});
@@ -623,10 +626,11 @@ static int build_scale_shift(dm_unet* u) {
     return 0;
 }
 
-static int build_attn_body(dm_unet* u, AttnLayer& A, const std::string& p, int dim, bool full) {
+static int build_attn_body(dm_unet* u, AttnLayer& A, const std::string& p, int dim, bool full, int heads) {
     A.full = full;
     A.dim = dim;
-    int hidden = u->heads * u->dh;
+    A.heads = heads;
+    int hidden = heads * u->dh;
     if (up1(u, p + ".norm.g", &A.norm_g) || up1(u, p + ".mem_kv", &A.mem_kv)) return 1;
     conv_src(u, p + ".to_qkv.weight", "");
     if (make_conv(u->own, A.qkv, P(u, p + ".to_qkv.weight").data.data(), nullptr, 3 * hidden, dim, 0, 1, 1, 1, 0, false))
@@ -636,7 +640,7 @@ static int build_attn_body(dm_unet* u, AttnLayer& A, const std::string& p, int d
         if (make_conv(u->own, A.out, P(u, p + ".to_out.weight").data.data(), P(u, p + ".to_out.bias").data.data(), dim,
                       hidden, 0, 1, 1, 1, 0, false)) return 1;
         A.has16 = false;
-        if (attn16_eligible(dim, u->heads, u->dh)) {
+        if (attn16_eligible(dim, heads, u->dh)) {
             std::vector<float> wp, wo;
             attn16_pack(P(u, p + ".to_qkv.weight").data.data(), P(u, p + ".norm.g").data.data(),
                         P(u, p + ".to_out.weight").data.data(), dim, wp, wo);
@@ -650,7 +654,7 @@ static int build_attn_body(dm_unet* u, AttnLayer& A, const std::string& p, int d
         if (make_conv(u->own, A.out, P(u, p + ".to_out.0.weight").data.data(), P(u, p + ".to_out.0.bias").data.data(),
                       dim, hidden, 0, 1, 1, 1, 0, false)) return 1;
         if (up1(u, p + ".to_out.1.g", &A.out_g)) return 1;
-        if (linattn_fused_eligible(dim, u->heads, u->dh)) {
+        if (linattn_fused_eligible(dim, heads, u->dh)) {
             std::vector<float> wq, wk, wv, wo, kb;
             const HostTensor& og = P(u, p + ".to_out.1.g");
             if (linattn_fused_pack(P(u, p + ".to_qkv.weight").data.data(), P(u, p + ".norm.g").data.data(),
@@ -672,8 +676,8 @@ static int build_attn_body(dm_unet* u, AttnLayer& A, const std::string& p, int d
     return 0;
 }
 
-static int build_attn(dm_unet* u, AttnLayer& A, const std::string& p, int dim, bool full) {
-    return weight_group(u, p, [&]() -> int { return build_attn_body(u, A, p, dim, full); });
+static int build_attn(dm_unet* u, AttnLayer& A, const std::string& p, int dim, bool full, int heads) {
+    return weight_group(u, p, [&]() -> int { return build_attn_body(u, A, p, dim, full, heads); });
 }
 
 static int build_cross_body(dm_unet* u, CrossLayer& C, const std::string& p, int dim) {
@@ -732,7 +736,7 @@ static int build_all(dm_unet* u) {
         Stage& S = u->downs[i];
         if (build_resnet(u, S.b1, q + ".0", din, 0, din, ss_off)) return 1;
         if (build_resnet(u, S.b2, q + ".1", din, 0, din, ss_off)) return 1;
-        if (build_attn(u, S.attn, q + ".2", din, cfg.full_attn[i] != 0)) return 1;
+        if (build_attn(u, S.attn, q + ".2", din, cfg.full_attn[i] != 0, stage_heads(cfg, i))) return 1;
         if (weight_group(u, q + ".3", [&]() -> int {
                 conv_src(u, i < n - 1 ? q + ".3.1.weight" : q + ".3.weight", i < n - 1 ? q + ".3.1.bias" : q + ".3.bias");
                 if (i < n - 1) {
@@ -747,7 +751,7 @@ static int build_all(dm_unet* u) {
     }
     int mid = u->dims.back();
     if (build_resnet(u, u->mid1, "mid_block1", mid, 0, mid, ss_off)) return 1;
-    if (build_attn(u, u->mid_attn, "mid_attn", mid, true)) return 1;
+    if (build_attn(u, u->mid_attn, "mid_attn", mid, true, stage_heads(cfg, n - 1))) return 1;
     if (build_resnet(u, u->mid2, "mid_block2", mid, 0, mid, ss_off)) return 1;
     for (int j = 0; j < n; ++j) {
         int din = u->dims[n - 1 - j], dout = u->dims[n - j];
@@ -755,7 +759,7 @@ static int build_all(dm_unet* u) {
         Stage& S = u->ups[j];
         if (build_resnet(u, S.b1, q + ".0", dout, din, dout, ss_off)) return 1;
         if (build_resnet(u, S.b2, q + ".1", dout, din, dout, ss_off)) return 1;
-        if (build_attn(u, S.attn, q + ".2", dout, cfg.full_attn[n - 1 - j] != 0)) return 1;
+        if (build_attn(u, S.attn, q + ".2", dout, cfg.full_attn[n - 1 - j] != 0, stage_heads(cfg, n - 1 - j))) return 1;
         if (weight_group(u, q + ".3", [&]() -> int {
                 conv_src(u, j < n - 1 ? q + ".3.1.weight" : q + ".3.weight", j < n - 1 ? q + ".3.1.bias" : q + ".3.bias");
                 if (j < n - 1)
@@ -1112,7 +1116,7 @@ static int run_attn(Ctx& c, const AttnLayer& At, const float* x, int H, int W, f
     const int res_flag = add_x ? EPI_RESIDUAL : 0;
     const float* xres = add_x ? x : nullptr;
     dm_unet* u = c.u;
-    const int n = H * W, hidden = u->heads * u->dh;
+    const int n = H * W, heads = At.heads, hidden = heads * u->dh;
     const size_t rows = (size_t)c.B * n;
     if (!At.full && At.has_fused) {
         float* ws = c.A->alloc(linattn_fused_ws_floats(c.B, n));
@@ -1139,15 +1143,15 @@ static int run_attn(Ctx& c, const AttnLayer& At, const float* x, int H, int W, f
     if (At.full) {
         if (!c.dry()) {
             const float* mk = At.mem_kv;
-            const float* mv = At.mem_kv + (size_t)u->heads * 4 * u->dh;
+            const float* mv = At.mem_kv + (size_t)heads * 4 * u->dh;
             if (launch_attention_core(qkv, 3 * hidden, qkv + hidden, qkv + 2 * hidden, 3 * hidden, mk, mv, 4, o,
-                                      hidden, c.B, n, n, u->heads, u->dh, 1.0f / sqrtf((float)u->dh), c.s))
+                                      hidden, c.B, n, n, heads, u->dh, 1.0f / sqrtf((float)u->dh), c.s))
                 return 1;
         }
         if (run_conv(c, At.out, o, nullptr, H, W, y, res_flag, nullptr, nullptr, xres)) return 1;
     } else {
-        float* ctxws = c.A->alloc((size_t)c.B * u->heads * u->dh * u->dh);
-        if (!c.dry() && launch_linear_attention_core(qkv, At.mem_kv, ctxws, o, c.B, n, u->heads, u->dh, c.s)) return 1;
+        float* ctxws = c.A->alloc((size_t)c.B * heads * u->dh * u->dh);
+        if (!c.dry() && launch_linear_attention_core(qkv, At.mem_kv, ctxws, o, c.B, n, heads, u->dh, c.s)) return 1;
         if (run_conv(c, At.out, o, nullptr, H, W, y, EPI_NORM | res_flag, At.out_g, nullptr, xres)) return 1;
         c.A->release(ctxws);
     }
@@ -1387,7 +1391,7 @@ static int check_hw(dm_unet* u, int H, int W) {
 extern "C" {
 
 const char* dm_last_error(void) { return g_err.c_str(); }
-int dm_abi_version(void) { return 4; }
+int dm_abi_version(void) { return 5; }
 
 int dm_unet_create(const dm_unet_cfg* cfg, int device, dm_unet** out) {
     DM_REQUIRE(cfg && out, "null argument");
@@ -1395,6 +1399,8 @@ int dm_unet_create(const dm_unet_cfg* cfg, int device, dm_unet** out) {
     DM_REQUIRE(cfg->dim > 0 && cfg->dim % 2 == 0, "dim must be positive and even");
     DM_REQUIRE(cfg->attn_dim_head == 32, "HIP attention kernels are specialised for attn_dim_head == 32");
     DM_REQUIRE(cfg->attn_heads >= 1 && cfg->attn_heads <= 16, "attn_heads out of range");
+    for (int i = 0; i < cfg->n_stages; ++i)
+        DM_REQUIRE(cfg->attn_heads_stage[i] >= 0 && cfg->attn_heads_stage[i] <= 16, "attn_heads of a stage out of range");
     int ndev = 0;
     DM_CHECK_HIP(hipGetDeviceCount(&ndev));
     DM_REQUIRE(device >= 0 && device < ndev, "no such HIP device");
@@ -1423,7 +1429,7 @@ int dm_unet_create(const dm_unet_cfg* cfg, int device, dm_unet** out) {
         std::string q = idx("downs", i);
         expect_resnet(p, q + ".0", din, din);
         expect_resnet(p, q + ".1", din, din);
-        expect_attn(p, q + ".2", din, cfg->full_attn[i] != 0);
+        expect_attn(p, q + ".2", din, cfg->full_attn[i] != 0, stage_heads(*cfg, i));
         if (i < n - 1) {
             expect(p, q + ".3.1.weight", {dout, din * 4, 1, 1});
             expect(p, q + ".3.1.bias", {dout});
@@ -1437,7 +1443,7 @@ int dm_unet_create(const dm_unet_cfg* cfg, int device, dm_unet** out) {
         std::string q = idx("ups", j);
         expect_resnet(p, q + ".0", dout + din, dout);
         expect_resnet(p, q + ".1", dout + din, dout);
-        expect_attn(p, q + ".2", dout, cfg->full_attn[n - 1 - j] != 0);
+        expect_attn(p, q + ".2", dout, cfg->full_attn[n - 1 - j] != 0, stage_heads(*cfg, n - 1 - j));
         if (j < n - 1) {
             expect(p, q + ".3.1.weight", {din, dout, 3, 3});
             expect(p, q + ".3.1.bias", {din});
@@ -1448,7 +1454,7 @@ int dm_unet_create(const dm_unet_cfg* cfg, int device, dm_unet** out) {
     }
     int mid = u->dims.back();
     expect_resnet(p, "mid_block1", mid, mid);
-    expect_attn(p, "mid_attn", mid, true);
+    expect_attn(p, "mid_attn", mid, true, stage_heads(*cfg, n - 1));
     expect_resnet(p, "mid_block2", mid, mid);
     expect_resnet(p, "final_res_block", 2 * u->init_dim, u->init_dim);
     expect(p, "final_conv.weight", {u->out_dim, u->init_dim, 1, 1});

@@ -50,7 +50,7 @@ class UnetConfig:
     random_fourier_features: bool = False
     learned_sinusoidal_dim: int = 16
     attn_dim_head: int = 32
-    attn_heads: int = 4
+    attn_heads: object = 4  # int, or one value per stage (cast_tuple(attn_heads, num_stages), denoising_diffusion.py:294)
     full_attn: Optional[Tuple[bool, ...]] = None
     # image-conditional variant widens init_conv (denoising_diffusion_image_conditional.py:42-49)
     cond_channels: int = 0
@@ -108,8 +108,16 @@ class UnetConfig:
         return tuple(self.full_attn)
 
     @property
+    def attn_heads_(self) -> Tuple[int, ...]:
+        """Heads of each stage's attention (:294, :310, :327); ``mid_attn`` takes the last entry (:324)."""
+        h = self.attn_heads
+        out = tuple(int(v) for v in h) if isinstance(h, (tuple, list)) else (int(h),) * self.num_stages
+        assert len(out) == self.num_stages, "attn_heads needs one entry per stage"
+        return out
+
+    @property
     def hidden_dim(self) -> int:
-        return self.attn_dim_head * self.attn_heads
+        return self.attn_dim_head * self.attn_heads_[0]
 
     @property
     def downsample_factor(self) -> int:
@@ -188,7 +196,7 @@ def unet_param_spec(cfg: UnetConfig, prefix: str = "") -> ParamSpec:
         last = i >= n - 1
         spec += _resnet_spec(f"{p}downs.{i}.0", din, din, td)
         spec += _resnet_spec(f"{p}downs.{i}.1", din, din, td)
-        spec += _attn_spec(f"{p}downs.{i}.2", din, full, cfg.attn_heads, cfg.attn_dim_head)
+        spec += _attn_spec(f"{p}downs.{i}.2", din, full, cfg.attn_heads_[i], cfg.attn_dim_head)
         if not last:
             spec += [(f"{p}downs.{i}.3.1.weight", (dout, din * 4, 1, 1)), (f"{p}downs.{i}.3.1.bias", (dout,))]
         else:
@@ -198,14 +206,14 @@ def unet_param_spec(cfg: UnetConfig, prefix: str = "") -> ParamSpec:
         last = j == n - 1
         spec += _resnet_spec(f"{p}ups.{j}.0", dout + din, dout, td)
         spec += _resnet_spec(f"{p}ups.{j}.1", dout + din, dout, td)
-        spec += _attn_spec(f"{p}ups.{j}.2", dout, full, cfg.attn_heads, cfg.attn_dim_head)
+        spec += _attn_spec(f"{p}ups.{j}.2", dout, full, cfg.attn_heads_[n - 1 - j], cfg.attn_dim_head)
         if not last:
             spec += [(f"{p}ups.{j}.3.1.weight", (din, dout, 3, 3)), (f"{p}ups.{j}.3.1.bias", (din,))]
         else:
             spec += [(f"{p}ups.{j}.3.weight", (din, dout, 3, 3)), (f"{p}ups.{j}.3.bias", (din,))]
     # ModuleLists `downs` and `ups` are registered before the mid blocks (:306-307)
     spec += _resnet_spec(f"{p}mid_block1", mid, mid, td)
-    spec += _attn_spec(f"{p}mid_attn", mid, True, cfg.attn_heads, cfg.attn_dim_head)
+    spec += _attn_spec(f"{p}mid_attn", mid, True, cfg.attn_heads_[-1], cfg.attn_dim_head)
     spec += _resnet_spec(f"{p}mid_block2", mid, mid, td)
     spec += _resnet_spec(f"{p}final_res_block", cfg.init_dim_ * 2, cfg.init_dim_, td)
     spec += [

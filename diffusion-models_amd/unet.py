@@ -59,8 +59,16 @@ class Unet:
     ):
         # learned_sinusoidal_cond / random_fourier_features (denoising_diffusion.py:86-101, :271-273): forward() only --
         # DenoisingDiffusion asserts such a U-Net away (:456-457), and so does ours
-        if not isinstance(attn_heads, int) or not isinstance(attn_dim_head, int):
-            raise NotImplementedError("per-stage attention head settings are not supported by the HIP path")
+        # attn_heads / attn_dim_head: one value or one per stage (cast_tuple, :294-295).  The attention kernels are specialised
+        # for 32-wide heads (the reference's default everywhere it builds a Unet); the head COUNT is per layer.
+        if isinstance(attn_dim_head, (tuple, list)):
+            if any(int(v) != int(attn_dim_head[0]) for v in attn_dim_head) or len(attn_dim_head) != len(tuple(dim_mults)):
+                raise NotImplementedError("per-stage attn_dim_head: the HIP attention kernels take one head width (32)")
+            attn_dim_head = int(attn_dim_head[0])
+        if isinstance(attn_heads, (tuple, list)):
+            attn_heads = tuple(int(v) for v in attn_heads)
+            if len(attn_heads) != len(tuple(dim_mults)):
+                raise ValueError("attn_heads needs one entry per stage")
         self.cfg = UnetConfig(
             dim=dim, init_dim=init_dim, out_dim=out_dim, dim_mults=tuple(dim_mults), channels=channels,
             self_condition=self_condition, learned_variance=learned_variance,
@@ -94,7 +102,9 @@ class Unet:
             c.dim_mults[i] = m
         for i, f in enumerate(cfg.full_attn_):
             c.full_attn[i] = int(f)
-        c.attn_heads, c.attn_dim_head = cfg.attn_heads, cfg.attn_dim_head
+        c.attn_heads, c.attn_dim_head = cfg.attn_heads_[0], cfg.attn_dim_head
+        for i, hd in enumerate(cfg.attn_heads_):
+            c.attn_heads_stage[i] = hd
         c.text_mode = 0 if not text_condition else (2 if use_cross_attn else 1)
         c.text_emb_dim = text_emb_dim
         c.sinusoidal_theta = float(sinusoidal_pos_emb_theta)

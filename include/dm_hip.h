@@ -54,6 +54,8 @@ typedef struct dm_unet_cfg {
     int32_t learned_sinusoidal_dim; /* 0: SinusoidalPosEmb(dim, theta); > 0: RandomOrLearnedSinusoidalPosEmb of that
                                        dimension (DD/denoising_diffusion.py:86-101, parameter time_mlp.0.weights) --
                                        dm_unet_forward only: DenoisingDiffusion refuses such a U-Net (:456-457) */
+    int32_t attn_heads_stage[DM_MAX_STAGES]; /* Unet(attn_heads = (h0, h1, ..)): heads of stage i's attention (:294, :310,
+                                                :327; mid_attn takes the last stage's, :324); 0 = attn_heads */
 } dm_unet_cfg;
 
 typedef struct dm_unet dm_unet;

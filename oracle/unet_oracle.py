@@ -204,7 +204,9 @@ def unet_forward(
     assert all(d % f == 0 for d in x.shape[-2:]), (
         f"your input dimensions {tuple(x.shape[-2:])} need to be divisible by {f}, given the unet"
     )
-    heads, dh = cfg.attn_heads, cfg.attn_dim_head
+    hs = cfg.attn_heads  # one value or one per stage (cast_tuple, DD/denoising_diffusion.py:294; mid_attn: the last, :324)
+    heads = tuple(hs) if isinstance(hs, (tuple, list)) else (hs,) * cfg.num_stages
+    dh = cfg.attn_dim_head
     if cfg.self_condition:
         if x_self_cond is None:
             x_self_cond = torch.zeros_like(x)
@@ -236,7 +238,7 @@ def unet_forward(
         skips.append(x)
         x = resnet_block(sd, q + ".1", x, t, drops)
         a = full_attention if full[i] else linear_attention
-        x = a(sd, q + ".2", x, heads, dh) + x
+        x = a(sd, q + ".2", x, heads[i], dh) + x
         skips.append(x)
         if not last:
             x = downsample(sd, q + ".3", x)
@@ -248,7 +250,7 @@ def unet_forward(
     x = resnet_block(sd, p + "mid_block1", x, t, drops)
     if use_text and cfg.use_cross_attn:
         x = _apply_cross(sd, p + "cross_attn", x, text_emb)
-    x = full_attention(sd, p + "mid_attn", x, heads, dh) + x
+    x = full_attention(sd, p + "mid_attn", x, heads[-1], dh) + x
     x = resnet_block(sd, p + "mid_block2", x, t, drops)
     if use_text and cfg.use_cross_attn:
         x = _apply_cross(sd, p + "cross_attn_up", x, text_emb)
@@ -261,7 +263,7 @@ def unet_forward(
         x = torch.cat((x, skips.pop()), dim=1)
         x = resnet_block(sd, q + ".1", x, t, drops)
         a = full_attention if full[n - 1 - j] else linear_attention
-        x = a(sd, q + ".2", x, heads, dh) + x
+        x = a(sd, q + ".2", x, heads[n - 1 - j], dh) + x
         if not last:
             x = upsample(sd, q + ".3", x)
         else:

@@ -4,6 +4,9 @@
 * ``Unet(learned_sinusoidal_cond=True)`` / ``Unet(random_fourier_features=True)`` forward (DD/denoising_diffusion.py:86-101,
   :271-278): the time embedding is ``cat(t, sin(t w 2 pi), cos(t w 2 pi))`` with the parameter ``time_mlp.0.weights``.
   ``DenoisingDiffusion`` refuses such a U-Net (:456-457), so only ``Unet.forward`` is pinned.
+* ``Unet(attn_heads=(2, 4, 8))`` -- one head count per stage (``cast_tuple(attn_heads, num_stages)``, :294; the stage's
+  LinearAttention / Attention at :318 / :335, ``mid_attn`` with the last entry, :324): forward, and ``p_losses`` + ``backward()``
+  (loss and a digest of every parameter gradient, as train.pt).
 Only DATA is written."""
 from __future__ import annotations
 
@@ -16,6 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 from make_golden import import_reference, save, seeded  # noqa: E402
+from make_golden_train import digest  # noqa: E402
 
 import diffusion_models_amd as dm  # noqa: E402
 from diffusion_models_amd.spec import UnetConfig  # noqa: E402
@@ -43,6 +47,25 @@ def main():
             refused = True
         out["unet_" + key]["diffusion_refuses"] = refused
         print(key, float(y.abs().mean()), "DenoisingDiffusion refuses:", refused)
+    # per-stage head counts (dim_head 32 throughout, the default)
+    heads = (2, 4, 8)
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2, 4), channels=3, attn_heads=heads)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=52)
+    net = dd.Unet(dim=32, dim_mults=(1, 2, 4), channels=3, attn_heads=heads)
+    net.load_state_dict(sd, strict=True)
+    x = seeded((2, 3, 16, 16), 91)
+    t = torch.tensor([3, 871])
+    with torch.inference_mode():
+        y = net.eval()(x, t)
+    diff = dd.DenoisingDiffusion(net, image_size=16, timesteps=1000).train()
+    img = torch.rand((3, 3, 16, 16), generator=torch.Generator().manual_seed(92))
+    tt = torch.tensor([0, 500, 999])
+    noise = seeded((3, 3, 16, 16), 93)
+    loss = diff.p_losses(diff.normalize(img), tt, noise=noise.clone())
+    loss.backward()
+    out["unet_stage_heads"] = dict(x=x, t=t, y=y, heads=heads, img=img, tt=tt, noise=noise, loss=float(loss),
+                                   grads={k: digest(k, p.grad) for k, p in net.named_parameters()})
+    print("stage heads", float(y.abs().mean()), float(loss))
     save("r4.pt", out)
 
 

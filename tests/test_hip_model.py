@@ -66,6 +66,29 @@ def test_learned_sinusoidal_unet_forward(golden_r4, key):
         u.train()
 
 
+def test_per_stage_attention_heads(golden_r4):
+    """Unet(attn_heads=(2, 4, 8)) (cast_tuple over the stages, denoising_diffusion.py:294; mid_attn: the last entry, :324):
+    forward against the reference's output, then p_losses + backward against the reference's loss and gradient digests."""
+    from conftest import check_grad_digest
+
+    b = golden_r4["unet_stage_heads"]
+    heads = tuple(b["heads"])
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2, 4), channels=3, attn_heads=heads)
+    u = dm.Unet(dim=32, dim_mults=(1, 2, 4), channels=3, attn_heads=heads, device=DEV)
+    u.load_state_dict(dm.synth_state_dict(dm.unet_param_spec(cfg), salt=52))
+    err = rel_l2(u(b["x"].to(DEV), b["t"].to(DEV)).cpu(), b["y"])
+    print("per-stage heads forward", err)
+    assert err < FWD_TOL
+    d = dm.DenoisingDiffusion(u, image_size=16, timesteps=1000).train()
+    loss = float(d.p_losses(b["img"] * 2 - 1, b["tt"], noise=b["noise"]))
+    assert abs(loss - b["loss"]) <= 1e-4 * abs(b["loss"]), (loss, b["loss"])
+    grads = d.model.grads()
+    for name, dg in b["grads"].items():
+        check_grad_digest(name, grads[name].cpu(), dg, 2e-4)
+    with pytest.raises(NotImplementedError):
+        dm.Unet(dim=32, dim_mults=(1, 2, 4), attn_dim_head=(32, 64, 32), device=DEV)
+
+
 def test_unet_text_variants(golden_blocks):
     g = golden_blocks
     u = build_unet(salt=2, dim=32, dim_mults=(1, 2), channels=3, text_condition=True, use_cross_attn=True)

@@ -493,6 +493,27 @@ def test_learned_sinusoidal_unet_forward(golden_r4, key):
     assert rel_l2(y, b["y"]) < 1e-5
 
 
+def test_per_stage_attention_heads(golden_r4):
+    """Unet(attn_heads=(2, 4, 8)): one head count per stage (cast_tuple, DD/denoising_diffusion.py:294; mid_attn takes the last,
+    :324) -- the oracle's forward and its autograd through p_losses against the reference's own output, loss and gradients."""
+    from conftest import check_grad_digest
+    from oracle import train_oracle as to
+
+    b = golden_r4["unet_stage_heads"]
+    cfg = UnetConfig(dim=32, dim_mults=(1, 2, 4), channels=3, attn_heads=tuple(b["heads"]))
+    spec = dict(dm.unet_param_spec(cfg))
+    assert spec["downs.0.2.to_qkv.weight"][0] == 3 * 2 * 32 and spec["downs.1.2.to_qkv.weight"][0] == 3 * 4 * 32
+    assert spec["mid_attn.to_qkv.weight"][0] == 3 * 8 * 32 and spec["ups.0.2.mem_kv"] == (2, 8, 4, 32)
+    sd = dm.synth_state_dict(dm.unet_param_spec(cfg), salt=52)
+    with torch.inference_mode():
+        y = uo.unet_forward(sd, cfg, b["x"], b["t"])
+    assert rel_l2(y, b["y"]) < 1e-5
+    loss, grads = to.loss_and_grads(sd, cfg, dm.make_schedule(1000, "linear"), b["img"] * 2 - 1, b["tt"], b["noise"])
+    assert abs(loss - b["loss"]) <= 1e-5 * abs(b["loss"])
+    for name, dg in b["grads"].items():
+        check_grad_digest(name, grads[name], dg, 2e-4)
+
+
 def test_prediction_helpers_and_guided_ddim(golden_guided):
     """oracle/sampler_oracle.py: model_predictions / p_mean_variance / q_posterior with a batch of different timesteps for the
     three objectives, and ddim_sample_guided (with and without a guide), against the reference's own outputs."""
