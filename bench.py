@@ -173,11 +173,11 @@ def step_breakdown(ms_per_denoise_step: float, pmc_steps: int = 50):
     return out, src
 
 
-TRAIN_FAMILIES = (("wgrad", "wgrad_"), ("wino4", "wino4_mfma_kernel"), ("wino", "wino_mfma_kernel"),
+TRAIN_FAMILIES = (("wgrad", ("wgrad_", "thin_out_bwd")), ("wino4", "wino4_mfma_kernel"), ("wino", "wino_mfma_kernel"),
                   ("upwino", "upwino_mfma_kernel"), ("pw", "pw_mfma_kernel"), ("norm_bwd", "norm_act_bwd"),
                   ("norm_fwd", "norm_act"), ("linattn_bwd", "linattn_bwd"), ("linattn", "linattn_"), ("attn", "att"),
                   ("optimiser", ("adam_ema", "pack_", "scatter_copy", "sumsq", "clip_coef", "lerp", "rot_transpose")),
-                  ("linear", ("linear_", "mlp_rows", "colsum", "rowgrad", "act_")), ("init7", "init7_mfma_kernel"))
+                  ("linear", ("linear_", "rows_gemm", "mlp_rows", "colsum", "rowgrad", "act_")), ("init7", "init7_mfma_kernel"))
 
 
 def train_family_of(kernel: str) -> str:

@@ -1,4 +1,8 @@
+# development aid: A/B of one environment switch on the training step:  bash tools/dev/r4_ab.sh VAR   (on the GPU box)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python -m pytest tests/test_hip_train.py tests/test_hip_train_ops.py tests/test_hip_forced_dispatch.py -x -q 2>&1 | grep -v "amdgpu.ids" | tail -3
-python3 tools/train_time.py --batch 64 --steps 30 --dropout 0.1 | tail -1
-python3 tools/train_time.py --batch 16 --steps 30 | tail -1
+for rep in 1 2; do
+for B in 64 16; do
+echo "B=$B default: $(python3 tools/train_time.py --batch $B --full-only 2>&1 | tail -1 | cut -c60-100)"
+echo "B=$B $1=1:    $(env $1=1 python3 tools/train_time.py --batch $B --full-only 2>&1 | tail -1 | cut -c60-100)"
+done
+done
