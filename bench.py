@@ -98,7 +98,19 @@ def pmc_traffic(kernel: str):
     if sha != csrc_sha():
         return None, f"{os.path.basename(newest)} was collected on other kernel sources ({sha} != {csrc_sha()})"
     rows = {k.replace(" ", ""): v for k, v in doc.items() if isinstance(v, dict)}
-    row = rows.get(kernel.replace(" ", ""))
+    want = kernel.replace(" ", "")
+    row = rows.get(want)
+    if not row and want.endswith(">"):
+        # the library's profile name may carry fewer template arguments than the symbol (wino_mfma_kernel<R> times every
+        # <R, Q> instantiation): take the instantiation(s) of that prefix -- one row, or the launch-weighted mean of several
+        cand = [v for k, v in rows.items() if k.startswith(want[:-1] + ",")]
+        if len(cand) == 1:
+            row = cand[0]
+        elif cand and all("launches" in v for v in cand):
+            n = sum(v["launches"] for v in cand)
+            row = {k: sum(v[k] * v["launches"] for v in cand) / n for k in cand[0]
+                   if isinstance(cand[0][k], (int, float)) and k != "launches" and all(k in v for v in cand)}
+            row["launches"] = n
     if not row:
         return None, f"{os.path.basename(newest)} has no row for {kernel}"
     return row["fetch_bytes_per_launch_corrected"] + row["write_bytes_per_launch"], os.path.basename(newest)
