@@ -45,6 +45,8 @@ for it in range(a.n):
               cond_channels=channels if variant == "imgcond" else 0)
     if rng.random() < 0.4:  # any pattern of full / linear attention over the stages (the default: full at the last one only)
         kw["full_attn"] = tuple(rng.random() < 0.5 for _ in mults)
+    if rng.random() < 0.3:  # one head count per stage (cast_tuple(attn_heads, num_stages); mid_attn takes the last)
+        kw["attn_heads"] = tuple(rng.choice([1, 2, 3, 4, 6, 8]) for _ in mults)
     cfg = UnetConfig(dim=dim, dim_mults=mults, channels=channels, **kw)
     case = (dim, mults, channels, (H, W), B, variant)
     try:
