@@ -587,7 +587,7 @@ int wino_launch(const ConvParams& pin, hipStream_t s) {
             snprintf(name, sizeof(name), "wino<%d> 3x3 s1 %d+%d->%d @%dx%d e%d k%d g%d q%d", R, p.C0, p.C1, p.Cout, p.Ho,
                      p.Wo, p.epi, g.splits, blocks * g.splits, g.NQ);
         else
-            snprintf(name, sizeof(name), "wino_mfma_kernel<%d>", R);
+            snprintf(name, sizeof(name), "wino_mfma_kernel<%d, %d>", R, g.NQ);  // the symbol rocprofv3 reports
         if (prof::begin(name, flops, bytes, s)) return 1;
     }
     if (R == 2 ? wino_launch_r<2, 2>(p, blocks, s) : (g.NQ == 1 ? wino_launch_r<1, 1>(p, blocks, s) : wino_launch_r<1, 2>(p, blocks, s)))
