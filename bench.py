@@ -625,7 +625,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_other_configs:
         result["other_configs"] = other_configs(dev)
     if not args.no_train:  # every rank: under world > 1 the iteration holds a collective
-        tr = train_leg(dev, with_cpu=world == 1 and not args.no_cpu_baseline, world=world, rank=rank, rehearse=rehearse)
+        try:
+            tr = train_leg(dev, with_cpu=world == 1 and not args.no_cpu_baseline, world=world, rank=rank, rehearse=rehearse)
+        except Exception as e:  # noqa: BLE001 -- the headline above must still be reported (every rank takes this branch
+            # together: the leg is the same code on every rank, a failure here is not a reason to lose the sampling result)
+            if world == 1:
+                raise
+            tr = {"error": f"{type(e).__name__}: {e}"[:400]}
         if rank == 0:
             result["train_step"] = tr
 
