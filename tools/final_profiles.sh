@@ -16,11 +16,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_b8 -o 
 rm -f gpurun_out/${tag}_b8/*kernel_trace.csv; tail -1 gpurun_out/${tag}_b8.log
 echo "== vae"; python3 tools/vae_time.py > gpurun_out/${tag}_vae.txt 2>&1; tail -3 gpurun_out/${tag}_vae.txt
 echo "== training step stats (the bench.py train leg: B=64, dropout 0.1; 1 + 9 full iterations)"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_train -o s -- python3 tools/train_time.py --batch 64 --dropout 0.1 --full-only --steps 9 > gpurun_out/${tag}_train.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_train -o s -- python3 tools/train_time.py --batch 64 --dropout 0.1 --full-only --warmup 1 --steps 9 > gpurun_out/${tag}_train.log 2>&1
 rm -f gpurun_out/${tag}_train/*kernel_trace.csv; cp gpurun_out/${tag}_train/s_kernel_stats.csv profiles/${tag}_train_kernel_stats.csv
 python3 tools/train_time.py --batch 64 --dropout 0.1 --steps 20 > gpurun_out/${tag}_train_time.txt 2>&1; tail -2 gpurun_out/${tag}_train_time.txt
 echo "== training step pmc (1 + 3 full iterations)"
-export PMC_ITERS=4 PMC_CMD="python3 tools/train_time.py --batch 64 --dropout 0.1 --full-only --steps 3"
+export PMC_ITERS=4 PMC_CMD="python3 tools/train_time.py --batch 64 --dropout 0.1 --full-only --warmup 1 --steps 3"
 bash tools/pmc_run.sh ${tag}_trainpmc
 python3 tools/pmc_summary.py gpurun_out/${tag}_trainpmc > gpurun_out/${tag}_train_pmc.json
 cp gpurun_out/${tag}_train_pmc.json profiles/${tag}_train_pmc.json

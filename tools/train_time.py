@@ -13,10 +13,11 @@ import diffusion_models_amd as dm  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
-ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--steps", type=int, default=50)
+ap.add_argument("--warmup", type=int, default=10, help="untimed full iterations first (the first ones run at ramping clocks and size the workspace; profiling scripts pass 1)")
 ap.add_argument("--size", type=int, default=32)
 ap.add_argument("--dropout", type=float, default=0.0)
-ap.add_argument("--full-only", action="store_true", help="only full Trainer.train iterations: 1 warm-up + --steps (profiling)")
+ap.add_argument("--full-only", action="store_true", help="only full Trainer.train iterations: --warmup + --steps (profiling: --warmup 1)")
 ap.add_argument("--host", action="store_true", help="also print the host time to ENQUEUE an iteration")
 args = ap.parse_args()
 u = dm.Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=3, dropout=args.dropout, device="cuda:0")
@@ -34,7 +35,8 @@ if not args.full_only:
     dt = (time.perf_counter() - t0) / args.steps
     print(f"loss+backward B={args.batch} {args.size}x{args.size}: {1e3 * dt:.2f} ms/step  {args.batch / dt:.1f} images/s  (loss {float(loss):.4f})")
 ema = dm.EMA(d, beta=0.995, update_every=10)
-dm.train_step(d, [img], lr=2e-4, ema=ema)
+for _ in range(max(1, args.warmup)):
+    dm.train_step(d, [img], lr=2e-4, ema=ema)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(args.steps):
